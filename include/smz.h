@@ -1,0 +1,207 @@
+/*
+ * smz.h -- C ABI of libsmz.so, the MI355X (gfx950) batched Stochastic-MuZero search engine.
+ *
+ * This is the drop-in boundary for the reference's search hot path.  The reference (DHDev0/Stochastic-muzero) is
+ * pure Python with no FFI layer of its own; the seam it offers is the duck-typed object pair
+ *     Monte_carlo_tree_search(**cfg).run(observation, model, train) -> root      monte_carlo_tree_search.py:76-85, 311-349
+ *     Game.policy_step(root, temperature, ...) / Game.store_search_statistics(root)  game.py:179-273
+ * and each entry point below cites the reference lines it replaces.  The Python binding a maintainer would add on
+ * the reference side (ctypes) is shown in INTEGRATION.md; the binding this repo ships is stochastic-muzero_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative smz_status; smz_last_error() gives the text (thread-local);
+ *   - nothing throws across the boundary;
+ *   - every `dev` pointer is caller-owned DEVICE memory (e.g. a torch tensor's data_ptr()) that stays valid until
+ *     the work enqueued on `stream` has run; `host` pointers are ordinary host memory, read before the call returns;
+ *   - all launches are asynchronous on the caller's HIP stream (a hipStream_t passed as void*; NULL = the default
+ *     stream) and are legal inside a stream capture (no allocation, no synchronisation), EXCEPT the functions
+ *     marked [sync], which synchronise the stream / device themselves and must not be captured;
+ *   - one handle owns the structure-of-arrays node buffers, search-path buffers, MinMax statistics and the
+ *     per-tree random streams of `num_trees` independent search trees on ONE device.  A handle is not thread-safe;
+ *     distinct handles are independent.
+ *   - tree i of a handle is, by contract, the reference's single tree run under `np.random.seed(seed_i)`.
+ */
+#ifndef SMZ_H
+#define SMZ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMZ_ABI_VERSION 1
+#define SMZ_MAX_ACTIONS 32 /* action_dimension limit of this build (per-lane scratch is sized by it) */
+#define SMZ_MT_WORDS 624   /* MT19937 state words per tree */
+
+typedef enum {
+    SMZ_OK = 0,
+    SMZ_ERR_INVALID = -1,   /* bad argument / hyper-parameter (the reference raises AssertionError, mcts:148-173) */
+    SMZ_ERR_HIP = -2,       /* a HIP runtime call failed */
+    SMZ_ERR_NOMEM = -3,     /* device allocation failed */
+    SMZ_ERR_STATE = -4      /* call order violated (e.g. select before root_init) */
+} smz_status;
+
+typedef enum {
+    SMZ_RNG_MT19937_NUMPY = 0, /* per-tree numpy-legacy RandomState stream: bit-parity with the reference */
+    SMZ_RNG_PHILOX = 1         /* counter-based stream (throughput mode; same distributions, different numbers) */
+} smz_rng_mode;
+
+typedef void *smz_stream; /* hipStream_t */
+typedef struct smz_handle smz_handle;
+
+/* Hyper-parameters: the kwargs of Monte_carlo_tree_search.__init__ (monte_carlo_tree_search.py:76-85), plus the
+ * batch geometry.  Validation mirrors monte_carlo_tree_search.py:148-173. */
+typedef struct {
+    int32_t num_trees;                 /* B: independent trees (envs) on this device */
+    int32_t num_actions;               /* A: action_dimension (policy width, muzero_model.py:260) */
+    int32_t max_action_sample;         /* maxium_action_sample; children per expansion K = min(this, A) (mcts:293) */
+    int32_t hidden_size;               /* S: floats per hidden state (31 for ckpt 421, 147 for the vision nets) */
+    int32_t num_simulations;           /* mcts:82 */
+    int32_t pb_c_base;                 /* mcts:77 */
+    double pb_c_init;                  /* mcts:78 */
+    double discount;                   /* mcts:79 */
+    double root_dirichlet_alpha;       /* mcts:80, 0 < alpha <= 1 */
+    double root_exploration_fraction;  /* mcts:81 */
+    int32_t rng_mode;                  /* smz_rng_mode */
+    int32_t device;                    /* HIP device ordinal */
+} smz_config;
+
+/* One node as seen by smz_debug_dump_tree (host side, parity tests). */
+typedef struct {
+    int32_t visit_count;  /* Node.visit_count  mcts:8  */
+    float value_sum;      /* Node.value_sum    mcts:10 */
+    float reward;         /* Node.reward       mcts:13 */
+    float prior;          /* Node.prior        mcts:9 (float32 policy entry; root children: see root priors) */
+    int32_t child_base;   /* index of the first child, 0 = not expanded (children are contiguous) */
+    int32_t action;       /* key of this node in its parent's `children` dict */
+} smz_node_view;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------ */
+/* [sync] Allocates all device state for cfg->num_trees trees.  Replaces Monte_carlo_tree_search.__init__/reset
+ * (mcts:76-177).  SMZ_ERR_INVALID where the reference asserts. */
+int smz_create(const smz_config *cfg, smz_handle **out);
+/* [sync] */
+int smz_destroy(smz_handle *h);
+int smz_abi_version(void);
+const char *smz_last_error(void);
+/* Number of nodes each tree can hold: 1 + A + num_simulations * K. */
+int smz_node_capacity(const smz_handle *h);
+
+/* [sync] pb_c[n] = log((n + pb_c_base + 1)/pb_c_base) + pb_c_init for n = 0..num_simulations+1 (mcts:236).
+ * smz_create fills it with libm's log; a Python host passes the table as numpy evaluates it so that the scores
+ * are the reference's to the last bit on that machine.  `n` must be >= num_simulations + 2. */
+int smz_set_pb_c_table(smz_handle *h, const double *host_table, int n);
+
+/* ---- random streams (numpy.random.seed / get_state / set_state; used at mcts:208,220,243,254,294, game.py:213) - */
+/* Seeds tree i with host_seeds[i] (numpy `seed(int)`: init_genrand on the low 32 bits).  Asynchronous on `stream`
+ * after an internal host->device copy of the seeds that completes before return. */
+int smz_seed(smz_handle *h, const uint64_t *host_seeds, smz_stream stream);
+/* [sync] numpy get_state()/set_state() of one tree: key[624] and pos in numpy's convention (pos == 624 means
+ * "regenerate before the next draw").  Lets a single-tree caller continue the process-global numpy stream. */
+int smz_set_rng_state(smz_handle *h, int tree, const uint32_t *host_key, int pos);
+int smz_get_rng_state(smz_handle *h, int tree, uint32_t *host_key, int *pos);
+
+/* ---- the search (one call per phase of Monte_carlo_tree_search.run, mcts:311-349) ----------------------------- */
+/* Root: resets the trees and MinMaxStats, stores the root hidden state, normalises the root policy, creates all A
+ * children (consuming the draws of np.random.choice, mcts:203-211) and, when `train` and num_simulations > 0,
+ * mixes Dirichlet noise into the priors (mcts:214-225).
+ *   hidden_dev  [B,S] f32  representation_function_inference output (mcts:179-183)
+ *   policy_dev  [B,A] f32  softmaxed prediction policy (mcts:197-200; the value head's output is discarded, :319)
+ *   noise_override_dev [B,A] f64 or NULL: when given, these values replace the device-drawn Dirichlet sample
+ *     (the stream still advances exactly as if it had been drawn) -- a parity-test affordance. */
+int smz_root_init(smz_handle *h, const float *hidden_dev, const float *policy_dev, const double *noise_override_dev,
+                  int train, smz_stream stream);
+
+/* Selection: full root->leaf descent for every tree (mcts:228-267: pUCT argmax at decision-flagged nodes,
+ * prior sampling at chance-flagged nodes), recording the search path, then gathers what the networks need
+ * (mcts:270-286): any output pointer may be NULL.
+ *   parent_hidden_dev [B,S]  f32  hidden state of the leaf's parent
+ *   last_action_dev   [B]    i32  history[-1]
+ *   branch_dev        [B]    u8   parent.is_chance: 1 -> dynamics + prediction, 0 -> afterstate_dynamics +
+ *                                 afterstate_prediction (mcts:333-342)
+ *   mlp_input_dev     [B,S+A] f32 [parent hidden | one_hot(last action)] exactly as neural_network_mlp_model.py:123,205
+ *                                 concatenates it (muzero_model.py:496-509) */
+int smz_select(smz_handle *h, float *parent_hidden_dev, int32_t *last_action_dev, uint8_t *branch_dev,
+               float *mlp_input_dev, smz_stream stream);
+
+/* Expansion + backup for the leaves chosen by the last smz_select (mcts:289-308): stores hidden state and reward
+ * on the leaf (reward only on the dynamics branch), samples K children without replacement from the normalised
+ * policy, then backs the value up the recorded path updating visit counts, value sums and MinMaxStats.
+ *   hidden_dev [B,S] f32, reward_dev [B] f32 (may be NULL = 0), policy_dev [B,A] f32 (softmaxed), value_dev [B] f32 */
+int smz_expand_backup(smz_handle *h, const float *hidden_dev, const float *reward_dev, const float *policy_dev,
+                      const float *value_dev, smz_stream stream);
+
+/* Fused smz_expand_backup + the next smz_select in one launch (the two halves touch the same tree from the same
+ * lane, so no grid-wide ordering is needed).  Outputs as smz_select. */
+int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float *reward_dev, const float *policy_dev,
+                             const float *value_dev, float *parent_hidden_dev, int32_t *last_action_dev,
+                             uint8_t *branch_dev, float *mlp_input_dev, smz_stream stream);
+
+/* Root statistics: what game.py reads off the returned root (game.py:181-204).  Any pointer may be NULL.
+ *   visits_dev [B,A] i32, priors_dev [B,A] f64, root_value_dev [B] f32 (Node.value(), mcts:20-21),
+ *   child_reward_dev [B,A] f32 */
+int smz_root_stats(smz_handle *h, int32_t *visits_dev, double *priors_dev, float *root_value_dev,
+                   float *child_reward_dev, smz_stream stream);
+
+/* Post-search policy and action (Game.policy_step up to the env step, game.py:197-235, and
+ * Game.store_search_statistics, game.py:179-195); draws from each tree's stream where the reference would
+ * (game.py:212-213).  pow_table_host[v] = float64(v) ** (1/temperature), v = 0..num_simulations, as numpy
+ * evaluates game.py:208 (NULL: device pow); read before return.
+ *   action_dev [B] i32, policy_dev [B,A] f64 (Game.policies entry), child_visits_dev [B,A] f64, root_value_dev [B] f32 */
+int smz_act(smz_handle *h, double temperature, const double *pow_table_host, int32_t *action_dev, double *policy_dev,
+            double *child_visits_dev, float *root_value_dev, smz_stream stream);
+
+/* ---- head epilogues (what muzero_model.py does around the torch modules) --------------------------------------- */
+/* inverse_transform_with_support (muzero_model.py:575-591): softmax over S bins, expectation over the integer
+ * support, inverse h-transform.  logits_dev [B,S] f32 -> out_dev [B] f32. */
+int smz_support_decode(const float *logits_dev, int S, float *out_dev, int B, smz_stream stream);
+/* Softmax over the last dimension (muzero_model.py:837,855): logits_dev [B,A] f32 -> out_dev [B,A] f32. */
+int smz_policy_softmax(const float *logits_dev, int A, float *out_dev, int B, smz_stream stream);
+/* scale_to_bound_action (neural_network_mlp_model.py:349-357) on both candidate next states, then per-tree choice
+ * by `branch`, plus the reward decode of the dynamics branch:
+ *   state_dyn_dev [B,S], state_after_dev [B,S], reward_logits_dev [B,S] (pre-activation head outputs), branch_dev [B] u8
+ *   -> hidden_out_dev [B,S] (scaled), reward_out_dev [B] (0 on the afterstate branch, mcts:338-342) */
+int smz_dynamics_epilogue(const float *state_dyn_dev, const float *state_after_dev, const float *reward_logits_dev,
+                          const uint8_t *branch_dev, int S, float *hidden_out_dev, float *reward_out_dev, int B,
+                          smz_stream stream);
+/* policy softmax + value decode of the branch each tree took (muzero_model.py:837-839, 855-856):
+ *   policy_logits_{pred,after}_dev [B,A], value_logits_{pred,after}_dev [B,S], branch_dev [B] u8
+ *   -> policy_out_dev [B,A] f32, value_out_dev [B] f32 */
+int smz_prediction_epilogue(const float *policy_logits_pred_dev, const float *value_logits_pred_dev,
+                            const float *policy_logits_after_dev, const float *value_logits_after_dev,
+                            const uint8_t *branch_dev, int A, int S, float *policy_out_dev, float *value_out_dev,
+                            int B, smz_stream stream);
+
+/* ---- synthetic environment + trajectory record (self_play.py:63-98 loop body around the search) -------------- */
+/* CartPole-v1 shaped Euler step on device (float64 state, float32 observation), used for the synthetic
+ * fixed-length episodes of the benchmark: state_dev [B,4] f64 in/out, action_dev [B] i32,
+ * obs_out_dev [B,4] f32, reward_out_dev [B] f32, terminated_out_dev [B] u8 (any output may be NULL). */
+int smz_cartpole_step(double *state_dev, const int32_t *action_dev, float *obs_out_dev, float *reward_out_dev,
+                      uint8_t *terminated_out_dev, int B, smz_stream stream);
+/* Appends one env step of every tree to a fixed-length trajectory buffer laid out [T][B][F] (step-major, so one
+ * step is one contiguous, coalesced slab and a finished chunk is one message for the trajectory gather):
+ * what Game.policy_step / store_search_statistics append to their lists (game.py:193-195, 263-267).  Record of F =
+ * smz_traj_floats(obs_dim, A) float64 values:
+ *   [ observation AFTER the step (obs_dim) | reward | policy (A) | action one-hot (A) | root value | child_visits (A) ]
+ * float64 keeps Game.policies / Game.child_visits exact; float32 fields widen exactly.  step t in [0,T). */
+int smz_traj_floats(int obs_dim, int A);
+int smz_traj_pack(double *traj_dev, int T, int t, int obs_dim, int A, const float *obs_dev, const float *reward_dev,
+                  const int32_t *action_dev, const double *policy_dev, const double *child_visits_dev,
+                  const float *root_value_dev, int B, smz_stream stream);
+
+/* ---- inspection ------------------------------------------------------------------------------------------------ */
+/* [sync] Copies one tree to the host: up to `cap` nodes into `nodes`; minmax_out[2] = {min, max} (may be NULL);
+ * path_out (cap_path entries) / path_len_out = the last recorded search path; root_priors_out [A] f64.
+ * Returns the number of allocated nodes (>= 0) or a negative status. */
+int smz_debug_dump_tree(smz_handle *h, int tree, smz_node_view *nodes, int cap, float *minmax_out, int32_t *path_out,
+                        int cap_path, int32_t *path_len_out, double *root_priors_out);
+/* Per-level counters accumulated by smz_select since the last reset (device-side atomics, off by default):
+ * levels_out[0] = decision levels, [1] = chance levels, [2] = descents, [3] = children scored.  [sync] */
+int smz_enable_stats(smz_handle *h, int on);
+int smz_read_stats(smz_handle *h, uint64_t levels_out[4], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMZ_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libsmz.so (the C ABI declared in include/smz.h).
+
+There is no fallback: if the HIP library is missing or was not built, importing the engine fails loudly.
+Build it with `python __graft_entry__.py build` (or `make -C stochastic-muzero_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmz.so")
+
+SMZ_OK, SMZ_ERR_INVALID, SMZ_ERR_HIP, SMZ_ERR_NOMEM, SMZ_ERR_STATE = 0, -1, -2, -3, -4
+RNG_MT19937_NUMPY, RNG_PHILOX = 0, 1
+MAX_ACTIONS = 32
+
+
+class SmzError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libsmz error {code}: {text}")
+        self.code = code
+
+
+class Config(C.Structure):
+    """smz_config (include/smz.h) -- kwargs of Monte_carlo_tree_search.__init__ + batch geometry."""
+    _fields_ = [("num_trees", C.c_int32), ("num_actions", C.c_int32), ("max_action_sample", C.c_int32),
+                ("hidden_size", C.c_int32), ("num_simulations", C.c_int32), ("pb_c_base", C.c_int32),
+                ("pb_c_init", C.c_double), ("discount", C.c_double), ("root_dirichlet_alpha", C.c_double),
+                ("root_exploration_fraction", C.c_double), ("rng_mode", C.c_int32), ("device", C.c_int32)]
+
+
+class NodeView(C.Structure):
+    _fields_ = [("visit_count", C.c_int32), ("value_sum", C.c_float), ("reward", C.c_float), ("prior", C.c_float),
+                ("child_base", C.c_int32), ("action", C.c_int32)]
+
+
+_P = C.c_void_p
+# every exported symbol of include/smz.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "smz_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "smz_destroy": (C.c_int, [_P]),
+    "smz_abi_version": (C.c_int, []),
+    "smz_last_error": (C.c_char_p, []),
+    "smz_node_capacity": (C.c_int, [_P]),
+    "smz_set_pb_c_table": (C.c_int, [_P, _P, C.c_int]),
+    "smz_seed": (C.c_int, [_P, _P, _P]),
+    "smz_set_rng_state": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "smz_get_rng_state": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int)]),
+    "smz_root_init": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
+    "smz_select": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "smz_expand_backup": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "smz_expand_backup_select": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "smz_root_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "smz_act": (C.c_int, [_P, C.c_double, _P, _P, _P, _P, _P, _P]),
+    "smz_support_decode": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
+    "smz_policy_softmax": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
+    "smz_dynamics_epilogue": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "smz_prediction_epilogue": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
+    "smz_cartpole_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
+    "smz_traj_floats": (C.c_int, [C.c_int, C.c_int]),
+    "smz_traj_pack": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "smz_debug_dump_tree": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int32), _P]),
+    "smz_enable_stats": (C.c_int, [_P, C.c_int]),
+    "smz_read_stats": (C.c_int, [_P, _P, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libsmz.so and declares every signature; raises if the library is absent (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the search engine.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if lib.smz_abi_version() != 1:
+            raise RuntimeError("libsmz.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise SmzError(rc, load().smz_last_error().decode("utf-8", "replace"))
+    return rc

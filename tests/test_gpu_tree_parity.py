@@ -1,0 +1,281 @@
+"""GPU parity proper: the HIP search kernels (through the C ABI) against golden vectors produced by the
+reference itself, and against the CPU oracle on seeded random inputs.  Bit-exact unless a tolerance is written."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise_from_oracle(cfg, data):
+    """Dirichlet noise as the reference drew it (via the oracle, which is pinned bit-exactly to numpy):
+    used as the override that removes the device-libm dependency from the prior comparison."""
+    import orc
+    B, A = data["root_policy"].shape
+    K = min(int(cfg["maxium_action_sample"]), A)
+    out = np.zeros((B, A), np.float64)
+    for i in range(B):
+        c = orc.make_cfg(A, K, 0, int(cfg["num_simulations"]), alpha=float(cfg["root_dirichlet_alpha"]),
+                         frac=float(cfg["root_exploration_fraction"]))
+        t = orc.Tree(c); t.seed(int(data["seed"][i]))
+        out[i] = t.root_init(data["root_policy"][i], train=bool(data["train"][i]))
+    return out
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name", gu.SEARCH_FIXTURES)
+def test_tape_driven_search_matches_reference(name, fused):
+    """Device-drawn Dirichlet noise: everything integer is exact; float64 root priors to 1e-13 relative (the
+    device log/pow are not glibc's); the number of exactly equal priors is reported."""
+    import gpu_harness as gh
+    eng, cfg, data = gh.drive_fixture(name, fused=fused)
+    gh.check_fixture_outputs(eng, cfg, data, prior_exact=False)
+    pri = eng.root_stats()[1].cpu().numpy()
+    exact = int((pri == data["root_priors"]).sum())
+    print(f"[{name}] root priors bit-identical: {exact}/{pri.size}")
+
+
+@pytest.mark.parametrize("name", gu.SEARCH_FIXTURES)
+def test_tape_driven_search_exact_with_reference_noise(name):
+    """Same replay with the reference's Dirichlet sample injected: every output bit-exact, priors included."""
+    import gpu_harness as gh
+    cfg, data = gu.load(name)
+    eng, cfg, data = gh.drive_fixture(name, noise_override=_noise_from_oracle(cfg, data))
+    gh.check_fixture_outputs(eng, cfg, data, prior_exact=True)
+
+
+@pytest.mark.parametrize("T", gu.TEMPERATURES)
+@pytest.mark.parametrize("name", gu.SEARCH_FIXTURES)
+def test_post_search_policy_and_action(name, T):
+    """game.py:197-232 and :179-195 on the device (smz_act)."""
+    import gpu_harness as gh
+    eng, cfg, data = gh.drive_fixture(name, check_inputs=False)
+    action, policy, child_visits, root_value = eng.act(T)
+    torch.cuda.synchronize()
+    k = f"T{T}"
+    assert np.array_equal(action.cpu().numpy(), data[k + "_action"])
+    sims = int(cfg["num_simulations"])
+    if sims >= 2:   # policies built from integer visit counts (and the numpy pow table): exact
+        assert np.array_equal(policy.cpu().numpy(), data[k + "_policy"])
+    else:           # built from float64 priors (device Dirichlet / device pow): 1e-12
+        np.testing.assert_allclose(policy.cpu().numpy(), data[k + "_policy"], rtol=1e-12)
+    if sims >= 3:
+        assert np.array_equal(child_visits.cpu().numpy(), data[k + "_child_visits"])
+    else:
+        np.testing.assert_allclose(child_visits.cpu().numpy(), data[k + "_child_visits"], rtol=1e-12)
+    assert np.array_equal(root_value.cpu().numpy(), data[k + "_root_value"])
+    for i in range(data["seed"].shape[0]):
+        key, pos = eng.get_rng_state(i)
+        rs = np.random.RandomState(0); rs.set_state(("MT19937", key, pos, 0, 0.0))
+        assert rs.random_sample() == data[k + "_probe"][i]
+
+
+@pytest.mark.parametrize("name", gu.SELFPLAY_FIXTURES)
+def test_whole_game_single_tree(name):
+    """The reference's own play_game (self_play.py:63-98), B = 1: one stream across search -> action -> search."""
+    import gpu_harness as gh
+    cfg, data = gu.load(name)
+    steps = data["obs"].shape[0]
+    T = float(data["temperature"])
+    sims = int(cfg["num_simulations"])
+    A = data["root_policy"].shape[-1]; S = data["root_hidden"].shape[-1]
+    eng = gh.make_engine(cfg, A, S, sims, 1)
+    eng.seed(np.array([int(data["seed"])], np.uint64))
+    for i in range(steps):
+        eng.root_init(gh.dev(data["root_hidden"][i][None]), gh.dev(data["root_policy"][i][None]), train=True)
+        for s in range(sims):
+            ph, la, br, _ = eng.select()
+            torch.cuda.synchronize()
+            assert int(br[0]) == data["tape_branch"][i][s] and int(la[0]) == data["tape_action"][i][s]
+            assert np.array_equal(ph.cpu().numpy()[0], data["tape_hidden_in"][i][s])
+            eng.expand_backup(gh.dev(data["tape_hidden_out"][i][s][None]), gh.dev(data["tape_reward"][i][s][None]),
+                              gh.dev(data["tape_policy"][i][s][None]), gh.dev(data["tape_value"][i][s][None]))
+        visits, priors, rv, _ = eng.root_stats()
+        action, policy, child_visits, root_value = eng.act(T)
+        torch.cuda.synchronize()
+        assert np.array_equal(visits.cpu().numpy()[0], data["root_visits"][i])
+        np.testing.assert_allclose(priors.cpu().numpy()[0], data["root_priors"][i], rtol=1e-13)
+        assert int(action[0]) == data["game_actions"][i]
+        assert np.array_equal(policy.cpu().numpy()[0], data["game_policies"][i])
+        assert np.array_equal(child_visits.cpu().numpy()[0], data["game_child_visits"][i])
+        assert np.float32(root_value[0].item()) == data["game_root_values"][i]
+    key, pos = eng.get_rng_state(0)
+    rs = np.random.RandomState(0); rs.set_state(("MT19937", key, pos, 0, 0.0))
+    assert rs.random_sample() == data["probe"]
+
+
+def test_rng_state_roundtrip_with_numpy():
+    """smz_set_rng_state / smz_get_rng_state speak numpy's get_state()/set_state() convention at every pos."""
+    import gpu_harness as gh
+    cfg = dict(maxium_action_sample=2, pb_c_base=19652, pb_c_init=1.25, discount=0.99, root_dirichlet_alpha=0.25,
+               root_exploration_fraction=0.25)
+    eng = gh.make_engine(cfg, 2, 4, 6, 8)
+    rs = np.random.RandomState(123)
+    for tree, burn in enumerate([0, 1, 2, 311, 312, 623, 624 // 2 * 3, 1000]):
+        rs2 = np.random.RandomState(1000 + tree)
+        if burn:
+            rs2.random_sample(burn)
+        _, key, pos, *_ = rs2.get_state()
+        eng.set_rng_state(tree, key, pos)
+        k2, p2 = eng.get_rng_state(tree)
+        assert p2 == pos and np.array_equal(k2, key)
+    # consume draws on the device (a search step) and continue in numpy from the exported state
+    B = 8
+    pol = torch.full((B, 2), 0.5, device="cuda"); hid = torch.zeros(B, 4, device="cuda")
+    expected = []
+    for tree in range(B):
+        key, pos = eng.get_rng_state(tree)
+        r = np.random.RandomState(0); r.set_state(("MT19937", key, pos, 0, 0.0))
+        p = (np.full(2, 0.5, np.float32) + 1e-12); p = p / p.sum()
+        r.choice(2, 2, p=p, replace=False); r.dirichlet([0.25] * 2)
+        expected.append(r.random_sample())
+    eng.root_init(hid, pol, train=True)
+    for tree in range(B):
+        key, pos = eng.get_rng_state(tree)
+        r = np.random.RandomState(0); r.set_state(("MT19937", key, pos, 0, 0.0))
+        assert r.random_sample() == expected[tree]
+
+
+@pytest.mark.parametrize("A,K,S,sims,B", [(2, 2, 31, 50, 512), (4, 2, 31, 50, 256), (4, 4, 8, 30, 256),
+                                           (11, 9, 16, 20, 128), (18, 5, 3, 16, 128), (32, 32, 4, 6, 64),
+                                           (3, 1, 5, 40, 100), (2, 2, 0, 20, 70), (1, 1, 2, 12, 65)])
+def test_random_tapes_against_oracle(A, K, S, sims, B):
+    """Seeded synthetic network outputs, device vs CPU oracle tree by tree (sizes the oracle finishes in seconds;
+    ragged B, hidden_size 0, single action, K = 1 and K = A = SMZ_MAX_ACTIONS included)."""
+    import gpu_harness as gh
+    import orc
+    cfg = dict(maxium_action_sample=K, pb_c_base=19652, pb_c_init=1.25, discount=0.997, root_dirichlet_alpha=0.3,
+               root_exploration_fraction=0.25)
+    rs = np.random.RandomState(A * 1000 + K)
+    eng = gh.make_engine(cfg, A, S, sims, B)
+    seeds = rs.randint(0, 2**32 - 1, size=B, dtype=np.uint64)
+    eng.seed(seeds)
+    trees = []
+    for i in range(B):
+        t = orc.Tree(orc.make_cfg(A, K, S, sims, discount=0.997, alpha=0.3, frac=0.25)); t.seed(int(seeds[i]))
+        trees.append(t)
+
+    def rand_policy():
+        x = rs.randn(B, A) * rs.choice([0.3, 1.0, 5.0], size=(B, 1))
+        e = np.exp(x - x.max(1, keepdims=True))
+        return (e / e.sum(1, keepdims=True)).astype(np.float32)
+    hid0 = rs.rand(B, max(S, 1)).astype(np.float32)[:, :S] if S else np.zeros((B, 0), np.float32)
+    pol0 = rand_policy()
+    noise = np.stack([trees[i].root_init(pol0[i], hidden=hid0[i] if S else None, train=True) for i in range(B)])
+    eng.root_init(gh.dev(hid0) if S else None, gh.dev(pol0), train=True, noise_override=gh.dev(noise))
+    for s in range(sims):
+        ph, la, br, xin = eng.select()
+        torch.cuda.synchronize()
+        exp = [trees[i].select(want_hidden=True) for i in range(B)]
+        assert np.array_equal(la.cpu().numpy(), np.array([e[2] for e in exp], np.int32)), f"sim {s}"
+        assert np.array_equal(br.cpu().numpy(), np.array([e[3] for e in exp], np.uint8)), f"sim {s}"
+        if S:
+            assert np.array_equal(ph.cpu().numpy(), np.stack([e[4][:S] for e in exp])), f"sim {s}"
+        h = rs.rand(B, S).astype(np.float32) if S else np.zeros((B, 0), np.float32)
+        rw = rs.randn(B).astype(np.float32); val = (rs.randn(B) * 3).astype(np.float32); pol = rand_policy()
+        for i in range(B):
+            trees[i].expand_backup(pol[i], val[i], reward=rw[i], hidden=h[i] if S else None)
+        eng.expand_backup(gh.dev(h) if S else None, gh.dev(rw), gh.dev(pol), gh.dev(val))
+    visits, priors, rv, cr = eng.root_stats()
+    torch.cuda.synchronize()
+    for i in range(B):
+        v, p, r, c = trees[i].root_stats()
+        assert np.array_equal(visits[i].cpu().numpy(), v) and np.array_equal(priors[i].cpu().numpy(), p)
+        assert np.float32(rv[i].item()) == r and np.array_equal(cr[i].cpu().numpy(), c)
+    for i in range(0, B, max(1, B // 16)):
+        d, o = eng.dump_tree(i), trees[i].dump()
+        n = o["n_nodes"]
+        assert d["n_nodes"] == n
+        for f in ("visit", "value_sum", "reward", "prior", "child_base", "action"):
+            assert np.array_equal(d[f][:n], o[f][:n]), (i, f)
+        assert np.array_equal(d["minmax"], o["minmax"])
+    for T in (0.0, 0.25, 1.0, 0.5):
+        action, policy, child_visits, root_value = eng.act(T)
+        torch.cuda.synchronize()
+        for i in range(B):
+            a, p, c, r = trees[i].act(T)
+            assert int(action[i]) == a, (T, i)
+            assert np.array_equal(policy[i].cpu().numpy(), p) and np.array_equal(child_visits[i].cpu().numpy(), c)
+
+
+def test_full_size_properties_and_shard_invariance():
+    """BASELINE config-2 size (4096 trees x 50 sims, A 2, S 31): size-independent properties, run-to-run determinism,
+    and shard invariance (a tree's result does not depend on which batch / rank it ran in)."""
+    import gpu_harness as gh
+    cfg = dict(maxium_action_sample=2, pb_c_base=19652, pb_c_init=1.25, discount=0.999, root_dirichlet_alpha=0.25,
+               root_exploration_fraction=0.1)
+    B, A, S, sims = 4096, 2, 31, 50
+
+    def run(lo, hi, fused):
+        n = hi - lo
+        g = torch.Generator(device="cpu"); g.manual_seed(5)
+        hid0 = torch.rand(B, S, generator=g)[lo:hi].cuda().contiguous()
+        pol0 = torch.softmax(torch.randn(B, A, generator=g), -1)[lo:hi].cuda().contiguous()
+        eng = gh.make_engine(cfg, A, S, sims, n)
+        eng.seed(np.arange(lo, hi, dtype=np.uint64))
+        eng.root_init(hid0, pol0, train=True)
+        ph, la, br, xin = eng.select()
+        for s in range(sims):
+            gs = torch.Generator(device="cpu"); gs.manual_seed(100 + s)
+            h = torch.rand(B, S, generator=gs)[lo:hi].cuda().contiguous()
+            pol = torch.softmax(2 * torch.randn(B, A, generator=gs), -1)[lo:hi].cuda().contiguous()
+            val = torch.randn(B, generator=gs)[lo:hi].cuda().contiguous()
+            rw = torch.randn(B, generator=gs)[lo:hi].cuda().contiguous()
+            # make the "network" depend on what select produced, so a wrong gather changes the outcome
+            val = (val + ph[:, 0] + la.float() * 0.1).contiguous()
+            if fused and s + 1 < sims:
+                ph, la, br, xin = eng.expand_backup_select(h, rw, pol, val)
+            else:
+                eng.expand_backup(h, rw, pol, val)
+                if s + 1 < sims:
+                    ph, la, br, xin = eng.select()
+        visits, priors, rv, _ = eng.root_stats()
+        action, policy, cv, _ = eng.act(1.0)
+        torch.cuda.synchronize()
+        out = dict(visits=visits.cpu().numpy().copy(), priors=priors.cpu().numpy().copy(), rv=rv.cpu().numpy().copy(),
+                   action=action.cpu().numpy().copy(), policy=policy.cpu().numpy().copy())
+        d = eng.dump_tree(n - 1)
+        return out, d
+
+    full, d = run(0, B, fused=False)
+    assert (full["visits"].sum(1) == sims).all()
+    assert d["n_nodes"] == 1 + A + sims * 2 and d["visit"][0] == sims
+    assert np.isfinite(full["rv"]).all() and np.allclose(full["policy"].sum(1), 1.0)
+    kids = d["child_base"][d["child_base"] > 0]
+    assert len(set(kids.tolist())) == len(kids)            # every expanded node owns a distinct child block
+    again, _ = run(0, B, fused=True)                          # determinism + fused kernel equivalence
+    for k in full:
+        assert np.array_equal(full[k], again[k]), k
+    lo, hi = 1024, 1024 + 1000                                # a ragged shard, as another rank would hold it
+    part, _ = run(lo, hi, fused=False)
+    for k in full:
+        assert np.array_equal(full[k][lo:hi], part[k]), k
+
+
+def test_create_rejects_what_the_reference_asserts():
+    """monte_carlo_tree_search.py:148-173 -> SMZ_ERR_INVALID."""
+    import stochastic_muzero_amd as smz
+    ok = dict(num_trees=4, num_actions=2, hidden_size=3, num_simulations=5)
+    for bad in (dict(pb_c_base=0), dict(pb_c_init=-1.0), dict(discount=-0.1), dict(root_dirichlet_alpha=1.5),
+                dict(root_exploration_fraction=-0.1), dict(maxium_action_sample=0), dict(num_simulations=-1),
+                dict(num_actions=0), dict(num_actions=33), dict(num_trees=0)):
+        with pytest.raises(smz._lib.SmzError) as e:
+            smz.SearchEngine(**{**ok, **bad})
+        assert e.value.code == smz._lib.SMZ_ERR_INVALID
+    eng = smz.SearchEngine(**ok)
+    with pytest.raises(smz._lib.SmzError) as e:
+        eng.select()
+    assert e.value.code == smz._lib.SMZ_ERR_STATE
+
+
+def test_zero_simulations_and_eval_mode():
+    """num_simulations == 0 forces train off (mcts:215-216): priors stay the float32 policy, visits 0, value 0."""
+    import gpu_harness as gh
+    eng, cfg, data = gh.drive_fixture("ckpt421_sims0")
+    gh.check_fixture_outputs(eng, cfg, data, prior_exact=True)
+    eng, cfg, data = gh.drive_fixture("ckpt421_sims25_notrain")
+    gh.check_fixture_outputs(eng, cfg, data, prior_exact=True)
