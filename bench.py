@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- MCTS simulations/sec of the batched self-play engine (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+A "step" is ONE env step of every environment of this rank: root inference, num_simulations x (select -> six-head
+evaluation -> expand + backup), action selection (smz_act), env step and trajectory record -- the loop body of
+self_play.py:79-94 for 4096 envs at once.  Workload at N=1 = BASELINE.json configs[1]: CartPole-v1 shaped synthetic
+episodes, checkpoint-421 MLP heads (S31/H64/L0), 4096 envs x 50 simulations, per-tree numpy-legacy MT19937 streams
+(parity mode, the mode the parity tests pin).  Inputs (weights, env state, trees) are resident in HBM before the
+timed region.  N > 1: each rank owns 4096 envs (weak scaling), and the finished K-step trajectory chunk is gathered
+to rank 0 over RCCL inside the timed region.
+
+The JSON line also carries
+  roofline     -- the dominant tree kernel's algorithmic bytes (SURVEY.md 8d formula evaluated on this run's own
+                  level histogram) / its mean launch duration measured with events on the launching stream;
+  cpu_baseline -- the CPU oracle (oracle/smz_oracle.c, plain-C heads, one game per thread) timed on this box's host
+                  cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (weights fixture, env kind, obs, A, K, sims)
+    "cartpole_mlp_4096x50": dict(weights="weights_ckpt421.npz", env="cartpole", obs=4, A=2, K=2, sims=50, envs=4096),
+    "lunarlander_mlp_4096x50": dict(weights="weights_lunar_L0.npz", env="synthetic", obs=8, A=4, K=2, sims=50, envs=4096),
+    "cartpole_mlp_4096x100": dict(weights="weights_ckpt421.npz", env="cartpole", obs=4, A=2, K=2, sims=100, envs=4096),
+}
+
+
+def algorithmic_bytes(stats, A, K, S, launches):
+    """bytes per simulation per tree for select (K2) and expand+backup (K5), evaluated on the
+    measured level histogram.  Returns (k2, k5) in bytes per tree per simulation."""
+    desc = max(1, stats["descents"])
+    dec = stats["decision_levels"] / desc          # decision-flag levels per descent (includes the root level)
+    ch = stats["chance_levels"] / desc
+    depth = dec + ch
+    k2 = (12 + 16 * A + 4 * A) + max(0.0, dec - 1) * (12 + 16 * K) + ch * (12 + 4 * K) + 8 + 4 * depth + (12 + 4 * S)
+    k5 = K * 20 + 4 * S + 4 + (depth + 1) * 20 + 16
+    return k2, k5, depth
+
+
+def cpu_baseline(wl, weights_path, seconds_target=12.0):
+    import orc
+    w = orc.MlpWeights.from_npz(weights_path)
+    cores = os.cpu_count() or 1
+    cfg = orc.make_cfg(wl["A"], wl["K"], w.dims["S"], wl["sims"], discount=0.999, alpha=0.25, frac=0.1)
+    steps = 4
+    n_env = cores
+    rs = np.random.RandomState(0)
+
+    def run(n_env):
+        obs0 = rs.uniform(-0.05, 0.05, (n_env, 4))
+        t0 = time.perf_counter()
+        out = orc.selfplay_cartpole(cfg, w, obs0, np.arange(n_env, dtype=np.uint32), steps, temperature=1.0,
+                                    train=True, threads=cores, record=False)
+        return out["simulations"], time.perf_counter() - t0
+    sims, dt = run(n_env)                                   # calibration
+    rate = sims / dt
+    n_env = int(max(cores, min(4096, (rate * seconds_target) / (steps * wl["sims"]))))
+    n_env -= n_env % cores
+    sims, dt = run(max(cores, n_env))
+    return dict(value=sims / dt, unit="simulations/s", cores=cores, kind="port",
+                sample=f"{max(cores, n_env)} envs x {steps} steps x {wl['sims']} sims, CartPole synthetic, C oracle with plain-C "
+                       f"MLP heads, {cores} threads (one game per thread), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cartpole_mlp_4096x50", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the workload's)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--temperature", type=float, default=1.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the search engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import stochastic_muzero_amd as smz  # noqa: F401
+    from importlib import import_module
+    mcts_mod = import_module("stochastic-muzero_amd.mcts")
+    model_mod = import_module("stochastic-muzero_amd.model")
+    envs_mod = import_module("stochastic-muzero_amd.envs")
+    sp = import_module("stochastic-muzero_amd.selfplay")
+    gather_mod = import_module("stochastic-muzero_amd.gather")
+
+    wl = dict(WORKLOADS[args.workload])
+    B = args.envs or wl["envs"]
+    wpath = os.path.join(ROOT, "tests", "golden", wl["weights"])
+    model = model_mod.Muzero.from_arrays(wpath)          # trained ckpt-421 weights exported as plain arrays
+    heads = model.heads(dev)
+    total = B * world
+    lo = rank * B
+    if wl["env"] == "cartpole":
+        env = envs_mod.CartPoleVec(B, dev, seed=0, first_env=lo, total_envs=total)
+    else:
+        env = envs_mod.SyntheticVec(B, wl["obs"], wl["A"], dev, seed=0, first_env=lo, total_envs=total)
+    mcts = mcts_mod.BatchedMCTS(B, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
+                                root_dirichlet_alpha=0.25, root_exploration_fraction=0.1, device=local_rank,
+                                use_graph=not args.no_graph, fused=True)
+    mcts.seed(np.arange(lo, lo + B, dtype=np.uint64))
+    env.reset()
+    T = max(args.steps, args.warmup, 1)
+    chunk = sp.TrajectoryChunk(T, B, env.obs_dim, env.num_actions, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    sp.play_games(env, heads, mcts, args.temperature, args.warmup, chunk=chunk)           # W untimed warm-up steps
+    barrier()
+    t0 = time.perf_counter()
+    sp.play_games(env, heads, mcts, args.temperature, args.steps, chunk=chunk)            # EXACTLY K timed steps
+    if world > 1:
+        gather_mod.gather_to_learner(chunk.data[:args.steps])                            # trajectories -> learner rank
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    sims_total = total * wl["sims"] * args.steps
+    out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs x 50 sims",
+           "value": sims_total / dt, "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32 tree values / f64 pUCT scores / i32 counts; f32 heads",
+           "data": "synthetic (CartPole-shaped Euler env, fixed-length episodes; checkpoint-421 weights)",
+           "config": {"workload": args.workload, "envs_per_gpu": B, "num_simulations": wl["sims"],
+                      "actions": wl["A"], "children_per_expansion": wl["K"], "hidden_floats": model.state_dimension,
+                      "rng": "per-tree MT19937 (numpy-legacy, parity mode)", "hip_graph": not args.no_graph,
+                      "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}}
+
+    # ---- roofline of the dominant tree kernel (rank 0) --------------------------------------------------------
+    if rank == 0 and not args.no_roofline:
+        eng = mcts.engine
+        S, A, K = eng.S, eng.A, eng.K
+        # (1) level histogram of this workload (stats atomics on; not timed)
+        eng.enable_stats(True)
+        eng.read_stats(reset=True)
+        mcts_e = mcts_mod.BatchedMCTS(B, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
+                                      root_dirichlet_alpha=0.25, root_exploration_fraction=0.1, device=local_rank,
+                                      use_graph=False, fused=True)
+        mcts_e.engine = eng
+        mcts_e._search(env.obs, heads, True)
+        stats = eng.read_stats(reset=True)
+        eng.enable_stats(False)
+        k2, k5, depth = algorithmic_bytes(stats, A, K, S, wl["sims"])
+        # (2) mean duration of the fused expand+backup+select launch: events on the launching stream, eager replay of
+        #     the same search (each launch bracketed), over the same number of steps as the timed region
+        durs = []
+        hidden, policy = heads.initial(env.obs)
+        for _ in range(max(1, min(args.steps, 4))):
+            eng.root_init(hidden, policy, train=True)
+            eng.select(want_parent_hidden=False)
+            for s in range(wl["sims"] - 1):
+                o = heads.recurrent(eng)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                eng.expand_backup_select(*o, want_parent_hidden=False)
+                e1.record()
+                durs.append((e0, e1))
+            eng.expand_backup(*heads.recurrent(eng))
+        torch.cuda.synchronize(dev)
+        ms = np.array([a.elapsed_time(b) for a, b in durs])
+        mean_us = float(ms.mean() * 1e3)
+        bytes_launch = (k2 + k5) * B
+        achieved = bytes_launch / (mean_us * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_expand_backup<MAXA,true> (expand + backup + next select)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "bytes_per_launch": bytes_launch, "mean_launch_us": mean_us,
+                           "median_launch_us": float(np.median(ms) * 1e3), "launches_timed": int(ms.size),
+                           "bytes_per_tree_select": k2, "bytes_per_tree_expand_backup": k5, "mean_depth": depth,
+                           "method": "event pairs on the launching (torch current) stream around each launch, eager "
+                                     "replay of the same search after the timed region"}
+    if rank == 0 and not args.no_cpu_baseline and wl["env"] == "cartpole":
+        out["cpu_baseline"] = cpu_baseline(wl, wpath)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,6 +102,11 @@ int smz_seed(smz_handle *h, const uint64_t *host_seeds, smz_stream stream);
 int smz_set_rng_state(smz_handle *h, int tree, const uint32_t *host_key, int pos);
 int smz_get_rng_state(smz_handle *h, int tree, uint32_t *host_key, int *pos);
 
+/* Asynchronous device-side snapshot / restore of ALL trees' streams (one backup slot per handle).  Lets a caller
+ * run throw-away warm-up searches (e.g. before capturing a HIP graph) without disturbing the per-tree streams. */
+int smz_rng_snapshot(smz_handle *h, smz_stream stream);
+int smz_rng_restore(smz_handle *h, smz_stream stream);
+
 /* ---- the search (one call per phase of Monte_carlo_tree_search.run, mcts:311-349) ----------------------------- */
 /* Root: resets the trees and MinMaxStats, stores the root hidden state, normalises the root policy, creates all A
  * children (consuming the draws of np.random.choice, mcts:203-211) and, when `train` and num_simulations > 0,
@@ -158,18 +163,20 @@ int smz_act(smz_handle *h, double temperature, const double *pow_table_host, int
 int smz_support_decode(const float *logits_dev, int S, float *out_dev, int B, smz_stream stream);
 /* Softmax over the last dimension (muzero_model.py:837,855): logits_dev [B,A] f32 -> out_dev [B,A] f32. */
 int smz_policy_softmax(const float *logits_dev, int A, float *out_dev, int B, smz_stream stream);
-/* scale_to_bound_action (neural_network_mlp_model.py:349-357) on both candidate next states, then per-tree choice
- * by `branch`, plus the reward decode of the dynamics branch:
- *   state_dyn_dev [B,S], state_after_dev [B,S], reward_logits_dev [B,S] (pre-activation head outputs), branch_dev [B] u8
- *   -> hidden_out_dev [B,S] (scaled), reward_out_dev [B] (0 on the afterstate branch, mcts:338-342) */
+/* scale_to_bound_action (neural_network_mlp_model.py:349-357) on the candidate next state of the branch each tree
+ * took, plus the reward decode of the dynamics branch.  The three inputs are row-major with a common row stride
+ * `ld` (in floats, >= S) so that they may be column slices of one fused GEMM output:
+ *   state_dyn_dev, state_after_dev, reward_logits_dev: [B] rows of S pre-activation head outputs; branch_dev [B] u8
+ *   -> hidden_out_dev [B,S] contiguous (scaled), reward_out_dev [B] (0 on the afterstate branch, mcts:338-342) */
 int smz_dynamics_epilogue(const float *state_dyn_dev, const float *state_after_dev, const float *reward_logits_dev,
-                          const uint8_t *branch_dev, int S, float *hidden_out_dev, float *reward_out_dev, int B,
+                          int ld, const uint8_t *branch_dev, int S, float *hidden_out_dev, float *reward_out_dev, int B,
                           smz_stream stream);
-/* policy softmax + value decode of the branch each tree took (muzero_model.py:837-839, 855-856):
- *   policy_logits_{pred,after}_dev [B,A], value_logits_{pred,after}_dev [B,S], branch_dev [B] u8
- *   -> policy_out_dev [B,A] f32, value_out_dev [B] f32 */
+/* policy softmax + value decode of the branch each tree took (muzero_model.py:837-839, 855-856); inputs row-major
+ * with common row stride `ld` floats:
+ *   policy_logits_{pred,after}_dev rows of A, value_logits_{pred,after}_dev rows of S, branch_dev [B] u8
+ *   -> policy_out_dev [B,A] f32, value_out_dev [B] f32 (contiguous) */
 int smz_prediction_epilogue(const float *policy_logits_pred_dev, const float *value_logits_pred_dev,
-                            const float *policy_logits_after_dev, const float *value_logits_after_dev,
+                            const float *policy_logits_after_dev, const float *value_logits_after_dev, int ld,
                             const uint8_t *branch_dev, int A, int S, float *policy_out_dev, float *value_out_dev,
                             int B, smz_stream stream);
 
@@ -183,11 +190,12 @@ int smz_cartpole_step(double *state_dev, const int32_t *action_dev, float *obs_o
  * step is one contiguous, coalesced slab and a finished chunk is one message for the trajectory gather):
  * what Game.policy_step / store_search_statistics append to their lists (game.py:193-195, 263-267).  Record of F =
  * smz_traj_floats(obs_dim, A) float64 values:
- *   [ observation AFTER the step (obs_dim) | reward | policy (A) | action one-hot (A) | root value | child_visits (A) ]
+ *   [ observation AFTER the step (obs_dim) | reward | terminated | policy (A) | action one-hot (A) | root value |
+ *     child_visits (A) ]
  * float64 keeps Game.policies / Game.child_visits exact; float32 fields widen exactly.  step t in [0,T). */
 int smz_traj_floats(int obs_dim, int A);
 int smz_traj_pack(double *traj_dev, int T, int t, int obs_dim, int A, const float *obs_dev, const float *reward_dev,
-                  const int32_t *action_dev, const double *policy_dev, const double *child_visits_dev,
+                  const uint8_t *terminated_dev, const int32_t *action_dev, const double *policy_dev, const double *child_visits_dev,
                   const float *root_value_dev, int B, smz_stream stream);
 
 /* ---- inspection ------------------------------------------------------------------------------------------------ */

@@ -45,6 +45,8 @@ SIGNATURES = {
     "smz_seed": (C.c_int, [_P, _P, _P]),
     "smz_set_rng_state": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "smz_get_rng_state": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int)]),
+    "smz_rng_snapshot": (C.c_int, [_P, _P]),
+    "smz_rng_restore": (C.c_int, [_P, _P]),
     "smz_root_init": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     "smz_select": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "smz_expand_backup": (C.c_int, [_P, _P, _P, _P, _P, _P]),
@@ -53,11 +55,11 @@ SIGNATURES = {
     "smz_act": (C.c_int, [_P, C.c_double, _P, _P, _P, _P, _P, _P]),
     "smz_support_decode": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "smz_policy_softmax": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
-    "smz_dynamics_epilogue": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
-    "smz_prediction_epilogue": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
+    "smz_dynamics_epilogue": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "smz_prediction_epilogue": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "smz_cartpole_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_traj_floats": (C.c_int, [C.c_int, C.c_int]),
-    "smz_traj_pack": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "smz_traj_pack": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_debug_dump_tree": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int32), _P]),
     "smz_enable_stats": (C.c_int, [_P, C.c_int]),
     "smz_read_stats": (C.c_int, [_P, _P, C.c_int]),

@@ -262,29 +262,29 @@ __global__ void __launch_bounds__(256) k_policy_softmax(const float *logits, int
 }
 
 __global__ void __launch_bounds__(256) k_dynamics_epilogue(const float *state_dyn, const float *state_after,
-                                                           const float *reward_logits, const uint8_t *branch, int S,
-                                                           float *hidden_out, float *reward_out, int B) {
+                                                           const float *reward_logits, int ld, const uint8_t *branch,
+                                                           int S, float *hidden_out, float *reward_out, int B) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= B) return;
     const bool dyn = branch[row] != 0;
-    const float *x = (dyn ? state_dyn : state_after) + (size_t)row * S;
+    const float *x = (dyn ? state_dyn : state_after) + (size_t)row * ld;
     float mn = x[0], mx = x[0];
     for (int i = 1; i < S; i++) { mn = fminf(mn, x[i]); mx = fmaxf(mx, x[i]); }
     float sc = mx - mn;
     if (sc < 1e-5f) sc += 1e-5f;  // neural_network_mlp_model.py:353
     for (int i = 0; i < S; i++) hidden_out[(size_t)row * S + i] = (x[i] - mn) / sc;
-    if (reward_out) reward_out[row] = (dyn && reward_logits) ? support_decode_row(reward_logits + (size_t)row * S, S) : 0.f;
+    if (reward_out) reward_out[row] = (dyn && reward_logits) ? support_decode_row(reward_logits + (size_t)row * ld, S) : 0.f;
 }
 
 __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pred, const float *val_pred,
                                                              const float *pol_after, const float *val_after,
-                                                             const uint8_t *branch, int A, int S, float *policy_out,
-                                                             float *value_out, int B) {
+                                                             int ld, const uint8_t *branch, int A, int S,
+                                                             float *policy_out, float *value_out, int B) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= B) return;
     const bool dyn = branch[row] != 0;
-    softmax_row((dyn ? pol_pred : pol_after) + (size_t)row * A, A, policy_out + (size_t)row * A);
-    value_out[row] = support_decode_row((dyn ? val_pred : val_after) + (size_t)row * S, S);
+    softmax_row((dyn ? pol_pred : pol_after) + (size_t)row * ld, A, policy_out + (size_t)row * A);
+    value_out[row] = support_decode_row((dyn ? val_pred : val_after) + (size_t)row * ld, S);
 }
 
 // ---- synthetic env + trajectory record ---------------------------------------------------------------------------
@@ -310,17 +310,20 @@ __global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int3
     if (term_out) term_out[e] = (fabs(nx) > 2.4 || fabs(nth) > 12.0 * 2.0 * 3.14159265358979323846 / 360.0) ? 1 : 0;
 }
 
-// record layout per (step, env): [obs(obs_dim) | reward | policy(A) | action one-hot(A) | root_value | child_visits(A)]
+// record layout per (step, env):
+//   [obs(obs_dim) | reward | terminated | policy(A) | action one-hot(A) | root_value | child_visits(A)]
 __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, int obs_dim, int A, const float *obs,
-                                                   const float *reward, const int32_t *action, const double *policy,
-                                                   const double *child_visits, const float *root_value, int B) {
+                                                   const float *reward, const uint8_t *terminated, const int32_t *action,
+                                                   const double *policy, const double *child_visits,
+                                                   const float *root_value, int B) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B) return;
-    const int F = obs_dim + 3 * A + 2;
+    const int F = obs_dim + 3 * A + 3;
     double *r = traj + ((size_t)t * B + e) * F;
     for (int i = 0; i < obs_dim; i++) r[i] = (double)obs[(size_t)e * obs_dim + i];
     r[obs_dim] = reward ? (double)reward[e] : 0.0;
-    double *p = r + obs_dim + 1;
+    r[obs_dim + 1] = (terminated && terminated[e]) ? 1.0 : 0.0;
+    double *p = r + obs_dim + 2;
     for (int a = 0; a < A; a++) p[a] = policy[(size_t)e * A + a];
     for (int a = 0; a < A; a++) p[A + a] = (a == action[e]) ? 1.0 : 0.0;
     p[2 * A] = (double)root_value[e];
@@ -345,6 +348,9 @@ struct smz_handle {
     bool pow_valid;
     unsigned long long *d_stats;
     bool stats_on;
+    uint32_t *d_mt_backup;
+    int32_t *d_pos_backup;
+    bool has_backup;
     std::vector<void *> allocs;
 };
 
@@ -485,6 +491,9 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     A_(dev_alloc(h, &h->d_pbc, (size_t)sims + 2));
     A_(dev_alloc(h, &h->d_pow, (size_t)sims + 1));
     A_(dev_alloc(h, &h->d_stats, (size_t)4));
+    A_(dev_alloc(h, &h->d_mt_backup, (size_t)B * kMtN));
+    A_(dev_alloc(h, &h->d_pos_backup, (size_t)B));
+    h->has_backup = false;
     if (rc != SMZ_OK) { smz_destroy(h); return rc; }
     P.pbc_sqrt = h->d_pbc;
     P.pow_table = nullptr;
@@ -575,6 +584,26 @@ int smz_get_rng_state(smz_handle *h, int tree, uint32_t *host_key, int *pos) {
         host_key[i] = host_key[im] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
     }
     *pos = idx;
+    return SMZ_OK;
+}
+
+int smz_rng_snapshot(smz_handle *h, smz_stream stream) {
+    if (!h) return fail(SMZ_ERR_INVALID, "smz_rng_snapshot: null handle%s");
+    DeviceGuard guard(h->cfg.device);
+    const size_t B = (size_t)h->cfg.num_trees;
+    HIP_TRY(hipMemcpyAsync(h->d_mt_backup, h->P.mt, B * kMtN * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(h->d_pos_backup, h->P.rng_pos, B * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    h->has_backup = true;
+    return SMZ_OK;
+}
+
+int smz_rng_restore(smz_handle *h, smz_stream stream) {
+    if (!h) return fail(SMZ_ERR_INVALID, "smz_rng_restore: null handle%s");
+    if (!h->has_backup) return fail(SMZ_ERR_STATE, "smz_rng_restore without smz_rng_snapshot%s");
+    DeviceGuard guard(h->cfg.device);
+    const size_t B = (size_t)h->cfg.num_trees;
+    HIP_TRY(hipMemcpyAsync(h->P.mt, h->d_mt_backup, B * kMtN * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(h->P.rng_pos, h->d_pos_backup, B * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SMZ_OK;
 }
 
@@ -672,24 +701,24 @@ int smz_policy_softmax(const float *logits_dev, int A, float *out_dev, int B, sm
 }
 
 int smz_dynamics_epilogue(const float *state_dyn_dev, const float *state_after_dev, const float *reward_logits_dev,
-                          const uint8_t *branch_dev, int S, float *hidden_out_dev, float *reward_out_dev, int B,
+                          int ld, const uint8_t *branch_dev, int S, float *hidden_out_dev, float *reward_out_dev, int B,
                           smz_stream stream) {
-    if (!state_dyn_dev || !state_after_dev || !branch_dev || !hidden_out_dev || S < 1 || B < 1)
+    if (!state_dyn_dev || !state_after_dev || !branch_dev || !hidden_out_dev || S < 1 || B < 1 || ld < S)
         return fail(SMZ_ERR_INVALID, "smz_dynamics_epilogue: bad argument%s");
     hipLaunchKernelGGL(k_dynamics_epilogue, row_grid(B), dim3(256), 0, (hipStream_t)stream, state_dyn_dev, state_after_dev,
-                       reward_logits_dev, branch_dev, S, hidden_out_dev, reward_out_dev, B);
+                       reward_logits_dev, ld, branch_dev, S, hidden_out_dev, reward_out_dev, B);
     return launch_check();
 }
 
 int smz_prediction_epilogue(const float *policy_logits_pred_dev, const float *value_logits_pred_dev,
                             const float *policy_logits_after_dev, const float *value_logits_after_dev,
-                            const uint8_t *branch_dev, int A, int S, float *policy_out_dev, float *value_out_dev,
-                            int B, smz_stream stream) {
+                            int ld, const uint8_t *branch_dev, int A, int S, float *policy_out_dev,
+                            float *value_out_dev, int B, smz_stream stream) {
     if (!policy_logits_pred_dev || !value_logits_pred_dev || !policy_logits_after_dev || !value_logits_after_dev ||
-        !branch_dev || !policy_out_dev || !value_out_dev || A < 1 || S < 1 || B < 1)
+        !branch_dev || !policy_out_dev || !value_out_dev || A < 1 || S < 1 || B < 1 || ld < 1)
         return fail(SMZ_ERR_INVALID, "smz_prediction_epilogue: bad argument%s");
     hipLaunchKernelGGL(k_prediction_epilogue, row_grid(B), dim3(256), 0, (hipStream_t)stream, policy_logits_pred_dev,
-                       value_logits_pred_dev, policy_logits_after_dev, value_logits_after_dev, branch_dev, A, S,
+                       value_logits_pred_dev, policy_logits_after_dev, value_logits_after_dev, ld, branch_dev, A, S,
                        policy_out_dev, value_out_dev, B);
     return launch_check();
 }
@@ -702,16 +731,16 @@ int smz_cartpole_step(double *state_dev, const int32_t *action_dev, float *obs_o
     return launch_check();
 }
 
-int smz_traj_floats(int obs_dim, int A) { return obs_dim + 3 * A + 2; }
+int smz_traj_floats(int obs_dim, int A) { return obs_dim + 3 * A + 3; }
 
 int smz_traj_pack(double *traj_dev, int T, int t, int obs_dim, int A, const float *obs_dev, const float *reward_dev,
-                  const int32_t *action_dev, const double *policy_dev, const double *child_visits_dev,
+                  const uint8_t *terminated_dev, const int32_t *action_dev, const double *policy_dev, const double *child_visits_dev,
                   const float *root_value_dev, int B, smz_stream stream) {
     if (!traj_dev || !obs_dev || !action_dev || !policy_dev || !child_visits_dev || !root_value_dev || t < 0 || t >= T ||
         B < 1 || A < 1 || obs_dim < 1)
         return fail(SMZ_ERR_INVALID, "smz_traj_pack: bad argument%s");
     hipLaunchKernelGGL(k_traj_pack, row_grid(B), dim3(256), 0, (hipStream_t)stream, traj_dev, T, t, obs_dim, A, obs_dev,
-                       reward_dev, action_dev, policy_dev, child_visits_dev, root_value_dev, B);
+                       reward_dev, terminated_dev, action_dev, policy_dev, child_visits_dev, root_value_dev, B);
     return launch_check();
 }
 

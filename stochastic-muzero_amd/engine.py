@@ -103,6 +103,12 @@ class SearchEngine:
         _lib.check(self.lib.smz_get_rng_state(self.h, int(tree), key.ctypes.data_as(C.c_void_p), C.byref(pos)))
         return key, pos.value
 
+    def snapshot_rng(self):
+        _lib.check(self.lib.smz_rng_snapshot(self.h, self._stream()))
+
+    def restore_rng(self):
+        _lib.check(self.lib.smz_rng_restore(self.h, self._stream()))
+
     # ---- search phases ----------------------------------------------------------------------------------------
     def _f32(self, t, shape):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device and tuple(t.shape) == shape, \
@@ -117,10 +123,10 @@ class SearchEngine:
         _lib.check(self.lib.smz_root_init(self.h, _ptr(hidden), _ptr(policy), _ptr(noise_override), int(bool(train)),
                                           self._stream()))
 
-    def select(self, want_mlp_input=True):
-        _lib.check(self.lib.smz_select(self.h, _ptr(self.parent_hidden) if self.S > 0 else None, _ptr(self.last_action),
-                                       _ptr(self.branch), _ptr(self.mlp_input) if (want_mlp_input and self.S > 0) else None,
-                                       self._stream()))
+    def select(self, want_mlp_input=True, want_parent_hidden=True):
+        _lib.check(self.lib.smz_select(self.h, _ptr(self.parent_hidden) if (want_parent_hidden and self.S > 0) else None,
+                                       _ptr(self.last_action), _ptr(self.branch),
+                                       _ptr(self.mlp_input) if (want_mlp_input and self.S > 0) else None, self._stream()))
         return self.parent_hidden, self.last_action, self.branch, self.mlp_input
 
     def expand_backup(self, hidden, reward, policy, value):
@@ -129,13 +135,13 @@ class SearchEngine:
                                               _ptr(self._f32(policy, (self.B, self.A))), _ptr(self._f32(value, (self.B,))),
                                               self._stream()))
 
-    def expand_backup_select(self, hidden, reward, policy, value, want_mlp_input=True):
+    def expand_backup_select(self, hidden, reward, policy, value, want_mlp_input=True, want_parent_hidden=True):
         hidden = self._f32(hidden.reshape(self.B, -1), (self.B, self.S)) if self.S > 0 else None
         _lib.check(self.lib.smz_expand_backup_select(
             self.h, _ptr(hidden), _ptr(None if reward is None else self._f32(reward, (self.B,))),
             _ptr(self._f32(policy, (self.B, self.A))), _ptr(self._f32(value, (self.B,))),
-            _ptr(self.parent_hidden) if self.S > 0 else None, _ptr(self.last_action), _ptr(self.branch),
-            _ptr(self.mlp_input) if (want_mlp_input and self.S > 0) else None, self._stream()))
+            _ptr(self.parent_hidden) if (want_parent_hidden and self.S > 0) else None, _ptr(self.last_action),
+            _ptr(self.branch), _ptr(self.mlp_input) if (want_mlp_input and self.S > 0) else None, self._stream()))
         return self.parent_hidden, self.last_action, self.branch, self.mlp_input
 
     def root_stats(self):

@@ -1,0 +1,33 @@
+"""Trajectory gather: the only inter-GPU exchange of the self-play path.
+
+Games are independent, so ranks never exchange tree state; after a fixed-length chunk each rank owns one contiguous
+[T][B][F] float64 slab and the learner rank (0) needs all of them for ReplayBuffer.save_game.  With torch.distributed's
+"nccl" backend (= RCCL on ROCm) this is one grouped send/recv: every GPU has a direct xGMI link to rank 0, so the 7
+receives proceed on 7 distinct links and no ring is involved.  "gloo" runs the same code on CPU tensors (tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def gather_to_learner(slab, dst=0, group=None):
+    """Returns the list of every rank's slab on rank `dst` (rank order), None elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [slab]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    slab = slab.contiguous()
+    if rank == dst:
+        parts = [slab if r == dst else torch.empty_like(slab) for r in range(world)]
+        ops = [dist.P2POp(dist.irecv, parts[r], r, group) for r in range(world) if r != dst]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return parts
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, slab, dst, group)]):
+        w.wait()
+    return None
+
+
+def shard_range(total_envs, rank, world):
+    """Contiguous env shard of a rank: env i keeps its seed and initial state whatever the world size."""
+    per = (total_envs + world - 1) // world
+    lo = min(total_envs, rank * per)
+    return lo, min(total_envs, lo + per)

@@ -1,0 +1,214 @@
+"""Batched evaluation of the learned heads for all pending leaves of a SearchEngine.
+
+The reference calls five tiny networks once per simulation with batch size 1 (muzero_model.py:802-909).  Here the
+same five functions are evaluated once per simulation round for ALL B trees.  Which pair of networks a tree needs
+depends on its leaf's parent flag (monte_carlo_tree_search.py:333-342); to keep every shape static (so a whole
+search can be captured in one HIP graph) both pairs are evaluated for every tree and the HIP epilogue kernels pick
+per tree (smz_dynamics_epilogue / smz_prediction_epilogue).  FLOPs are irrelevant here (~30 kFLOP per leaf).
+
+PyTorch-ROCm is used for the dense layers only; softmax, support decode, min-max scaling and the branch select are
+libsmz kernels.
+
+Two implementations of the same interface:
+  FusedMlpHeads  -- `mlp_model` family (neural_network_mlp_model.py:5-250): the two dynamics trunks share their
+                    input and the two prediction trunks share theirs, so each pair is evaluated as ONE stacked
+                    linear layer + ONE block-structured output layer (4 GEMMs per round instead of 10).
+  ModuleHeads    -- any head family following the reference's module signatures (vision, lstm, ...): calls the
+                    five torch modules batched and uses the same epilogues.
+Interface:
+  initial(obs)                      -> hidden [B,S] f32, policy [B,A] f32 (softmaxed; the root value is unused, mcts:319)
+  recurrent(mlp_input/hidden, last_action, branch) -> hidden' [B,S], reward [B], policy [B,A], value [B]
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+# weight names of the mlp_model family as plain arrays: <head>_<layer>_{w,b}
+MLP_ARRAYS = ["rep_in", "rep_mid", "rep_out",
+              "pre_in", "pre_mid", "pre_pol", "pre_val",
+              "apr_in", "apr_mid", "apr_pol", "apr_val",
+              "ady_in", "ady_mid", "ady_st",
+              "dyn_in", "dyn_mid", "dyn_rw", "dyn_st"]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class FusedMlpHeads:
+    wants_mlp_input, wants_parent_hidden = True, False
+
+    def __init__(self, weights, dims, device):
+        """weights: dict name -> array-like ('rep_in_w', 'rep_in_b', ...); dims: obs, A, S, H, L."""
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.obs, self.A, self.S, self.H, self.L = (int(dims[k]) for k in ("obs", "A", "S", "H", "L"))
+        w = {k: torch.as_tensor(v, dtype=torch.float32).to(self.device) for k, v in weights.items()}
+        self.w = w
+        A, S, H = self.A, self.S, self.H
+        z = lambda r, c: torch.zeros(r, c, device=self.device)
+        # representation (mlp:5-42): Linear -> ELU -> [Linear(H,H) -> ELU] x L (one shared module) -> Linear -> scale
+        self.rep = [(w["rep_in_w"].t().contiguous(), w["rep_in_b"])] + \
+                   [(w["rep_mid_w"].t().contiguous(), w["rep_mid_b"])] * self.L
+        self.rep_out = (w["rep_out_w"].t().contiguous(), w["rep_out_b"])
+        # root prediction (mlp:47-83): policy and value share the trunk weights
+        self.pre = [(w["pre_in_w"].t().contiguous(), w["pre_in_b"])] + \
+                   [(w["pre_mid_w"].t().contiguous(), w["pre_mid_b"])] * self.L
+        self.pre_pol = (w["pre_pol_w"].t().contiguous(), w["pre_pol_b"])
+        # dynamics || afterstate_dynamics, both fed [hidden | one-hot action] (mlp:122-124, 204-206)
+        self.dyn_in = (torch.cat([w["dyn_in_w"], w["ady_in_w"]], 0).t().contiguous(),
+                       torch.cat([w["dyn_in_b"], w["ady_in_b"]]))
+        self.dyn_mid = (torch.block_diag(w["dyn_mid_w"], w["ady_mid_w"]).t().contiguous(),
+                        torch.cat([w["dyn_mid_b"], w["ady_mid_b"]]))
+        w2 = torch.cat([torch.cat([w["dyn_rw_w"], z(S, H)], 1),     # reward logits      <- dynamics trunk
+                        torch.cat([w["dyn_st_w"], z(S, H)], 1),     # next state         <- dynamics trunk
+                        torch.cat([z(S, H), w["ady_st_w"]], 1)], 0)  # afterstate         <- afterstate trunk
+        self.dyn_out = (w2.t().contiguous(), torch.cat([w["dyn_rw_b"], w["dyn_st_b"], w["ady_st_b"]]))
+        # prediction || afterstate_prediction on the chosen next state
+        self.prd_in = (torch.cat([w["pre_in_w"], w["apr_in_w"]], 0).t().contiguous(),
+                       torch.cat([w["pre_in_b"], w["apr_in_b"]]))
+        self.prd_mid = (torch.block_diag(w["pre_mid_w"], w["apr_mid_w"]).t().contiguous(),
+                        torch.cat([w["pre_mid_b"], w["apr_mid_b"]]))
+        w3 = torch.cat([torch.cat([w["pre_pol_w"], z(A, H)], 1), torch.cat([w["pre_val_w"], z(S, H)], 1),
+                        torch.cat([z(A, H), w["apr_pol_w"]], 1), torch.cat([z(S, H), w["apr_val_w"]], 1)], 0)
+        self.prd_out = (w3.t().contiguous(),
+                        torch.cat([w["pre_pol_b"], w["pre_val_b"], w["apr_pol_b"], w["apr_val_b"]]))
+        self._buf = {}
+
+    @classmethod
+    def from_npz(cls, path, device):
+        import numpy as np
+        z = np.load(path)
+        dims = {k: int(z["dim_" + k]) for k in ("obs", "A", "S", "H", "L")}
+        weights = {n + s: z[n + s] for n in MLP_ARRAYS for s in ("_w", "_b")}
+        return cls(weights, dims, device)
+
+    def _out(self, name, shape, dtype=torch.float32):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._buf[name] = torch.empty(*shape, dtype=dtype, device=self.device)
+        return t
+
+    @staticmethod
+    def _trunk(x, layers):
+        for wt, b in layers:
+            x = F.elu(torch.addmm(b, x, wt))
+        return x
+
+    def initial(self, obs):
+        B = obs.shape[0]
+        pre = torch.addmm(self.rep_out[1], self._trunk(obs, self.rep), self.rep_out[0])     # [B,S] pre-scale
+        hidden = self._out("h0", (B, self.S))
+        zero = self._out("zero_branch", (B,), torch.uint8)
+        zero.zero_()
+        # scale_to_bound_action through the same epilogue (afterstate slot, branch 0, no reward)
+        _lib.check(self.lib.smz_dynamics_epilogue(_ptr(pre), _ptr(pre), None, self.S, _ptr(zero), self.S, _ptr(hidden),
+                                                  None, B, _stream(self.device)))
+        logits = torch.addmm(self.pre_pol[1], self._trunk(hidden, self.pre), self.pre_pol[0])
+        policy = self._out("p0", (B, self.A))
+        _lib.check(self.lib.smz_policy_softmax(_ptr(logits), self.A, _ptr(policy), B, _stream(self.device)))
+        return hidden, policy
+
+    def recurrent(self, engine):
+        """Consumes engine.mlp_input / engine.branch (outputs of the last select); returns the four tensors that
+        smz_expand_backup takes."""
+        x, branch = engine.mlp_input, engine.branch
+        B, A, S = x.shape[0], self.A, self.S
+        t = F.elu(torch.addmm(self.dyn_in[1], x, self.dyn_in[0]))
+        for _ in range(self.L):
+            t = F.elu(torch.addmm(self.dyn_mid[1], t, self.dyn_mid[0]))
+        o = torch.addmm(self.dyn_out[1], t, self.dyn_out[0])                                 # [B, 3S]
+        hidden = self._out("h", (B, S))
+        reward = self._out("r", (B,))
+        fs = o.element_size()
+        base = o.data_ptr()
+        _lib.check(self.lib.smz_dynamics_epilogue(C.c_void_p(base + S * fs), C.c_void_p(base + 2 * S * fs),
+                                                  C.c_void_p(base), 3 * S, _ptr(branch), S, _ptr(hidden), _ptr(reward),
+                                                  B, _stream(self.device)))
+        u = F.elu(torch.addmm(self.prd_in[1], hidden, self.prd_in[0]))
+        for _ in range(self.L):
+            u = F.elu(torch.addmm(self.prd_mid[1], u, self.prd_mid[0]))
+        q = torch.addmm(self.prd_out[1], u, self.prd_out[0])                                 # [B, 2A+2S]
+        policy = self._out("p", (B, A))
+        value = self._out("v", (B,))
+        qb = q.data_ptr()
+        _lib.check(self.lib.smz_prediction_epilogue(C.c_void_p(qb), C.c_void_p(qb + A * fs), C.c_void_p(qb + (A + S) * fs),
+                                                    C.c_void_p(qb + (2 * A + S) * fs), 2 * A + 2 * S, _ptr(branch), A, S,
+                                                    _ptr(policy), _ptr(value), B, _stream(self.device)))
+        return hidden, reward, policy, value
+
+
+class ModuleHeads:
+    """Heads given as five torch modules with the reference's signatures:
+         representation(obs) -> hidden                                   (already scaled)
+         prediction(h), afterstate_prediction(h) -> (policy_logits, value_logits)
+         afterstate_dynamics(h, action_encoding) -> hidden
+         dynamics(h, action_encoding) -> (reward_logits, hidden)
+       `encode_action(last_action[B] int64, hidden) -> tensor` builds the action input (one-hot for vector
+       observations, constant plane (a+1)/A for RGB: muzero_model.py:496-523)."""
+
+    wants_mlp_input, wants_parent_hidden = False, True
+
+    def __init__(self, representation, prediction, afterstate_prediction, afterstate_dynamics, dynamics, num_actions,
+                 support_size, device, is_rgb=False):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.rep, self.pre, self.apr, self.ady, self.dyn = (m.to(self.device).eval() for m in (
+            representation, prediction, afterstate_prediction, afterstate_dynamics, dynamics))
+        self.A, self.Ssup, self.is_rgb = int(num_actions), int(support_size), bool(is_rgb)
+        self._buf = {}
+
+    def _out(self, name, shape, dtype=torch.float32):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._buf[name] = torch.empty(*shape, dtype=dtype, device=self.device)
+        return t
+
+    def encode_action(self, action, hidden):
+        if not self.is_rgb:
+            return F.one_hot(action.long(), self.A).to(hidden.dtype)
+        plane = (action.to(hidden.dtype) + 1) / self.A
+        return plane.view(-1, 1, 1, 1).expand(-1, 1, hidden.shape[2], hidden.shape[3]).contiguous()
+
+    @torch.no_grad()
+    def initial(self, obs):
+        hidden = self.rep(obs)
+        self.hidden_shape = tuple(hidden.shape[1:])
+        logits, _ = self.pre(hidden)
+        B = obs.shape[0]
+        policy = self._out("p0", (B, self.A))
+        logits = logits.float().contiguous()
+        _lib.check(self.lib.smz_policy_softmax(_ptr(logits), self.A, _ptr(policy), B, _stream(self.device)))
+        return hidden.reshape(B, -1).float().contiguous(), policy
+
+    @torch.no_grad()
+    def recurrent(self, engine):
+        B = engine.B
+        h = engine.parent_hidden[:, :engine.S].reshape((B,) + self.hidden_shape)
+        enc = self.encode_action(engine.last_action, h)
+        reward_logits, s_dyn = self.dyn(h, enc)
+        s_aft = self.ady(h, enc)
+        m = engine.branch.bool()
+        hidden = torch.where(m.view((B,) + (1,) * (s_dyn.dim() - 1)), s_dyn, s_aft).contiguous()
+        rl = reward_logits.float().contiguous()
+        rdec = self._out("rdec", (B,))
+        _lib.check(self.lib.smz_support_decode(_ptr(rl), self.Ssup, _ptr(rdec), B, _stream(self.device)))
+        reward = torch.where(m, rdec, torch.zeros_like(rdec))
+        pp, vp = self.pre(hidden)
+        pa, va = self.apr(hidden)
+        pp, vp, pa, va = (t.float().contiguous() for t in (pp, vp, pa, va))
+        policy = self._out("p", (B, self.A))
+        value = self._out("v", (B,))
+        # policy rows (A wide) and value rows (S wide) have different strides: one epilogue call per width
+        _lib.check(self.lib.smz_policy_softmax(_ptr(torch.where(m[:, None], pp, pa).contiguous()), self.A, _ptr(policy),
+                                               B, _stream(self.device)))
+        _lib.check(self.lib.smz_support_decode(_ptr(torch.where(m[:, None], vp, va).contiguous()), self.Ssup,
+                                               _ptr(value), B, _stream(self.device)))
+        return hidden.reshape(B, -1).float().contiguous(), reward.contiguous(), policy, value

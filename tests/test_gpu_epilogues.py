@@ -68,7 +68,7 @@ def test_dynamics_and_prediction_epilogues(B, A, S):
     sd[3] = 0.25                                        # constant row: range < 1e-5 -> +1e-5 rule
     br = (torch.rand(B, generator=g) < 0.5).to(torch.uint8).cuda()
     hid = torch.empty(B, S, device="cuda"); rw = torch.empty(B, device="cuda")
-    smz._lib.check(lib.smz_dynamics_epilogue(_p(sd), _p(sa), _p(rl), _p(br), S, _p(hid), _p(rw), B, _s()))
+    smz._lib.check(lib.smz_dynamics_epilogue(_p(sd), _p(sa), _p(rl), S, _p(br), S, _p(hid), _p(rw), B, _s()))
     m = br.bool()
     ref_h = torch.where(m[:, None], _ref_scale(sd.clone()), _ref_scale(sa.clone()))
     torch.testing.assert_close(hid, ref_h, rtol=1e-6, atol=1e-6)
@@ -78,7 +78,7 @@ def test_dynamics_and_prediction_epilogues(B, A, S):
     pp, pa = (torch.randn(B, A, generator=g).cuda() * 2 for _ in range(2))
     vp, va = (torch.randn(B, S, generator=g).cuda() * 2 for _ in range(2))
     pol = torch.empty(B, A, device="cuda"); val = torch.empty(B, device="cuda")
-    smz._lib.check(lib.smz_prediction_epilogue(_p(pp), _p(vp), _p(pa), _p(va), _p(br), A, S, _p(pol), _p(val), B, _s()))
+    smz._lib.check(lib.smz_prediction_epilogue(_p(pp), _p(vp), _p(pa), _p(va), max(A, S), _p(br), A, S, _p(pol), _p(val), B, _s()))
     torch.testing.assert_close(pol, torch.where(m[:, None], torch.softmax(pp, -1), torch.softmax(pa, -1)), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(val, torch.where(m, _ref_decode(vp), _ref_decode(va)), rtol=1e-4, atol=5e-4)
 
@@ -103,16 +103,17 @@ def test_cartpole_step_and_traj_pack():
     np.testing.assert_allclose(obs.cpu().numpy(), ref.astype(np.float32), rtol=1e-6, atol=1e-9)
     assert (rw == 1).all() and (term == 0).all()
     F = lib.smz_traj_floats(4, A)
-    assert F == 4 + 3 * A + 2
+    assert F == 4 + 3 * A + 3
     traj = torch.zeros(T, B, F, dtype=torch.float64, device="cuda")
     pol = torch.rand(B, A, dtype=torch.float64, device="cuda"); cv = torch.rand(B, A, dtype=torch.float64, device="cuda")
     rv = torch.rand(B, device="cuda")
-    smz._lib.check(lib.smz_traj_pack(_p(traj), T, 1, 4, A, _p(obs), _p(rw), _p(d_act), _p(pol), _p(cv), _p(rv), B, _s()))
+    smz._lib.check(lib.smz_traj_pack(_p(traj), T, 1, 4, A, _p(obs), _p(rw), _p(term), _p(d_act), _p(pol), _p(cv), _p(rv), B, _s()))
     t = traj.cpu().numpy()
     assert (t[0] == 0).all() and (t[2] == 0).all()
     assert np.array_equal(t[1][:, :4], obs.cpu().numpy().astype(np.float64))
     assert np.array_equal(t[1][:, 4], rw.cpu().numpy().astype(np.float64))
-    assert np.array_equal(t[1][:, 5:5 + A], pol.cpu().numpy())
-    assert np.array_equal(t[1][:, 5 + A:5 + 2 * A], np.eye(A)[act])
-    assert np.array_equal(t[1][:, 5 + 2 * A], rv.cpu().numpy().astype(np.float64))
-    assert np.array_equal(t[1][:, 6 + 2 * A:], cv.cpu().numpy())
+    assert (t[1][:, 5] == 0).all()
+    assert np.array_equal(t[1][:, 6:6 + A], pol.cpu().numpy())
+    assert np.array_equal(t[1][:, 6 + A:6 + 2 * A], np.eye(A)[act])
+    assert np.array_equal(t[1][:, 6 + 2 * A], rv.cpu().numpy().astype(np.float64))
+    assert np.array_equal(t[1][:, 7 + 2 * A:], cv.cpu().numpy())
