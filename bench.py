@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--temperature", type=float, default=1.0)
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("SMZ_STREAM_GROUPS", "1")),
+                    help="independent env groups per GPU, each on its own HIP stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,32 +117,39 @@ def main():
     B = args.envs or wl["envs"]
     wpath = os.path.join(ROOT, "tests", "golden", wl["weights"])
     model = model_mod.Muzero.from_arrays(wpath)          # trained ckpt-421 weights exported as plain arrays
-    heads = model.heads(dev)
     total = B * world
     lo = rank * B
-    if wl["env"] == "cartpole":
-        env = envs_mod.CartPoleVec(B, dev, seed=0, first_env=lo, total_envs=total)
-    else:
-        env = envs_mod.SyntheticVec(B, wl["obs"], wl["A"], dev, seed=0, first_env=lo, total_envs=total)
-    mcts = mcts_mod.BatchedMCTS(B, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
-                                root_dirichlet_alpha=0.25, root_exploration_fraction=0.1, device=local_rank,
-                                use_graph=not args.no_graph, fused=True)
-    mcts.seed(np.arange(lo, lo + B, dtype=np.uint64))
-    env.reset()
     T = max(args.steps, args.warmup, 1)
-    chunk = sp.TrajectoryChunk(T, B, env.obs_dim, env.num_actions, dev)
+    G = max(1, args.groups)
+    assert B % G == 0, "--groups must divide the env count"
+    Bg = B // G
+    groups = []
+    for gi in range(G):
+        glo = lo + gi * Bg
+        if wl["env"] == "cartpole":
+            env = envs_mod.CartPoleVec(Bg, dev, seed=0, first_env=glo, total_envs=total)
+        else:
+            env = envs_mod.SyntheticVec(Bg, wl["obs"], wl["A"], dev, seed=0, first_env=glo, total_envs=total)
+        m = mcts_mod.BatchedMCTS(Bg, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
+                                 root_dirichlet_alpha=0.25, root_exploration_fraction=0.1, device=local_rank,
+                                 use_graph=not args.no_graph, fused=True)
+        m.seed(np.arange(glo, glo + Bg, dtype=np.uint64))
+        env.reset()
+        groups.append(sp.StreamGroup(env, model.heads(dev, instance=gi), m, T))
+    env, heads, mcts = groups[0].env, groups[0].heads, groups[0].mcts
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    sp.play_games(env, heads, mcts, args.temperature, args.warmup, chunk=chunk)           # W untimed warm-up steps
+    sp.play_games_grouped(groups, args.temperature, args.warmup)                          # W untimed warm-up steps
     barrier()
     t0 = time.perf_counter()
-    sp.play_games(env, heads, mcts, args.temperature, args.steps, chunk=chunk)            # EXACTLY K timed steps
+    chunks = sp.play_games_grouped(groups, args.temperature, args.steps)                  # EXACTLY K timed steps
     if world > 1:
-        gather_mod.gather_to_learner(chunk.data[:args.steps])                            # trajectories -> learner rank
+        slab = torch.cat([c.data[:args.steps] for c in chunks], dim=1)
+        gather_mod.gather_to_learner(slab)                                               # trajectories -> learner rank
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -156,6 +165,7 @@ def main():
            "config": {"workload": args.workload, "envs_per_gpu": B, "num_simulations": wl["sims"],
                       "actions": wl["A"], "children_per_expansion": wl["K"], "hidden_floats": model.state_dimension,
                       "rng": "per-tree MT19937 (numpy-legacy, parity mode)", "hip_graph": not args.no_graph,
+                      "stream_groups": G,
                       "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}}
 
     # ---- roofline of the dominant tree kernel (rank 0) --------------------------------------------------------
@@ -165,6 +175,7 @@ def main():
         # (1) level histogram of this workload (stats atomics on; not timed)
         eng.enable_stats(True)
         eng.read_stats(reset=True)
+        B = Bg
         mcts_e = mcts_mod.BatchedMCTS(B, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
                                       root_dirichlet_alpha=0.25, root_exploration_fraction=0.1, device=local_rank,
                                       use_graph=False, fused=True)

@@ -1,10 +1,19 @@
 // smz_device.hpp -- device-side building blocks of the gfx950 search kernels.
 //
-// Everything here is per-tree scalar logic executed by ONE lane per tree (64 trees per wavefront); the wave-wide
-// parts (row gathers/scatters of hidden states) live in smz_kernels.hip.  The arithmetic follows, operation by
-// operation and with the same float32/float64 roundings, the reference's monte_carlo_tree_search.py and the numpy
-// legacy RandomState it draws from.  This translation unit MUST be compiled with -ffp-contract=off: a fused
-// multiply-add would change the roundings the reference performs separately.
+// Execution shape: one search tree per lane, 64 trees per wavefront.  The per-tree logic below is scalar code run
+// by one lane; the wave-cooperative parts (random-word staging, hidden-row moves) live in smz_kernels.hip.
+// The arithmetic follows, operation by operation and with the same float32/float64 roundings, the reference's
+// monte_carlo_tree_search.py and the numpy legacy RandomState it draws from.  This translation unit MUST be
+// compiled with -ffp-contract=off: a fused multiply-add would change roundings the reference performs separately.
+//
+// Data layout (HBM).  A tree is a header plus "child blocks"; a block holds the children of ONE node as a small
+// structure-of-arrays, so that one descent level touches one contiguous 64/128-byte block:
+//     root block   (A children): visit[A] | value_sum[A] | reward[A] | prior32[A] | child[A] | (pad) | prior64[A]
+//     expansion e  (K children): visit[K] | value_sum[K] | reward[K] | prior32[K] | child[K] | action[K]
+// `child` = 1 + index of the expansion block holding that node's own children (0 = not expanded), so the block
+// just loaded already names the next block to load: one dependent memory round trip per level.  Node ids (used for
+// the hidden-state rows and by the debug dump) stay the creation-order ids of the reference-side goldens:
+// root 0, root children 1..A, children of expansion e at 1 + A + e*K + j.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,27 +23,32 @@ namespace smz {
 constexpr int kMtN = 624;
 constexpr int kMtM = 397;
 constexpr int kWave = 64;
+constexpr int kRngStage = 64;   // MT words staged per tree per launch
+constexpr int kRngStride = kRngStage + 1;
 
-struct TreeHdr {       // one 16-byte record per tree
-    int32_t alloc;     // next free node index
-    int32_t path_len;  // nodes on the recorded search path
-    float mn, mx;      // MinMaxStats (monte_carlo_tree_search.py:24-36)
+struct TreeHdr {          // one 32-byte record per tree
+    int32_t n_exp;        // expansion blocks allocated so far
+    int32_t path_len;     // non-root nodes on the recorded search path
+    float mn, mx;         // MinMaxStats (monte_carlo_tree_search.py:24-36)
+    int32_t root_visit;   // root.visit_count
+    float root_value_sum; // root.value_sum
+    int32_t pad0, pad1;
 };
 
-// Kernel parameter block (by value).  Node fields are structure-of-arrays, [B][N] each; children of a node are
-// contiguous (child_base .. child_base + count), count = A for the root and K for every other node.
 struct Params {
     int32_t B, A, K, S, N, P, sims;
-    float disc32;   // float32(discount): python float * np.float32 -> float32 under NEP 50 (mcts:239, :308)
-    float keep32;   // float32(1 - root_exploration_fraction) (mcts:224-225)
+    int32_t tpw;        // trees per wavefront (power of two <= 64): lanes >= tpw only help in the cooperative phases
+    int32_t rb_words;   // words in a root block (multiple of 16)
+    int32_t eb_words;   // words in an expansion block (multiple of 16)
+    int32_t rp_off;     // word offset of prior64[] inside the root block (even)
+    int64_t tree_words; // words per tree = rb_words + sims * eb_words
+    float disc32;       // float32(discount): python float * np.float32 -> float32 under NEP 50 (mcts:239, :308)
+    float keep32;       // float32(1 - root_exploration_fraction) (mcts:224-225)
     double frac, alpha;
-    int32_t *visit;
-    float *value_sum, *reward, *prior;
-    int32_t *child_base, *action;
+    uint32_t *nodes;        // [B][tree_words]
     float *hidden;          // [B][N][S]
-    double *root_prior;     // [B][A]  float64 priors of the root children (after noise)
     TreeHdr *hdr;           // [B]
-    int32_t *path;          // [B][P]
+    int32_t *path;          // [B][P]   entries (block << 8) | slot, block 0 = root block, e + 1 = expansion e
     uint32_t *mt;           // [B][624]
     int32_t *rng_pos;       // [B]  (ready << 16) | idx
     const double *pbc_sqrt; // [sims+2]  sqrt(n) * pb_c(n)
@@ -42,19 +56,50 @@ struct Params {
     unsigned long long *stats;  // [4] or nullptr
 };
 
+__device__ inline uint32_t *tree_base(const Params &P, int tree) { return P.nodes + (size_t)tree * P.tree_words; }
+__device__ inline uint32_t *block_ptr(const Params &P, uint32_t *tb, int blk) {
+    return blk == 0 ? tb : tb + P.rb_words + (size_t)(blk - 1) * P.eb_words;
+}
+__device__ inline int loc_node_id(const Params &P, int loc) {
+    const int blk = loc >> 8, slot = loc & 0xff;
+    return blk == 0 ? 1 + slot : 1 + P.A + (blk - 1) * P.K + slot;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // numpy legacy RandomState: MT19937 advanced one word at a time.
 // The block regeneration numpy performs every 624 draws is equivalent to twisting word i in place when draw i is
 // requested (word i needs old[i], old[i+1] and old-or-new[i+397 mod 624] exactly as the in-place block loop has
-// them), which removes the 624-iteration divergent refill.  `ready` counts words at idx.. that are ALREADY
-// twisted (non-zero only right after importing a numpy state whose pos < 624).
+// them).  `ready` counts words at idx.. that are ALREADY twisted: the kernels twist ahead cooperatively (one
+// coalesced pass per tree) and stage the next kRngStage tempered words of every tree in LDS, so that drawing is
+// an LDS read; a lane that needs more than the staged words falls back to twisting in global memory.
 // ---------------------------------------------------------------------------------------------------------------
+__device__ inline uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+__device__ inline uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t t = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+}
+
 struct Rng {
-    uint32_t *mt;
-    int idx, ready;
-    __device__ void load(uint32_t *state, int packed) { mt = state; idx = packed & 0xffff; ready = packed >> 16; }
+    uint32_t *mt;           // this tree's 624 words in global memory
+    const uint32_t *stage;  // this lane's staged (tempered) words in LDS, or nullptr
+    int idx, ready, used, staged;
+    __device__ void load(uint32_t *state, int packed, const uint32_t *lds_row, int n_staged) {
+        mt = state; idx = packed & 0xffff; ready = packed >> 16; stage = lds_row; staged = n_staged; used = 0;
+    }
     __device__ int pack() const { return (ready << 16) | idx; }
     __device__ uint32_t next32() {
+        if (used < staged) {              // fast path: word was twisted and tempered by the staging pass
+            const uint32_t y = stage[used++];
+            --ready;
+            idx = (idx + 1 == kMtN) ? 0 : idx + 1;
+            return y;
+        }
         const int i = idx;
         uint32_t y;
         if (ready > 0) {
@@ -64,17 +109,11 @@ struct Rng {
             const int i1 = (i + 1 == kMtN) ? 0 : i + 1;
             int im = i + kMtM;
             if (im >= kMtN) im -= kMtN;
-            const uint32_t a = mt[i], b = mt[i1], c = mt[im];
-            const uint32_t t = (a & 0x80000000u) | (b & 0x7fffffffu);
-            y = c ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+            y = mt_twist(mt[i], mt[i1], mt[im]);
             mt[i] = y;
         }
         idx = (i + 1 == kMtN) ? 0 : i + 1;
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
+        return mt_temper(y);
     }
     // RandomState.random_sample(): (a * 2^26 + b) / 2^53 with a = 27 bits, b = 26 bits
     __device__ double random_sample() {
@@ -89,7 +128,8 @@ template <typename T, int MAXA>
 __device__ inline T np_sum(const T *a, int n) {
     if (MAXA < 8 || n < 8) {
         T r = (T)0;
-        for (int i = 0; i < n; i++) r += a[i];
+#pragma unroll
+        for (int i = 0; i < MAXA; i++) if (i < n) r += a[i];
         return r;
     }
     T r[8];
@@ -107,10 +147,12 @@ template <int MAXA>
 __device__ inline int sample_cdf(const double *p, int n, double u) {
     double cdf[MAXA];
     double acc = 0.0;
-    for (int i = 0; i < n; i++) { acc += p[i]; cdf[i] = acc; }
-    const double last = cdf[n - 1];
+#pragma unroll
+    for (int i = 0; i < MAXA; i++) if (i < n) { acc += p[i]; cdf[i] = acc; }
+    const double last = acc;
     int k = 0;
-    for (int i = 0; i < n; i++) k += ((cdf[i] / last) <= u) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < MAXA; i++) if (i < n) k += ((cdf[i] / last) <= u) ? 1 : 0;
     return k;
 }
 
@@ -163,9 +205,11 @@ __device__ inline double legacy_gamma(Rng &rng, double shape) {
 // p = (policy + 1e-12) / sum, float32 (monte_carlo_tree_search.py:205-206, 291-292)
 template <int MAXA>
 __device__ inline void normalise_policy(const float *policy, int A, float *p) {
-    for (int a = 0; a < A; a++) p[a] = policy[a] + 1e-12f;
+#pragma unroll
+    for (int a = 0; a < MAXA; a++) p[a] = (a < A) ? policy[a] + 1e-12f : 0.f;
     const float s = np_sum<float, MAXA>(p, A);
-    for (int a = 0; a < A; a++) p[a] = p[a] / s;
+#pragma unroll
+    for (int a = 0; a < MAXA; a++) if (a < A) p[a] = p[a] / s;
 }
 
 __device__ inline int depth_flag(int depth) { return (depth >> 1) & 1; }  // F F T T ...
@@ -177,7 +221,7 @@ template <int MAXA>
 __device__ inline void root_init_tree(const Params &P, int tree, Rng &rng, const float *policy_row,
                                       const double *noise_override_row, bool train) {
     const int A = P.A;
-    const size_t nb = (size_t)tree * P.N;
+    uint32_t *rb = tree_base(P, tree);
     float p[MAXA];
     double p64[MAXA];
     int32_t picks[MAXA];
@@ -186,22 +230,16 @@ __device__ inline void root_init_tree(const Params &P, int tree, Rng &rng, const
     normalise_policy<MAXA>(pol, A, p);
     for (int a = 0; a < A; a++) p64[a] = (double)p[a];
     choice_noreplace<MAXA>(rng, p64, A, A, picks);  // sorted result is 0..A-1; only the draws matter (mcts:208)
-    P.visit[nb] = 0;
-    P.value_sum[nb] = 0.f;
-    P.reward[nb] = 0.f;
-    P.prior[nb] = 0.f;
-    P.child_base[nb] = 1;
-    P.action[nb] = 0;
+    int32_t *vi = (int32_t *)rb;
+    float *fs = (float *)rb;
     for (int a = 0; a < A; a++) {
-        const size_t c = nb + 1 + a;
-        P.visit[c] = 0;
-        P.value_sum[c] = 0.f;
-        P.reward[c] = 0.f;
-        P.prior[c] = p[a];
-        P.child_base[c] = 0;
-        P.action[c] = a;
+        vi[a] = 0;                 // visit
+        fs[A + a] = 0.f;           // value_sum
+        fs[2 * A + a] = 0.f;       // reward
+        fs[3 * A + a] = p[a];      // float32 prior
+        vi[4 * A + a] = 0;         // child
     }
-    double *rp = P.root_prior + (size_t)tree * A;
+    double *rp = (double *)(rb + P.rp_off);
     if (train && P.sims > 0) {
         double noise[MAXA];
         double acc = 0.0;
@@ -216,99 +254,132 @@ __device__ inline void root_init_tree(const Params &P, int tree, Rng &rng, const
         for (int a = 0; a < A; a++) rp[a] = (double)p[a];
     }
     TreeHdr h;
-    h.alloc = 1 + A;
+    h.n_exp = 0;
     h.path_len = 0;
     h.mn = __builtin_inff();
     h.mx = -__builtin_inff();
+    h.root_visit = 0;
+    h.root_value_sum = 0.f;
+    h.pad0 = h.pad1 = 0;
     P.hdr[tree] = h;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// selection (monte_carlo_tree_search.py:228-267)
+// selection (monte_carlo_tree_search.py:228-267): one block load per level, everything else in registers / LDS
 // ---------------------------------------------------------------------------------------------------------------
 struct Leaf {
-    int32_t leaf, parent, action, branch;
+    int32_t leaf_id, parent_id, action, branch;
 };
 
 template <int MAXA>
-__device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, float mn, float mx, int &path_len_out,
-                                   unsigned &n_dec, unsigned &n_chance, unsigned &n_children) {
+__device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const TreeHdr &h, const double *pbc_sqrt,
+                                   int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children) {
     const int A = P.A, K = P.K;
-    const size_t nb = (size_t)tree * P.N;
+    uint32_t *tb = tree_base(P, tree);
     int32_t *path = P.path + (size_t)tree * P.P;
-    int node = 0, depth = 0, len = 1, parent = 0;
-    path[0] = 0;
-    int cb = P.child_base[nb];
+    const float mn = h.mn, mx = h.mx;
     const bool norm = mx > mn;
     const float span = mx - mn;
-    while (cb != 0) {
-        const int cnt = (node == 0) ? A : K;
+    int blk = 0, depth = 0, cur_visit = h.root_visit;
+    int leaf_id = 0, parent_id = 0, action = 0;
+    for (;;) {
+        const int cnt = (blk == 0) ? A : K;
+        const uint32_t *bp = block_ptr(P, tb, blk);
+        // the whole child block: independent loads, one latency
+        int32_t vis[MAXA], chd[MAXA], act[MAXA];
+        float vsum[MAXA], rew[MAXA], pri[MAXA];
+        double pri64[MAXA];
+#pragma unroll
+        for (int j = 0; j < MAXA; j++) {
+            if (j < cnt) {
+                vis[j] = (int32_t)bp[j];
+                vsum[j] = __uint_as_float(bp[cnt + j]);
+                rew[j] = __uint_as_float(bp[2 * cnt + j]);
+                pri[j] = __uint_as_float(bp[3 * cnt + j]);
+                chd[j] = (int32_t)bp[4 * cnt + j];
+                act[j] = (blk == 0) ? j : (int32_t)bp[5 * cnt + j];
+                pri64[j] = (blk == 0) ? ((const double *)(bp + P.rp_off))[j] : (double)pri[j];
+            } else {
+                vis[j] = 0; chd[j] = 0; act[j] = 0; vsum[j] = 0.f; rew[j] = 0.f; pri[j] = 0.f; pri64[j] = 0.0;
+            }
+        }
         int pick = 0;
         if (depth_flag(depth)) {
             // chance-flagged: sample an outcome from the smoothed priors (mcts:247-255)
-            float pr[MAXA], tmp[MAXA];
+            float tmp[MAXA];
             double q64[MAXA];
-            for (int j = 0; j < cnt; j++) pr[j] = P.prior[nb + cb + j];
-            for (int j = 0; j < cnt; j++) { const float om = 1.0f - pr[j]; tmp[j] = om + 1e-12f; }
+#pragma unroll
+            for (int j = 0; j < MAXA; j++) { const float om = 1.0f - pri[j]; tmp[j] = om + 1e-12f; }
             const float s = np_sum<float, MAXA>(tmp, cnt);
             const float r = fabsf((float)((double)s / (double)cnt));
-            for (int j = 0; j < cnt; j++) tmp[j] = pr[j] + r;
+#pragma unroll
+            for (int j = 0; j < MAXA; j++) tmp[j] = pri[j] + r;
             const float qs = np_sum<float, MAXA>(tmp, cnt);
-            for (int j = 0; j < cnt; j++) q64[j] = (double)(tmp[j] / qs);
+#pragma unroll
+            for (int j = 0; j < MAXA; j++) q64[j] = (double)(tmp[j] / qs);
             pick = sample_cdf<MAXA>(q64, cnt, rng.random_sample());
             n_chance++;
         } else {
             // decision-flagged: pUCT argmax (mcts:235-243, 257-259)
-            const int Np = P.visit[nb + node];
-            const double sp = P.pbc_sqrt[Np];
+            const double sp = pbc_sqrt[cur_visit];
             double best = 0.0;
-            for (int j = 0; j < cnt; j++) {
-                const size_t c = nb + cb + j;
-                const int Nc = P.visit[c];
-                const double prior = (node == 0) ? P.root_prior[(size_t)tree * A + j] : (double)P.prior[c];
-                const double prior_score = (sp * prior) / (double)(Nc + 1);
-                double value_score = 0.0;
-                if (Nc > 0) {
-                    const float qv = P.value_sum[c] / (float)Nc;
-                    const float dv = P.disc32 * qv;
-                    float x = P.reward[c] + dv;
-                    if (norm) { const float num = x - mn; x = num / span; }
-                    value_score = (double)x;
+#pragma unroll
+            for (int j = 0; j < MAXA; j++) {
+                if (j < cnt) {
+                    const int Nc = vis[j];
+                    const double prior_score = (sp * pri64[j]) / (double)(Nc + 1);
+                    double value_score = 0.0;
+                    if (Nc > 0) {
+                        const float qv = vsum[j] / (float)Nc;
+                        const float dv = P.disc32 * qv;
+                        float x = rew[j] + dv;
+                        if (norm) { const float num = x - mn; x = num / span; }
+                        value_score = (double)x;
+                    }
+                    const double jitter = 1e-7 + (2e-7 - 1e-7) * rng.random_sample();
+                    const double score = (prior_score + value_score) + jitter;
+                    if (j == 0 || score >= best) { best = score; pick = j; }  // exact tie -> larger action
                 }
-                const double jitter = 1e-7 + (2e-7 - 1e-7) * rng.random_sample();
-                const double score = (prior_score + value_score) + jitter;
-                if (j == 0 || score >= best) { best = score; pick = j; }  // exact tie -> larger action
             }
             n_dec++;
             n_children += (unsigned)cnt;
         }
-        parent = node;
-        node = cb + pick;
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < MAXA; j++) if (j == pick) { c = chd[j]; cur_visit = vis[j]; action = act[j]; }
+        const int loc = (blk << 8) | pick;
+        path[depth] = loc;
+        parent_id = leaf_id;
+        leaf_id = loc_node_id(P, loc);
         depth++;
-        path[len++] = node;
-        cb = P.child_base[nb + node];
+        if (c == 0) break;
+        blk = c;
     }
-    path_len_out = len;
+    path_len_out = depth;
     Leaf L;
-    L.leaf = node;
-    L.parent = parent;
-    L.action = P.action[nb + node];
+    L.leaf_id = leaf_id;
+    L.parent_id = parent_id;
+    L.action = action;
     L.branch = depth_flag(depth - 1);
     return L;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // expansion + backup (monte_carlo_tree_search.py:289-308); the leaf's hidden row is stored by the caller.
+// Returns the leaf's node id.
 // ---------------------------------------------------------------------------------------------------------------
 template <int MAXA>
-__device__ inline void expand_backup_tree(const Params &P, int tree, Rng &rng, TreeHdr &h, const float *policy_row,
-                                          float reward, float value) {
+__device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, TreeHdr &h, const float *policy_row,
+                                         float reward, float value) {
+    constexpr int CH = 8;   // path nodes gathered per round trip
     const int A = P.A, K = P.K;
-    const size_t nb = (size_t)tree * P.N;
+    uint32_t *tb = tree_base(P, tree);
     const int32_t *path = P.path + (size_t)tree * P.P;
     const int len = h.path_len;
-    const int leaf = path[len - 1];
-    const int pflag = depth_flag(len - 2);
+    // ---- gather the path (independent loads) -------------------------------------------------------------------
+    const int leaf_loc = path[len - 1];
+    const int pflag = depth_flag(len - 1);       // flag of the leaf's parent (depth len-1; root is depth 0)
+    // ---- expansion ---------------------------------------------------------------------------------------------
     float p[MAXA], pol[MAXA];
     double p64[MAXA];
     int32_t picks[MAXA];
@@ -322,35 +393,81 @@ __device__ inline void expand_backup_tree(const Params &P, int tree, Rng &rng, T
         while (j >= 0 && picks[j] > x) { picks[j + 1] = picks[j]; j--; }
         picks[j + 1] = x;
     }
-    const int cb = h.alloc;
-    h.alloc = cb + K;
-    P.child_base[nb + leaf] = cb;
-    P.reward[nb + leaf] = pflag ? reward : 0.0f;  // the afterstate branch never assigns a reward (mcts:338-342)
-    for (int j = 0; j < K; j++) {
-        const size_t c = nb + cb + j;
-        P.visit[c] = 0;
-        P.value_sum[c] = 0.f;
-        P.reward[c] = 0.f;
-        P.prior[c] = p[picks[j]];
-        P.child_base[c] = 0;
-        P.action[c] = picks[j];
+    const int e = h.n_exp;
+    h.n_exp = e + 1;
+    {
+        uint32_t *nb = block_ptr(P, tb, e + 1);
+        for (int j = 0; j < K; j++) {
+            nb[j] = 0u;                                  // visit
+            nb[K + j] = __float_as_uint(0.f);            // value_sum
+            nb[2 * K + j] = __float_as_uint(0.f);        // reward
+            float pj = 0.f;
+            for (int a = 0; a < A; a++) if (a == picks[j]) pj = p[a];
+            nb[3 * K + j] = __float_as_uint(pj);         // prior = un-renormalised p[a]
+            nb[4 * K + j] = 0u;                          // child
+            nb[5 * K + j] = (uint32_t)picks[j];          // action
+        }
     }
+    const float leaf_reward = pflag ? reward : 0.0f;     // the afterstate branch never assigns one (mcts:338-342)
+    {
+        const int lb = leaf_loc >> 8, ls = leaf_loc & 0xff;
+        const int lc = (lb == 0) ? A : K;
+        uint32_t *lp = block_ptr(P, tb, lb);
+        lp[4 * lc + ls] = (uint32_t)(e + 1);             // leaf.children now live in expansion e
+        lp[2 * lc + ls] = __float_as_uint(leaf_reward);
+    }
+    // ---- backup, leaf -> root, CH nodes per round trip ------------------------------------------------------------
     float v = value;
     float mn = h.mn, mx = h.mx;
-    for (int i = len - 1; i >= 0; i--) {
-        const size_t n = nb + path[i];
-        const float vs = P.value_sum[n] + v;
-        const int vc = P.visit[n] + 1;
-        P.value_sum[n] = vs;
-        P.visit[n] = vc;
-        const float qv = vs / (float)vc;
+    for (int i0 = len - 1; i0 >= 0; i0 -= CH) {
+        int locs[CH];
+        uint32_t *np_[CH];
+        int cnts[CH];
+        int32_t vi[CH];
+        float vs[CH], rw[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) locs[c] = (i0 - c >= 0) ? path[i0 - c] : 0;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int b = locs[c] >> 8, s = locs[c] & 0xff;
+            cnts[c] = (b == 0) ? A : K;
+            np_[c] = block_ptr(P, tb, b) + s;
+            if (i0 - c >= 0) {
+                vi[c] = (int32_t)np_[c][0];
+                vs[c] = __uint_as_float(np_[c][cnts[c]]);
+                rw[c] = __uint_as_float(np_[c][2 * cnts[c]]);
+            } else {
+                vi[c] = 0; vs[c] = 0.f; rw[c] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            if (i0 - c >= 0) {
+                const float r = (i0 - c == len - 1) ? leaf_reward : rw[c];
+                const float nvs = vs[c] + v;
+                const int nvc = vi[c] + 1;
+                np_[c][0] = (uint32_t)nvc;
+                np_[c][cnts[c]] = __float_as_uint(nvs);
+                const float qv = nvs / (float)nvc;
+                if (qv > mx) mx = qv;
+                if (qv < mn) mn = qv;
+                const float dv = P.disc32 * v;
+                v = r + dv;
+            }
+        }
+    }
+    {   // the root itself (reward 0)
+        const float nvs = h.root_value_sum + v;
+        const int nvc = h.root_visit + 1;
+        h.root_value_sum = nvs;
+        h.root_visit = nvc;
+        const float qv = nvs / (float)nvc;
         if (qv > mx) mx = qv;
         if (qv < mn) mn = qv;
-        const float dv = P.disc32 * v;
-        v = P.reward[n] + dv;
     }
     h.mn = mn;
     h.mx = mx;
+    return loc_node_id(P, leaf_loc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -360,10 +477,11 @@ template <int MAXA>
 __device__ inline void act_tree(const Params &P, int tree, Rng &rng, double temperature, int32_t *action_out,
                                 double *policy_out, double *child_visits_out, float *root_value_out) {
     const int A = P.A;
-    const size_t nb = (size_t)tree * P.N;
+    const uint32_t *rb = tree_base(P, tree);
+    const double *rp = (const double *)(rb + P.rp_off);
     double pol[MAXA], vis[MAXA], pri[MAXA];
     int32_t vc[MAXA];
-    for (int a = 0; a < A; a++) { vc[a] = P.visit[nb + 1 + a]; vis[a] = (double)vc[a]; pri[a] = P.root_prior[(size_t)tree * A + a]; }
+    for (int a = 0; a < A; a++) { vc[a] = (int32_t)rb[a]; vis[a] = (double)vc[a]; pri[a] = rp[a]; }
     const double vsum = np_sum<double, MAXA>(vis, A);
     const bool from_visits = !(vsum <= 1.0);
     for (int a = 0; a < A; a++) pol[a] = from_visits ? vis[a] : pri[a];
@@ -392,8 +510,8 @@ __device__ inline void act_tree(const Params &P, int tree, Rng &rng, double temp
         }
     }
     if (root_value_out) {
-        const int rv = P.visit[nb];
-        root_value_out[tree] = rv ? P.value_sum[nb] / (float)rv : 0.0f;
+        const TreeHdr h = P.hdr[tree];
+        root_value_out[tree] = h.root_visit ? h.root_value_sum / (float)h.root_visit : 0.0f;
     }
 }
 

@@ -55,21 +55,85 @@ __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds)
     P.rng_pos[tree] = 0;  // idx 0, nothing pre-twisted: the first draw twists word 0 (== numpy pos 624)
 }
 
-// Moves one row per tree of this wave.  src_row/dst_row are per-lane row pointers (of the lane's own tree);
-// rows are handed around with ds_bpermute so that `lpr` consecutive lanes move one row.
-__device__ inline void wave_copy_rows(const float *src_row, float *dst_row, bool valid, int width) {
+// Random-word staging: for each of the wave's 64 trees, all 64 lanes cooperate on that tree's NEXT 64 words --
+// lane j owns word (idx + j) mod 624; words not yet twisted (j >= ready) are twisted in place (every lane reads
+// its three source words before any lane stores, which is exactly the sequential in-place order because the
+// sources of word p are p, p+1 and p+397 and at most 64 consecutive words change) -- and the tempered words go to
+// this wave's LDS tile [tree lane][word].  Global traffic is coalesced 256-byte segments.  Returns the lane's
+// packed (ready << 16 | idx) after staging.
+__device__ inline int wave_stage_rng(const Params &P, int tree, bool valid, uint32_t *lds_tile) {
+    constexpr int U = 16;   // trees in flight: their loads are all issued before the first dependent store
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tree0 = tree - lane;
+    const int packed = valid ? P.rng_pos[tree] : 0;
+    for (int t0 = 0; t0 < P.tpw; t0 += U) {
+        uint32_t w[U], b[U], c[U];
+        int pos[U];
+        bool tw[U], vt[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int pk = __shfl(packed, t0 + u);
+            vt[u] = __shfl((int)valid, t0 + u) != 0;          // wave-uniform
+            const int idx = pk & 0xffff, ready = pk >> 16;
+            const uint32_t *mt = P.mt + (size_t)(tree0 + t0 + u) * kMtN;
+            int p = idx + lane;
+            if (p >= kMtN) p -= kMtN;
+            pos[u] = p;
+            tw[u] = vt[u] && lane >= ready;
+            w[u] = b[u] = c[u] = 0u;
+            if (vt[u]) w[u] = mt[p];
+            if (tw[u]) {
+                const int p1 = (p + 1 == kMtN) ? 0 : p + 1;
+                int pm = p + kMtM;
+                if (pm >= kMtN) pm -= kMtN;
+                b[u] = mt[p1];
+                c[u] = mt[pm];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (tw[u]) {
+                w[u] = mt_twist(w[u], b[u], c[u]);
+                (P.mt + (size_t)(tree0 + t0 + u) * kMtN)[pos[u]] = w[u];
+            }
+            if (vt[u]) lds_tile[(t0 + u) * kRngStride + lane] = mt_temper(w[u]);
+        }
+    }
+    const int idx = packed & 0xffff, ready = packed >> 16;
+    return ((ready > kRngStage ? ready : kRngStage) << 16) | idx;
+}
+
+// Row moves.  `lpr` consecutive lanes move one row of `width` floats; the rows of the wave's 64 trees are handed
+// around with ds_bpermute.  Loads of kRowBatch rows are issued before the first store so that the (independent)
+// row reads overlap instead of each waiting behind the previous row's may-alias store.
+constexpr int kRowBatch = 16;
+
+// Moves one row per tree of this wave.  src_row/dst_row are per-lane row pointers (of the lane's own tree).
+// Every lane executes every shuffle (a lane whose column index falls outside the row still serves as a source).
+__device__ inline void wave_copy_rows(const float *src_row, float *dst_row, bool valid, int width, int tpw) {
     const RowGeom g = row_geom(width);
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane / g.lpr, li = lane % g.lpr;
     const unsigned long long s64 = (unsigned long long)src_row, d64 = (unsigned long long)dst_row;
-    for (int j0 = 0; j0 < kWave; j0 += g.rows_per_iter) {
-        const int j = j0 + sub;
-        const unsigned long long sj = __shfl(s64, j), dj = __shfl(d64, j);
-        const int vj = __shfl((int)valid, j);
-        if (vj) {
-            const float *s = (const float *)sj;
-            float *d = (float *)dj;
-            for (int i = li; i < width; i += g.lpr) d[i] = s[i];
+    const int iters = (tpw + g.rows_per_iter - 1) / g.rows_per_iter;
+    for (int it0 = 0; it0 < iters; it0 += kRowBatch) {
+        unsigned long long sj[kRowBatch], dj[kRowBatch];
+        bool ok[kRowBatch];
+#pragma unroll
+        for (int u = 0; u < kRowBatch; u++) {
+            const int it = it0 + u;
+            const int j = ((it < iters ? it : 0) * g.rows_per_iter + sub) & (kWave - 1);
+            sj[u] = __shfl(s64, j);
+            dj[u] = __shfl(d64, j);
+            ok[u] = (it < iters) && (__shfl((int)valid, j) != 0);
+        }
+        for (int i = li; i < width; i += g.lpr) {                   // one pass per lpr-wide column slab
+            float v[kRowBatch];
+#pragma unroll
+            for (int u = 0; u < kRowBatch; u++) v[u] = ok[u] ? ((const float *)sj[u])[i] : 0.f;
+#pragma unroll
+            for (int u = 0; u < kRowBatch; u++)
+                if (ok[u]) ((float *)dj[u])[i] = v[u];
         }
     }
 }
@@ -82,16 +146,32 @@ __device__ inline void wave_gather_inputs(const Params &P, int tree, bool valid,
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane / g.lpr, li = lane % g.lpr;
     const int tree0 = tree - lane;
-    for (int j0 = 0; j0 < kWave; j0 += g.rows_per_iter) {
-        const int j = j0 + sub;
-        const int pj = __shfl(parent, j), aj = __shfl(act, j), vj = __shfl((int)valid, j);
-        if (vj) {
-            const int t = tree0 + j;
-            const float *src = P.hidden + ((size_t)t * P.N + pj) * S;
-            for (int i = li; i < g.width; i += g.lpr) {
-                const float v = (i < S) ? src[i] : ((i - S) == aj ? 1.0f : 0.0f);
-                if (mlp_input) mlp_input[(size_t)t * W + i] = v;
-                if (parent_hidden && i < S) parent_hidden[(size_t)t * S + i] = v;
+    const int iters = (P.tpw + g.rows_per_iter - 1) / g.rows_per_iter;
+    for (int it0 = 0; it0 < iters; it0 += kRowBatch) {
+        int tj[kRowBatch], pj[kRowBatch], aj[kRowBatch];
+        bool ok[kRowBatch];
+#pragma unroll
+        for (int u = 0; u < kRowBatch; u++) {
+            const int it = it0 + u;
+            const int j = ((it < iters ? it : 0) * g.rows_per_iter + sub) & (kWave - 1);
+            pj[u] = __shfl(parent, j);
+            aj[u] = __shfl(act, j);
+            ok[u] = (it < iters) && (__shfl((int)valid, j) != 0);
+            tj[u] = tree0 + j;
+        }
+        for (int i = li; i < g.width; i += g.lpr) {
+            float v[kRowBatch];
+#pragma unroll
+            for (int u = 0; u < kRowBatch; u++) {
+                v[u] = 0.f;
+                if (ok[u]) v[u] = (i < S) ? P.hidden[((size_t)tj[u] * P.N + pj[u]) * S + i] : ((i - S) == aj[u] ? 1.0f : 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < kRowBatch; u++) {
+                if (ok[u]) {
+                    if (mlp_input) mlp_input[(size_t)tj[u] * W + i] = v[u];
+                    if (parent_hidden && i < S) parent_hidden[(size_t)tj[u] * S + i] = v[u];
+                }
             }
         }
     }
@@ -113,53 +193,70 @@ __device__ inline void wave_add_stats(unsigned long long *stats, unsigned a, uns
     }
 }
 
+// sqrt(n) * pb_c(n) table staged in LDS (dynamic shared memory) when it fits, so that the pUCT loop does not pay a
+// dependent global load per level.
+constexpr int kPbcLdsMax = 4096;
+extern __shared__ double smz_dyn_lds[];
+__device__ inline const double *stage_pbc(const Params &P) {
+    const int n = P.sims + 2;
+    if (n > kPbcLdsMax) return P.pbc_sqrt;
+    for (int i = threadIdx.x; i < n; i += kWave) smz_dyn_lds[i] = P.pbc_sqrt[i];
+    __syncthreads();
+    return smz_dyn_lds;
+}
+
 template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidden, const float *policy,
                                                      const double *noise_override, int train) {
-    const int tree = blockIdx.x * kWave + threadIdx.x;
-    const bool valid = tree < P.B;
+    __shared__ uint32_t rng_tile[kWave * kRngStride];
+    const int tree = blockIdx.x * P.tpw + threadIdx.x;
+    const bool valid = (int)threadIdx.x < P.tpw && tree < P.B;
+    const int packed = wave_stage_rng(P, tree, valid, rng_tile);
     if (valid) {
         Rng rng;
-        rng.load(P.mt + (size_t)tree * kMtN, P.rng_pos[tree]);
+        rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + threadIdx.x * kRngStride, kRngStage);
         root_init_tree<MAXA>(P, tree, rng, policy + (size_t)tree * P.A,
                              noise_override ? noise_override + (size_t)tree * P.A : nullptr, train != 0);
         P.rng_pos[tree] = rng.pack();
     }
     if (P.S > 0 && hidden) {
         const int t = valid ? tree : 0;
-        wave_copy_rows(hidden + (size_t)t * P.S, P.hidden + (size_t)t * P.N * P.S, valid, P.S);
+        wave_copy_rows(hidden + (size_t)t * P.S, P.hidden + (size_t)t * P.N * P.S, valid, P.S, P.tpw);
     }
 }
 
 template <int MAXA>
-__device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &rng, TreeHdr &h, float *parent_hidden,
-                                    int32_t *last_action, uint8_t *branch, float *mlp_input) {
+__device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &rng, TreeHdr &h, const double *pbc_lds,
+                                    float *parent_hidden, int32_t *last_action, uint8_t *branch, float *mlp_input) {
     Leaf L = {0, 0, 0, 0};
     unsigned n_dec = 0, n_chance = 0, n_children = 0;
     if (valid) {
         int len = 0;
-        L = select_tree<MAXA>(P, tree, rng, h.mn, h.mx, len, n_dec, n_chance, n_children);
+        L = select_tree<MAXA>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children);
         h.path_len = len;
         if (last_action) last_action[tree] = L.action;
         if (branch) branch[tree] = (uint8_t)L.branch;
     }
     if (P.S > 0 && (parent_hidden || mlp_input))
-        wave_gather_inputs(P, tree, valid, L.parent, L.action, parent_hidden, mlp_input);
+        wave_gather_inputs(P, tree, valid, L.parent_id, L.action, parent_hidden, mlp_input);
     wave_add_stats(P.stats, n_dec, n_chance, valid ? 1u : 0u, n_children);
 }
 
 template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_select(Params P, float *parent_hidden, int32_t *last_action,
                                                   uint8_t *branch, float *mlp_input) {
-    const int tree = blockIdx.x * kWave + threadIdx.x;
-    const bool valid = tree < P.B;
+    __shared__ uint32_t rng_tile[kWave * kRngStride];
+    const int tree = blockIdx.x * P.tpw + threadIdx.x;
+    const bool valid = (int)threadIdx.x < P.tpw && tree < P.B;
+    const double *pbc_lds = stage_pbc(P);
+    const int packed = wave_stage_rng(P, tree, valid, rng_tile);
     Rng rng;
-    TreeHdr h = {0, 0, 0.f, 0.f};
+    TreeHdr h = {0, 0, 0.f, 0.f, 0, 0.f, 0, 0};
     if (valid) {
-        rng.load(P.mt + (size_t)tree * kMtN, P.rng_pos[tree]);
+        rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + threadIdx.x * kRngStride, kRngStage);
         h = P.hdr[tree];
     }
-    select_phase<MAXA>(P, tree, valid, rng, h, parent_hidden, last_action, branch, mlp_input);
+    select_phase<MAXA>(P, tree, valid, rng, h, pbc_lds, parent_hidden, last_action, branch, mlp_input);
     if (valid) {
         P.rng_pos[tree] = rng.pack();
         P.hdr[tree] = h;
@@ -171,26 +268,28 @@ __global__ void __launch_bounds__(kWave) k_expand_backup(Params P, const float *
                                                          const float *policy, const float *value,
                                                          float *parent_hidden, int32_t *last_action, uint8_t *branch,
                                                          float *mlp_input) {
-    const int tree = blockIdx.x * kWave + threadIdx.x;
-    const bool valid = tree < P.B;
+    __shared__ uint32_t rng_tile[kWave * kRngStride];
+    const int tree = blockIdx.x * P.tpw + threadIdx.x;
+    const bool valid = (int)threadIdx.x < P.tpw && tree < P.B;
+    const double *pbc_lds = FUSE_SELECT ? stage_pbc(P) : nullptr;
+    const int packed = wave_stage_rng(P, tree, valid, rng_tile);
     Rng rng;
-    TreeHdr h = {0, 0, 0.f, 0.f};
+    TreeHdr h = {0, 0, 0.f, 0.f, 0, 0.f, 0, 0};
     int leaf = 0;
     if (valid) {
-        rng.load(P.mt + (size_t)tree * kMtN, P.rng_pos[tree]);
+        rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + threadIdx.x * kRngStride, kRngStage);
         h = P.hdr[tree];
-        leaf = P.path[(size_t)tree * P.P + h.path_len - 1];
-        expand_backup_tree<MAXA>(P, tree, rng, h, policy + (size_t)tree * P.A, reward ? reward[tree] : 0.0f,
-                                 value[tree]);
+        leaf = expand_backup_tree<MAXA>(P, tree, rng, h, policy + (size_t)tree * P.A, reward ? reward[tree] : 0.0f,
+                                        value[tree]);
     }
     if (P.S > 0 && hidden) {
         const int t = valid ? tree : 0;
-        wave_copy_rows(hidden + (size_t)t * P.S, P.hidden + ((size_t)t * P.N + leaf) * P.S, valid, P.S);
+        wave_copy_rows(hidden + (size_t)t * P.S, P.hidden + ((size_t)t * P.N + leaf) * P.S, valid, P.S, P.tpw);
     }
     if (FUSE_SELECT) {
         // the leaf rows just written by other lanes of this wave may be the next parent rows
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        select_phase<MAXA>(P, tree, valid, rng, h, parent_hidden, last_action, branch, mlp_input);
+        select_phase<MAXA>(P, tree, valid, rng, h, pbc_lds, parent_hidden, last_action, branch, mlp_input);
     }
     if (valid) {
         P.rng_pos[tree] = rng.pack();
@@ -202,15 +301,16 @@ __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits,
                                                       float *child_reward) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
     if (tree >= P.B) return;
-    const size_t nb = (size_t)tree * P.N;
+    const uint32_t *rb = tree_base(P, tree);
+    const double *rp = (const double *)(rb + P.rp_off);
     for (int a = 0; a < P.A; a++) {
-        if (visits) visits[(size_t)tree * P.A + a] = P.visit[nb + 1 + a];
-        if (priors) priors[(size_t)tree * P.A + a] = P.root_prior[(size_t)tree * P.A + a];
-        if (child_reward) child_reward[(size_t)tree * P.A + a] = P.reward[nb + 1 + a];
+        if (visits) visits[(size_t)tree * P.A + a] = (int32_t)rb[a];
+        if (priors) priors[(size_t)tree * P.A + a] = rp[a];
+        if (child_reward) child_reward[(size_t)tree * P.A + a] = __uint_as_float(rb[2 * P.A + a]);
     }
     if (root_value) {
-        const int rv = P.visit[nb];
-        root_value[tree] = rv ? P.value_sum[nb] / (float)rv : 0.0f;
+        const TreeHdr h = P.hdr[tree];
+        root_value[tree] = h.root_visit ? h.root_value_sum / (float)h.root_visit : 0.0f;
     }
 }
 
@@ -220,71 +320,108 @@ __global__ void __launch_bounds__(kWave) k_act(Params P, double temperature, int
     const int tree = blockIdx.x * kWave + threadIdx.x;
     if (tree >= P.B) return;
     Rng rng;
-    rng.load(P.mt + (size_t)tree * kMtN, P.rng_pos[tree]);
+    rng.load(P.mt + (size_t)tree * kMtN, P.rng_pos[tree], nullptr, 0);
     act_tree<MAXA>(P, tree, rng, temperature, action, policy, child_visits, root_value);
     P.rng_pos[tree] = rng.pack();
 }
 
-// ---- head epilogues ------------------------------------------------------------------------------------------------
-// inverse_transform_with_support on one row held by one lane (muzero_model.py:575-591)
-__device__ inline float support_decode_row(const float *row, int S) {
-    float m = row[0];
-    for (int i = 1; i < S; i++) m = fmaxf(m, row[i]);
+// ---- head epilogues: `lpr` lanes cooperate on one row (coalesced loads, shuffle reductions) ------------------------
+__device__ inline float grp_max(float v, int lpr) {
+    for (int off = lpr >> 1; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ inline float grp_min(float v, int lpr) {
+    for (int off = lpr >> 1; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ inline float grp_sum(float v, int lpr) {
+    for (int off = lpr >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// inverse_transform_with_support of one row by a lane group (muzero_model.py:575-591); every lane gets the result
+__device__ inline float support_decode_group(const float *row, int S, int li, int lpr) {
+    float m = -__builtin_inff();
+    for (int i = li; i < S; i += lpr) m = fmaxf(m, row[i]);
+    m = grp_max(m, lpr);
     float den = 0.f, num = 0.f;
     const int half = S / 2;
-    for (int i = 0; i < S; i++) {
+    for (int i = li; i < S; i += lpr) {
         const float e = expf(row[i] - m);
         den += e;
         num += (float)(i - half) * e;
     }
+    den = grp_sum(den, lpr);
+    num = grp_sum(num, lpr);
     const float y = num / den;
     const float sg = (y > 0.f) ? 1.f : ((y < 0.f) ? -1.f : 0.f);
     const float r = (sqrtf(1.f + 4.f * 0.001f * (fabsf(y) + 1.f + 0.001f)) - 1.f) / (2.f * 0.001f);
     return sg * (r * r - 1.f);
 }
 
-__global__ void __launch_bounds__(256) k_support_decode(const float *logits, int S, float *out, int B) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row < B) out[row] = support_decode_row(logits + (size_t)row * S, S);
-}
-
-__device__ inline void softmax_row(const float *row, int A, float *out) {
-    float m = row[0];
-    for (int i = 1; i < A; i++) m = fmaxf(m, row[i]);
+__device__ inline void softmax_group(const float *row, int A, float *out, int li, int lpr) {
+    float m = -__builtin_inff();
+    for (int i = li; i < A; i += lpr) m = fmaxf(m, row[i]);
+    m = grp_max(m, lpr);
     float den = 0.f;
-    for (int i = 0; i < A; i++) den += expf(row[i] - m);
-    for (int i = 0; i < A; i++) out[i] = expf(row[i] - m) / den;
+    for (int i = li; i < A; i += lpr) den += expf(row[i] - m);
+    den = grp_sum(den, lpr);
+    for (int i = li; i < A; i += lpr) out[i] = expf(row[i] - m) / den;
 }
 
-__global__ void __launch_bounds__(256) k_policy_softmax(const float *logits, int A, float *out, int B) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row < B) softmax_row(logits + (size_t)row * A, A, out + (size_t)row * A);
+__global__ void __launch_bounds__(256) k_support_decode(const float *logits, int S, float *out, int B, int lpr) {
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
+    const int row = gid < B ? gid : B - 1;     // surplus groups recompute the last row (keeps shuffles convergent)
+    const float v = support_decode_group(logits + (size_t)row * S, S, li, lpr);
+    if (gid < B && li == 0) out[row] = v;
+}
+
+__global__ void __launch_bounds__(256) k_policy_softmax(const float *logits, int A, float *out, int B, int lpr) {
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
+    if (gid < B) softmax_group(logits + (size_t)gid * A, A, out + (size_t)gid * A, li, lpr);
+    else { float dummy[1]; softmax_group(logits + (size_t)(B - 1) * A, 0, dummy, li, lpr); }
 }
 
 __global__ void __launch_bounds__(256) k_dynamics_epilogue(const float *state_dyn, const float *state_after,
                                                            const float *reward_logits, int ld, const uint8_t *branch,
-                                                           int S, float *hidden_out, float *reward_out, int B) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= B) return;
+                                                           int S, float *hidden_out, float *reward_out, int B, int lpr) {
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
+    const int row = gid < B ? gid : B - 1;
+    const bool live = gid < B;
     const bool dyn = branch[row] != 0;
     const float *x = (dyn ? state_dyn : state_after) + (size_t)row * ld;
-    float mn = x[0], mx = x[0];
-    for (int i = 1; i < S; i++) { mn = fminf(mn, x[i]); mx = fmaxf(mx, x[i]); }
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    for (int i = li; i < S; i += lpr) { const float v = x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    mn = grp_min(mn, lpr);
+    mx = grp_max(mx, lpr);
     float sc = mx - mn;
     if (sc < 1e-5f) sc += 1e-5f;  // neural_network_mlp_model.py:353
-    for (int i = 0; i < S; i++) hidden_out[(size_t)row * S + i] = (x[i] - mn) / sc;
-    if (reward_out) reward_out[row] = (dyn && reward_logits) ? support_decode_row(reward_logits + (size_t)row * ld, S) : 0.f;
+    if (live) for (int i = li; i < S; i += lpr) hidden_out[(size_t)row * S + i] = (x[i] - mn) / sc;
+    if (reward_out) {
+        float r = 0.f;
+        if (reward_logits) r = support_decode_group(reward_logits + (size_t)row * ld, S, li, lpr);
+        if (live && li == 0) reward_out[row] = dyn ? r : 0.f;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pred, const float *val_pred,
                                                              const float *pol_after, const float *val_after,
                                                              int ld, const uint8_t *branch, int A, int S,
-                                                             float *policy_out, float *value_out, int B) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= B) return;
+                                                             float *policy_out, float *value_out, int B, int lpr) {
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
+    const int row = gid < B ? gid : B - 1;
+    const bool live = gid < B;
     const bool dyn = branch[row] != 0;
-    softmax_row((dyn ? pol_pred : pol_after) + (size_t)row * ld, A, policy_out + (size_t)row * A);
-    value_out[row] = support_decode_row((dyn ? val_pred : val_after) + (size_t)row * ld, S);
+    const float *pl = (dyn ? pol_pred : pol_after) + (size_t)row * ld;
+    float m = -__builtin_inff();
+    for (int i = li; i < A; i += lpr) m = fmaxf(m, pl[i]);
+    m = grp_max(m, lpr);
+    float den = 0.f;
+    for (int i = li; i < A; i += lpr) den += expf(pl[i] - m);
+    den = grp_sum(den, lpr);
+    if (live) for (int i = li; i < A; i += lpr) policy_out[(size_t)row * A + i] = expf(pl[i] - m) / den;
+    const float v = support_decode_group((dyn ? val_pred : val_after) + (size_t)row * ld, S, li, lpr);
+    if (live && li == 0) value_out[row] = v;
 }
 
 // ---- synthetic env + trajectory record ---------------------------------------------------------------------------
@@ -398,7 +535,11 @@ int dev_alloc(smz_handle *h, T **out, size_t count) {
 }
 
 inline dim3 tree_grid(int B) { return dim3((unsigned)((B + kWave - 1) / kWave)); }
+inline dim3 wave_grid(const Params &P) { return dim3((unsigned)((P.B + P.tpw - 1) / P.tpw)); }
+inline size_t pbc_lds_bytes(const Params &P) { return (P.sims + 2 <= kPbcLdsMax) ? (size_t)(P.sims + 2) * sizeof(double) : 0; }
 inline dim3 row_grid(int B) { return dim3((unsigned)((B + 255) / 256)); }
+inline int group_lanes(int width) { int l = 1; while (l < width && l < kWave) l <<= 1; return l; }
+inline dim3 group_grid(int B, int lpr) { const int per = 256 / lpr; return dim3((unsigned)((B + per - 1) / per)); }
 
 int launch_check() {
     hipError_t e = hipGetLastError();
@@ -468,21 +609,29 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     Params &P = h->P;
     memset(&P, 0, sizeof(P));
     P.B = B; P.A = A; P.K = h->K; P.S = S; P.N = h->N; P.P = h->Ppath; P.sims = sims;
+    {   // trees per wavefront: spread small batches over the whole chip (>= 1 wave per SIMD before packing lanes)
+        int tpw = kWave;
+        while (tpw > 4 && (B + tpw - 1) / tpw < 1024) tpw >>= 1;
+        if (const char *e = getenv("SMZ_TREES_PER_WAVE")) {
+            const int v = atoi(e);
+            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) tpw = v;
+        }
+        P.tpw = tpw;
+    }
     P.disc32 = (float)cfg->discount;
     P.keep32 = (float)(1.0 - cfg->root_exploration_fraction);
     P.frac = cfg->root_exploration_fraction;
     P.alpha = cfg->root_dirichlet_alpha;
     const size_t BN = (size_t)B * h->N;
+    // child-block geometry (16-word = 64-byte granules so that a block never straddles more lines than it must)
+    P.rp_off = (5 * A + 1) & ~1;
+    P.rb_words = ((P.rp_off + 2 * A) + 15) & ~15;
+    P.eb_words = ((6 * h->K) + 15) & ~15;
+    P.tree_words = (int64_t)P.rb_words + (int64_t)sims * P.eb_words;
     int rc = SMZ_OK;
     auto A_ = [&](int r) { if (rc == SMZ_OK) rc = r; };
-    A_(dev_alloc(h, &P.visit, BN));
-    A_(dev_alloc(h, &P.value_sum, BN));
-    A_(dev_alloc(h, &P.reward, BN));
-    A_(dev_alloc(h, &P.prior, BN));
-    A_(dev_alloc(h, &P.child_base, BN));
-    A_(dev_alloc(h, &P.action, BN));
+    A_(dev_alloc(h, &P.nodes, (size_t)B * (size_t)P.tree_words));
     A_(dev_alloc(h, &P.hidden, BN * (size_t)S));
-    A_(dev_alloc(h, &P.root_prior, (size_t)B * A));
     A_(dev_alloc(h, &P.hdr, (size_t)B));
     A_(dev_alloc(h, &P.path, (size_t)B * h->Ppath));
     A_(dev_alloc(h, &P.mt, (size_t)B * kMtN));
@@ -498,8 +647,8 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     P.pbc_sqrt = h->d_pbc;
     P.pow_table = nullptr;
     P.stats = nullptr;
-    // defined contents before first use (child_base == 0 <=> not expanded)
-    hipError_t e = hipMemset(P.child_base, 0, BN * sizeof(int32_t));
+    // defined contents before first use
+    hipError_t e = hipMemset(P.nodes, 0, (size_t)B * (size_t)P.tree_words * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(P.hdr, 0, (size_t)B * sizeof(TreeHdr));
     if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(P.rng_pos, 0, (size_t)B * sizeof(int32_t));
@@ -573,16 +722,35 @@ int smz_get_rng_state(smz_handle *h, int tree, uint32_t *host_key, int *pos) {
     HIP_TRY(hipMemcpy(host_key, h->P.mt + (size_t)tree * kMtN, kMtN * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&packed, h->P.rng_pos + tree, sizeof(int32_t), hipMemcpyDeviceToHost));
     const int idx = packed & 0xffff, ready = packed >> 16;
-    if (ready > 0) { *pos = idx; return SMZ_OK; }       // still inside an imported block
-    if (idx == 0) { *pos = kMtN; return SMZ_OK; }        // block boundary: numpy regenerates on the next draw
-    // words [0, idx) belong to the new block, [idx, 624) to the previous one: finish the in-place twist
-    for (int i = idx; i < kMtN; i++) {
+    // Device form: words [idx, idx+ready) (cyclic) are twisted ahead of consumption, everything already consumed in
+    // this pass is twisted, the rest still holds the previous block.  numpy's form wants one complete block + pos.
+    auto twist_at = [&](int i) {
         const int i1 = (i + 1 == kMtN) ? 0 : i + 1;
         int im = i + kMtM;
         if (im >= kMtN) im -= kMtN;
         const uint32_t t = (host_key[i] & 0x80000000u) | (host_key[i1] & 0x7fffffffu);
         host_key[i] = host_key[im] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+    };
+    if (idx + ready <= kMtN) {
+        if (idx == 0 && ready == 0) { *pos = kMtN; return SMZ_OK; }   // block boundary: numpy regenerates next
+        for (int i = idx + ready; i < kMtN; i++) twist_at(i);          // finish the in-place pass
+        *pos = idx;
+        return SMZ_OK;
     }
+    // The twist-ahead window wrapped: words [0, w) already hold NEXT-block values.  Recover the current-block words
+    // they replaced by inverting the twist (new[k] ^ cur[k+397] gives the msb of cur[k] and the low 31 bits of
+    // cur[k+1]; the low bits of cur[0] are never read again by the generator and are left zero).
+    const int w = idx + ready - kMtN;
+    if (w + kMtM > kMtN) return fail(SMZ_ERR_STATE, "smz_get_rng_state: twist-ahead window too long%s");
+    std::vector<uint32_t> t((size_t)w);
+    for (int k = 0; k < w; k++) {
+        uint32_t y = host_key[k] ^ host_key[k + kMtM];
+        uint32_t low = 0;
+        if (y & 0x80000000u) { y ^= 0x9908b0dfu; low = 1u; }
+        t[k] = (y << 1) | low;                                       // (cur[k] & UPPER) | (cur[k+1] & LOWER)
+    }
+    for (int k = 0; k < w; k++)
+        host_key[k] = (t[k] & 0x80000000u) | (k > 0 ? (t[k - 1] & 0x7fffffffu) : 0u);
     *pos = idx;
     return SMZ_OK;
 }
@@ -614,7 +782,7 @@ int smz_root_init(smz_handle *h, const float *hidden_dev, const float *policy_de
     if (train && h->cfg.num_simulations > 0 && !(h->cfg.root_dirichlet_alpha > 0))
         return fail(SMZ_ERR_INVALID, "root_dirichlet_alpha must be > 0 to draw noise (numpy raises ValueError)%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_root_init<MA>), tree_grid(h->P.B), dim3(kWave), 0, (hipStream_t)stream,
+    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_root_init<MA>), wave_grid(h->P), dim3(kWave), 0, (hipStream_t)stream,
                                              h->P, hidden_dev, policy_dev, noise_override_dev, train));
     h->root_ready = true;
     h->selected = false;
@@ -626,7 +794,7 @@ int smz_select(smz_handle *h, float *parent_hidden_dev, int32_t *last_action_dev
     if (!h) return fail(SMZ_ERR_INVALID, "smz_select: null handle%s");
     if (!h->root_ready) return fail(SMZ_ERR_STATE, "smz_select before smz_root_init%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_select<MA>), tree_grid(h->P.B), dim3(kWave), 0, (hipStream_t)stream, h->P,
+    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_select<MA>), wave_grid(h->P), dim3(kWave), pbc_lds_bytes(h->P), (hipStream_t)stream, h->P,
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
     h->selected = true;
     return launch_check();
@@ -637,7 +805,7 @@ int smz_expand_backup(smz_handle *h, const float *hidden_dev, const float *rewar
     if (!h || !policy_dev || !value_dev) return fail(SMZ_ERR_INVALID, "smz_expand_backup: null argument%s");
     if (!h->selected) return fail(SMZ_ERR_STATE, "smz_expand_backup without a preceding smz_select%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, false>), tree_grid(h->P.B), dim3(kWave), 0,
+    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, false>), wave_grid(h->P), dim3(kWave), 0,
                                              (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev,
                                              (float *)nullptr, (int32_t *)nullptr, (uint8_t *)nullptr, (float *)nullptr));
     h->selected = false;
@@ -650,7 +818,7 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
     if (!h || !policy_dev || !value_dev) return fail(SMZ_ERR_INVALID, "smz_expand_backup_select: null argument%s");
     if (!h->selected) return fail(SMZ_ERR_STATE, "smz_expand_backup_select without a preceding smz_select%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, true>), tree_grid(h->P.B), dim3(kWave), 0,
+    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, true>), wave_grid(h->P), dim3(kWave), pbc_lds_bytes(h->P),
                                              (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev,
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
     return launch_check();
@@ -690,13 +858,15 @@ int smz_act(smz_handle *h, double temperature, const double *pow_table_host, int
 
 int smz_support_decode(const float *logits_dev, int S, float *out_dev, int B, smz_stream stream) {
     if (!logits_dev || !out_dev || S < 1 || B < 1) return fail(SMZ_ERR_INVALID, "smz_support_decode: bad argument%s");
-    hipLaunchKernelGGL(k_support_decode, row_grid(B), dim3(256), 0, (hipStream_t)stream, logits_dev, S, out_dev, B);
+    const int lpr = group_lanes(S);
+    hipLaunchKernelGGL(k_support_decode, group_grid(B, lpr), dim3(256), 0, (hipStream_t)stream, logits_dev, S, out_dev, B, lpr);
     return launch_check();
 }
 
 int smz_policy_softmax(const float *logits_dev, int A, float *out_dev, int B, smz_stream stream) {
     if (!logits_dev || !out_dev || A < 1 || B < 1) return fail(SMZ_ERR_INVALID, "smz_policy_softmax: bad argument%s");
-    hipLaunchKernelGGL(k_policy_softmax, row_grid(B), dim3(256), 0, (hipStream_t)stream, logits_dev, A, out_dev, B);
+    const int lpr = group_lanes(A);
+    hipLaunchKernelGGL(k_policy_softmax, group_grid(B, lpr), dim3(256), 0, (hipStream_t)stream, logits_dev, A, out_dev, B, lpr);
     return launch_check();
 }
 
@@ -705,8 +875,9 @@ int smz_dynamics_epilogue(const float *state_dyn_dev, const float *state_after_d
                           smz_stream stream) {
     if (!state_dyn_dev || !state_after_dev || !branch_dev || !hidden_out_dev || S < 1 || B < 1 || ld < S)
         return fail(SMZ_ERR_INVALID, "smz_dynamics_epilogue: bad argument%s");
-    hipLaunchKernelGGL(k_dynamics_epilogue, row_grid(B), dim3(256), 0, (hipStream_t)stream, state_dyn_dev, state_after_dev,
-                       reward_logits_dev, ld, branch_dev, S, hidden_out_dev, reward_out_dev, B);
+    const int lpr = group_lanes(S);
+    hipLaunchKernelGGL(k_dynamics_epilogue, group_grid(B, lpr), dim3(256), 0, (hipStream_t)stream, state_dyn_dev,
+                       state_after_dev, reward_logits_dev, ld, branch_dev, S, hidden_out_dev, reward_out_dev, B, lpr);
     return launch_check();
 }
 
@@ -717,9 +888,10 @@ int smz_prediction_epilogue(const float *policy_logits_pred_dev, const float *va
     if (!policy_logits_pred_dev || !value_logits_pred_dev || !policy_logits_after_dev || !value_logits_after_dev ||
         !branch_dev || !policy_out_dev || !value_out_dev || A < 1 || S < 1 || B < 1 || ld < 1)
         return fail(SMZ_ERR_INVALID, "smz_prediction_epilogue: bad argument%s");
-    hipLaunchKernelGGL(k_prediction_epilogue, row_grid(B), dim3(256), 0, (hipStream_t)stream, policy_logits_pred_dev,
+    const int lpr = group_lanes(S > A ? S : A);
+    hipLaunchKernelGGL(k_prediction_epilogue, group_grid(B, lpr), dim3(256), 0, (hipStream_t)stream, policy_logits_pred_dev,
                        value_logits_pred_dev, policy_logits_after_dev, value_logits_after_dev, ld, branch_dev, A, S,
-                       policy_out_dev, value_out_dev, B);
+                       policy_out_dev, value_out_dev, B, lpr);
     return launch_check();
 }
 
@@ -750,32 +922,47 @@ int smz_debug_dump_tree(smz_handle *h, int tree, smz_node_view *nodes, int cap, 
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     const Params &P = h->P;
+    const int A = P.A, K = P.K;
     TreeHdr hdr;
     HIP_TRY(hipMemcpy(&hdr, P.hdr + tree, sizeof(hdr), hipMemcpyDeviceToHost));
-    const int n = hdr.alloc;
+    std::vector<uint32_t> blob((size_t)P.tree_words);
+    HIP_TRY(hipMemcpy(blob.data(), P.nodes + (size_t)tree * P.tree_words, (size_t)P.tree_words * 4, hipMemcpyDeviceToHost));
+    const int n = 1 + A + hdr.n_exp * K;
+    auto f32 = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
     if (nodes && cap > 0) {
-        const int m = n < cap ? n : cap;
-        std::vector<int32_t> vi((size_t)m), cb((size_t)m), ac((size_t)m);
-        std::vector<float> vs((size_t)m), rw((size_t)m), pr((size_t)m);
-        const size_t off = (size_t)tree * P.N;
-        if (m > 0) {
-            HIP_TRY(hipMemcpy(vi.data(), P.visit + off, (size_t)m * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(vs.data(), P.value_sum + off, (size_t)m * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(rw.data(), P.reward + off, (size_t)m * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(pr.data(), P.prior + off, (size_t)m * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(cb.data(), P.child_base + off, (size_t)m * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(ac.data(), P.action + off, (size_t)m * 4, hipMemcpyDeviceToHost));
+        // flatten the child blocks back to creation-order node ids (root 0, its children 1..A, expansion e at 1+A+e*K)
+        if (cap > 0) nodes[0] = smz_node_view{hdr.root_visit, hdr.root_value_sum, 0.f, 0.f, 1, 0};
+        for (int a = 0; a < A && 1 + a < cap; a++) {
+            const uint32_t *rb = blob.data();
+            const int c = (int)rb[4 * A + a];
+            nodes[1 + a] = smz_node_view{(int32_t)rb[a], f32(rb[A + a]), f32(rb[2 * A + a]), f32(rb[3 * A + a]),
+                                         c ? 1 + A + (c - 1) * K : 0, a};
         }
-        for (int i = 0; i < m; i++) nodes[i] = smz_node_view{vi[i], vs[i], rw[i], pr[i], cb[i], ac[i]};
+        for (int e = 0; e < hdr.n_exp; e++) {
+            const uint32_t *eb = blob.data() + P.rb_words + (size_t)e * P.eb_words;
+            for (int j = 0; j < K; j++) {
+                const int id = 1 + A + e * K + j;
+                if (id >= cap) break;
+                const int c = (int)eb[4 * K + j];
+                nodes[id] = smz_node_view{(int32_t)eb[j], f32(eb[K + j]), f32(eb[2 * K + j]), f32(eb[3 * K + j]),
+                                          c ? 1 + A + (c - 1) * K : 0, (int32_t)eb[5 * K + j]};
+            }
+        }
     }
     if (minmax_out) { minmax_out[0] = hdr.mn; minmax_out[1] = hdr.mx; }
-    if (path_len_out) *path_len_out = hdr.path_len;
-    if (path_out && cap_path > 0 && hdr.path_len > 0) {
-        const int m = hdr.path_len < cap_path ? hdr.path_len : cap_path;
-        HIP_TRY(hipMemcpy(path_out, P.path + (size_t)tree * P.P, (size_t)m * 4, hipMemcpyDeviceToHost));
+    // the recorded path as node ids, root first (the device stores (block << 8 | slot) without the root)
+    const int plen = hdr.path_len > 0 ? hdr.path_len + 1 : 0;
+    if (path_len_out) *path_len_out = plen;
+    if (path_out && cap_path > 0 && plen > 0) {
+        std::vector<int32_t> locs((size_t)hdr.path_len);
+        HIP_TRY(hipMemcpy(locs.data(), P.path + (size_t)tree * P.P, (size_t)hdr.path_len * 4, hipMemcpyDeviceToHost));
+        path_out[0] = 0;
+        for (int i = 0; i < hdr.path_len && i + 1 < cap_path; i++) {
+            const int blk = locs[i] >> 8, slot = locs[i] & 0xff;
+            path_out[i + 1] = blk == 0 ? 1 + slot : 1 + A + (blk - 1) * K + slot;
+        }
     }
-    if (root_priors_out)
-        HIP_TRY(hipMemcpy(root_priors_out, P.root_prior + (size_t)tree * P.A, (size_t)P.A * 8, hipMemcpyDeviceToHost));
+    if (root_priors_out) memcpy(root_priors_out, blob.data() + P.rp_off, (size_t)A * 8);
     return n;
 }
 

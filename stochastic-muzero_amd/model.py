@@ -188,8 +188,10 @@ class Muzero:
         return m
 
     # ---- batched heads for the GPU engine -----------------------------------------------------------------------
-    def heads(self, device):
-        key = str(device)
+    def heads(self, device, instance=0):
+        """Batched evaluator on `device`.  `instance` distinguishes evaluators that must not share output buffers
+        (one per concurrently running stream group)."""
+        key = (str(device), instance)
         if key not in self._heads:
             if self.model_structure == "mlp_model":
                 arrays = mlp_arrays_from_modules(self.representation_function, self.prediction_function,

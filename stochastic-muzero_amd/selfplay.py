@@ -142,6 +142,43 @@ def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
     return chunk
 
 
+class StreamGroup:
+    """One slice of a rank's environments with its own engine, head buffers, trajectory chunk and HIP stream.
+
+    At 4096 envs every kernel of a simulation round is latency/launch bound and occupies a small part of the chip,
+    so a rank splits its envs into G independent groups and runs each group's (captured) search on its own stream:
+    the groups' kernels overlap on the GPU.  Trees are independent, so results do not depend on the grouping."""
+
+    def __init__(self, env, heads, mcts, steps, stream=None):
+        self.env, self.heads, self.mcts = env, heads, mcts
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=env.device)
+        self.chunk = TrajectoryChunk(steps, env.B, env.obs_dim, env.num_actions, env.device)
+
+
+def play_games_grouped(groups, temperature, steps, train=True):
+    """play_games for several StreamGroups concurrently: step t of every group is enqueued before step t+1 of any,
+    each on its group's stream; the caller's stream waits for all of them at the end."""
+    dev = groups[0].env.device
+    cur = torch.cuda.current_stream(dev)
+    for g in groups:
+        g.stream.wait_stream(cur)
+    lib = _lib.load()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    for t in range(steps):
+        for g in groups:
+            with torch.cuda.stream(g.stream):
+                env = g.env
+                eng = g.mcts.run(env.obs, g.heads, train=train)
+                action, policy, child_visits, root_value = eng.act(temperature)
+                obs, reward, terminated = env.step(action)
+                _lib.check(lib.smz_traj_pack(P(g.chunk.data), g.chunk.T, t, env.obs_dim, env.num_actions, P(obs),
+                                             P(reward), P(terminated), P(action), P(policy), P(child_visits),
+                                             P(root_value), env.B, C.c_void_p(g.stream.cuda_stream)))
+    for g in groups:
+        cur.wait_stream(g.stream)
+    return [g.chunk for g in groups]
+
+
 def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None, gather=None, priority_scale=1,
                         ignore_termination=False):
     """Self-play half of one learning_cycle iteration (self_play.py:245-271): play, gather to the learner rank,

@@ -75,10 +75,14 @@ def test_dynamics_and_prediction_epilogues(B, A, S):
     ref_r = torch.where(m, _ref_decode(rl), torch.zeros_like(rw))
     torch.testing.assert_close(rw, ref_r, rtol=1e-4, atol=5e-4)
     assert (rw[~m] == 0).all()
-    pp, pa = (torch.randn(B, A, generator=g).cuda() * 2 for _ in range(2))
-    vp, va = (torch.randn(B, S, generator=g).cuda() * 2 for _ in range(2))
+    # prediction epilogue: the four logit blocks are column slices of one [B, 2A+2S] GEMM output (row stride ld)
+    ld = 2 * A + 2 * S
+    q = (torch.randn(B, ld, generator=g) * 2).cuda()
+    pp, vp, pa, va = q[:, :A], q[:, A:A + S], q[:, A + S:2 * A + S], q[:, 2 * A + S:]
+    fs = q.element_size()
+    ptr = lambda off: C.c_void_p(q.data_ptr() + off * fs)
     pol = torch.empty(B, A, device="cuda"); val = torch.empty(B, device="cuda")
-    smz._lib.check(lib.smz_prediction_epilogue(_p(pp), _p(vp), _p(pa), _p(va), max(A, S), _p(br), A, S, _p(pol), _p(val), B, _s()))
+    smz._lib.check(lib.smz_prediction_epilogue(ptr(0), ptr(A), ptr(A + S), ptr(2 * A + S), ld, _p(br), A, S, _p(pol), _p(val), B, _s()))
     torch.testing.assert_close(pol, torch.where(m[:, None], torch.softmax(pp, -1), torch.softmax(pa, -1)), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(val, torch.where(m, _ref_decode(vp), _ref_decode(va)), rtol=1e-4, atol=5e-4)
 

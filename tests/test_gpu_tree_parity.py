@@ -140,6 +140,32 @@ def test_rng_state_roundtrip_with_numpy():
         assert r.random_sample() == expected[tree]
 
 
+def test_exported_stream_is_exact_across_block_boundaries():
+    """The kernels twist MT19937 words ahead of consumption (64 per launch); the exported numpy state must still
+    continue the stream exactly, including when the twist-ahead window straddles the 624-word block boundary."""
+    import gpu_harness as gh
+    cfg = dict(maxium_action_sample=2, pb_c_base=19652, pb_c_init=1.25, discount=0.99, root_dirichlet_alpha=0.25,
+               root_exploration_fraction=0.25)
+    B, A = 3, 3
+    eng = gh.make_engine(cfg, A, 2, 6, B)
+    eng.seed(np.array([11, 12, 13], np.uint64))
+    refs = [np.random.RandomState(s) for s in (11, 12, 13)]
+    pol = np.array([[0.2, 0.3, 0.5]] * B, np.float32)
+    p = pol[0] + 1e-12; p = p / p.sum()
+    d_pol = gh.dev(pol); d_hid = torch.zeros(B, 2, device="cuda")
+    wrapped = 0
+    for it in range(150):
+        eng.root_init(d_hid, d_pol, train=True)
+        for t in range(B):
+            refs[t].choice(A, A, p=p, replace=False); refs[t].dirichlet([0.25] * A)
+            key, pos = eng.get_rng_state(t)
+            r = np.random.RandomState(0); r.set_state(("MT19937", key, pos, 0, 0.0))
+            wrapped += int(pos > 624 - 64)
+            cont = np.random.RandomState(0); cont.set_state(refs[t].get_state())
+            assert np.array_equal(r.random_sample(1400), cont.random_sample(1400)), (it, t, pos)
+    assert wrapped > 10      # the straddling case was exercised
+
+
 @pytest.mark.parametrize("A,K,S,sims,B", [(2, 2, 31, 50, 512), (4, 2, 31, 50, 256), (4, 4, 8, 30, 256),
                                            (11, 9, 16, 20, 128), (18, 5, 3, 16, 128), (32, 32, 4, 6, 64),
                                            (3, 1, 5, 40, 100), (2, 2, 0, 20, 70), (1, 1, 2, 12, 65)])
