@@ -422,10 +422,31 @@ def gen_selfplay(ref, mz, name, sims, temperature, limit, seed):
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB, {len(steps)} steps)")
 
 
+def gen_temperature_schedule(ref):
+    """temperature_scheduler (self_play.py:124-163) tabulated for every mode over a few horizon lengths."""
+    modes = ["reversal_tanh_temperature", "extreme_temperature", "linear_decrease_temperature",
+             "static_temperature", "static_one_temperature"]
+    rows = []
+    for mi, mode in enumerate(modes):
+        for epoch in (1, 2, 7, 100, 701):
+            for actual in sorted(set([1, 2, epoch // 7 + 1, epoch // 2, epoch // 2 + 1, (3 * epoch) // 4 + 1, epoch])):
+                if not 1 <= actual <= epoch:
+                    continue
+                t = ref.self_play.temperature_scheduler(epoch, actual, mode)
+                t = np.nan if t is None else float(np.asarray(t).reshape(-1)[0])
+                rows.append((mi, epoch, actual, t))
+    path = os.path.join(OUT, "temperature_schedule.npz")
+    np.savez_compressed(path, modes=np.array(modes), rows=np.array(rows, np.float64))
+    print(f"wrote {path} ({len(rows)} rows)")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = R.import_reference()
     torch.set_num_threads(1)
+    gen_temperature_schedule(ref)
+    if os.environ.get("SMZ_GOLDEN_ONLY") == "temperature":
+        return
 
     base = dict(pb_c_base=19652, pb_c_init=1.25, discount=0.999, root_dirichlet_alpha=0.25,
                 root_exploration_fraction=0.1, maxium_action_sample=2, number_of_player=1, custom_loop=None)

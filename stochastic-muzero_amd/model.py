@@ -124,6 +124,7 @@ class Muzero:
         if model_update_or_backtrack is not None:
             return
         os.makedirs(directory, exist_ok=True)
+        install_compat_modules()      # the pickles must name neural_network_mlp_model.* like the reference's
         if tag:
             self.random_tag = tag
         for f in _FUNCS:

@@ -1,0 +1,179 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/smz.h declares (no compute without a
+GPU), and the host-side mirrors of the reference's interfaces behave like the reference (goldens from
+oracle/gen_golden.py)."""
+import ctypes as C
+import os
+import re
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pkg(name):
+    import stochastic_muzero_amd  # noqa: F401
+    return import_module("stochastic-muzero_amd." + name)
+
+
+def test_library_exports_every_declared_symbol():
+    import stochastic_muzero_amd as smz
+    header = open(os.path.join(ROOT, "include", "smz.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*\*?(smz_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 25
+    assert declared == set(smz._lib.SIGNATURES), declared ^ set(smz._lib.SIGNATURES)
+    lib = smz._lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.smz_abi_version() == 1
+    assert lib.smz_traj_floats(4, 2) == 4 + 3 * 2 + 3
+
+
+def test_create_fails_loudly_without_a_gpu_or_with_bad_arguments():
+    import stochastic_muzero_amd as smz
+    lib = smz._lib.load()
+    h = C.c_void_p()
+    bad = smz._lib.Config(4, 2, 2, 3, 5, 0, 1.25, 0.95, 0.25, 0.25, 0, 0)      # pb_c_base = 0
+    assert lib.smz_create(C.byref(bad), C.byref(h)) == smz._lib.SMZ_ERR_INVALID
+    assert b"pb_c_base" in lib.smz_last_error()
+    if not torch.cuda.is_available():
+        ok = smz._lib.Config(4, 2, 2, 3, 5, 19652, 1.25, 0.95, 0.25, 0.25, 0, 0)
+        assert lib.smz_create(C.byref(ok), C.byref(h)) == smz._lib.SMZ_ERR_HIP
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            smz.SearchEngine(4, 2, 3)
+
+
+def test_search_object_keeps_the_reference_constructor_surface():
+    """Monte_carlo_tree_search(**json) -- same kwargs, attributes, AssertionErrors (mcts:76-85, 148-173)."""
+    mcts = _pkg("mcts")
+    m = mcts.Monte_carlo_tree_search(pb_c_base=19652, pb_c_init=1.25, discount=0.999, root_dirichlet_alpha=0.25,
+                                     root_exploration_fraction=0.1, num_simulations=11, maxium_action_sample=2,
+                                     number_of_player=1, custom_loop=None)
+    for k, v in dict(pb_c_base=19652, pb_c_init=1.25, discount=0.999, root_dirichlet_alpha=0.25,
+                     root_exploration_fraction=0.1, num_simulations=11, maxium_action_sample=2, number_of_player=1,
+                     custom_loop=None).items():
+        assert getattr(m, k) == v
+    m.cycle.global_reset()
+    d = mcts.Monte_carlo_tree_search()
+    assert (d.num_simulations, d.discount, d.maxium_action_sample) == (10, 0.95, 2)
+    for bad in (dict(pb_c_base=0), dict(pb_c_base=1.5), dict(pb_c_init=1), dict(discount=-1.0),
+                dict(root_dirichlet_alpha=2.0), dict(root_exploration_fraction=1.5), dict(num_simulations=-1),
+                dict(num_simulations=2.0), dict(maxium_action_sample=0), dict(number_of_player=0), dict(custom_loop=3)):
+        with pytest.raises(AssertionError):
+            mcts.Monte_carlo_tree_search(**bad)
+    b = mcts.BatchedMCTS(8, num_simulations=5)
+    assert b.num_simulations == 5 and b.engine is None
+
+
+def test_temperature_scheduler_matches_reference_table():
+    sp = _pkg("selfplay")
+    z = np.load(os.path.join(gu.GOLDEN, "temperature_schedule.npz"))
+    modes = [str(m) for m in z["modes"]]
+    for mi, epoch, actual, want in z["rows"]:
+        got = sp.temperature_scheduler(int(epoch), int(actual), modes[int(mi)])
+        got = np.nan if got is None else float(np.asarray(got).reshape(-1)[0])
+        assert (np.isnan(want) and np.isnan(got)) or got == want, (modes[int(mi)], epoch, actual, got, want)
+    assert sp.temperature_scheduler(10, 3, 0.35) == 0.35
+
+
+@pytest.mark.parametrize("name", gu.SELFPLAY_FIXTURES)
+def test_trajectory_chunk_to_game_records_and_priorities(name):
+    """chunk_to_games rebuilds the lists of game.py:72-77 and make_priority reproduces what the reference's
+    ReplayBuffer.save_game derived from the reference's own game (replay_buffer.py:109-137, game.py:316-337)."""
+    sp = _pkg("selfplay")
+    cfg, data = gu.load(name)
+    T = int(data["game_length"]); A = 2; obs_dim = 4
+    F = obs_dim + 3 * A + 3
+    chunk = np.zeros((T, 1, F))
+    chunk[:, 0, :4] = data["game_observations"]
+    chunk[:, 0, 4] = data["game_rewards"]
+    chunk[:, 0, 6:8] = data["game_policies"]
+    chunk[:, 0, 8:10] = data["game_action_onehot"]
+    chunk[:, 0, 10] = data["game_root_values"]
+    chunk[:, 0, 11:13] = data["game_child_visits"]
+    (g,) = sp.chunk_to_games(chunk, obs_dim, A, float(cfg["discount"]), priority_scale=0.5, limit_of_game_play=int(data["limit"]))
+    assert g.game_length == T and g.done == bool(data["game_done"]) and g.reanalyzed is False
+    assert all(o.shape == (1, 4) and o.dtype == torch.float32 for o in g.observations)
+    assert np.array_equal(np.array(g.policies), data["game_policies"])
+    assert np.array_equal(np.array(g.child_visits), data["game_child_visits"])
+    assert np.array_equal(np.array(g.root_values, np.float32), data["game_root_values"])
+    assert [int(np.argmax(a)) for a in g.action_history] == list(data["game_actions"])
+    pos, top = g.make_priority(50)
+    np.testing.assert_allclose(pos, data["buffer_prio_position"], rtol=1e-12)
+    np.testing.assert_allclose(top, data["buffer_prio_game"], rtol=1e-12)
+
+
+def test_checkpoint_surface_roundtrip(tmp_path):
+    """save_model / load_model keep the reference's file names, JSON keys and pickled class paths
+    (muzero_model.py:911-996)."""
+    model = _pkg("model")
+    m = model.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_lunar_L2.npz"))
+    m.save_model(directory=str(tmp_path), tag=77)
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted([f"77_muzero_{f}_function.pt" for f in ("representation", "prediction", "afterstate_prediction",
+                            "afterstate_dynamics", "dynamics", "encoder")] + ["77_muzero_init_variables.json"])
+    import json
+    iv = json.load(open(tmp_path / "77_muzero_init_variables.json"))
+    for k in ("model_structure", "observation_space_dimensions", "action_space_dimensions", "state_space_dimensions",
+              "k_hypothetical_steps", "learning_rate", "optimizer", "loss_type", "lr_scheduler", "num_of_epoch", "device",
+              "hidden_layer_dimensions", "number_of_hidden_layer", "random_tag", "action_map", "use_amp",
+              "priority_scale", "rescale_value_loss"):
+        assert k in iv, k
+    raw = open(tmp_path / "77_muzero_dynamics_function.pt", "rb").read()
+    assert b"neural_network_mlp_model" in raw and b"Dynamics_function" in raw
+    m2 = model.Muzero.from_checkpoint(str(tmp_path), tag=77)
+    a1 = model.mlp_arrays_from_modules(m.representation_function, m.prediction_function, m.afterstate_prediction_function,
+                                       m.afterstate_dynamics_function, m.dynamics_function)
+    a2 = model.mlp_arrays_from_modules(m2.representation_function, m2.prediction_function, m2.afterstate_prediction_function,
+                                       m2.afterstate_dynamics_function, m2.dynamics_function)
+    assert all(torch.equal(a1[k], a2[k]) for k in a1)
+    assert m2.action_dictionnary == [0, 1, 2, 3] and m2.state_dimension == 16 and m2.number_of_hidden_layer == 2
+
+
+@pytest.mark.parametrize("name,wname", [("ckpt421_sims50", "weights_ckpt421"), ("lunarL2_K3_sims24", "weights_lunar_L2"),
+                                        ("wideA11_K9_sims24", "weights_wide_A11")])
+def test_batch1_inference_api_reproduces_reference_outputs(name, wname):
+    """The five *_inference methods (muzero_model.py:802-909) on CPU against the reference's recorded outputs.
+    Same torch build, same float32 operations -> the hidden states and policies agree to 1e-6."""
+    model = _pkg("model")
+    m = model.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
+    cfg, cases = gu.cases(name)
+    c = cases[0]
+    h = m.representation_function_inference(torch.from_numpy(c["obs"][None]))
+    np.testing.assert_allclose(h.numpy().ravel(), c["root_hidden"], atol=1e-6)
+    p, v = m.prediction_function_inference(h)
+    assert p.shape == (1, c["root_policy"].size) and p.dtype == np.float32 and isinstance(v, np.float32)
+    np.testing.assert_allclose(p[0], c["root_policy"], atol=1e-6)
+    for s in range(len(c["tape_branch"])):
+        hin = torch.from_numpy(c["tape_hidden_in"][s][None])
+        if c["tape_branch"][s]:
+            r, h2 = m.dynamics_function_inference(hin, int(c["tape_action"][s]))
+            p, v = m.prediction_function_inference(h2)
+            np.testing.assert_allclose(r, c["tape_reward"][s], rtol=1e-4, atol=5e-4)
+        else:
+            h2 = m.afterstate_dynamics_function_inference(hin, int(c["tape_action"][s]))
+            p, v = m.afterstate_prediction_function_inference(h2)
+        np.testing.assert_allclose(h2.numpy().ravel(), c["tape_hidden_out"][s], atol=2e-6)
+        np.testing.assert_allclose(p[0], c["tape_policy"][s], atol=1e-6)
+        np.testing.assert_allclose(v, c["tape_value"][s], rtol=1e-4, atol=5e-4)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model_checkpoint"), reason="reference checkpoints not present")
+def test_loads_the_reference_checkpoint_files_without_the_reference_source():
+    """The real 421 checkpoint (whole-module pickles naming neural_network_mlp_model.*) loads through the
+    compatibility classes and carries exactly the weights of the committed array fixture."""
+    import sys
+    model = _pkg("model")
+    assert "/root/reference" not in sys.path
+    m = model.Muzero.from_checkpoint("/root/reference/model_checkpoint", tag=421)
+    assert type(m.dynamics_function).__module__ == "neural_network_mlp_model"
+    got = model.mlp_arrays_from_modules(m.representation_function, m.prediction_function, m.afterstate_prediction_function,
+                                        m.afterstate_dynamics_function, m.dynamics_function)
+    z = np.load(os.path.join(gu.GOLDEN, "weights_ckpt421.npz"))
+    for k, v in got.items():
+        assert np.array_equal(v.numpy(), z[k]), k
+    assert (m.observation_dimension, m.action_dimension, m.state_dimension) == (4, 2, 31)
