@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--temperature", type=float, default=1.0)
+    ap.add_argument("--heads", default="auto", choices=["auto", "hip", "torch"],
+                    help="hip: fused LDS-resident HIP heads kernel; torch: torch-ROCm GEMMs + HIP epilogues")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SMZ_STREAM_GROUPS", "1")),
                     help="independent env groups per GPU, each on its own HIP stream")
     args = ap.parse_args()
@@ -135,7 +137,7 @@ def main():
                                  use_graph=not args.no_graph, fused=True)
         m.seed(np.arange(glo, glo + Bg, dtype=np.uint64))
         env.reset()
-        groups.append(sp.StreamGroup(env, model.heads(dev, instance=gi), m, T))
+        groups.append(sp.StreamGroup(env, model.heads(dev, instance=gi, backend=args.heads), m, T))
     env, heads, mcts = groups[0].env, groups[0].heads, groups[0].mcts
 
     def barrier():
@@ -165,7 +167,7 @@ def main():
            "config": {"workload": args.workload, "envs_per_gpu": B, "num_simulations": wl["sims"],
                       "actions": wl["A"], "children_per_expansion": wl["K"], "hidden_floats": model.state_dimension,
                       "rng": "per-tree MT19937 (numpy-legacy, parity mode)", "hip_graph": not args.no_graph,
-                      "stream_groups": G,
+                      "stream_groups": G, "heads": type(groups[0].heads).__name__,
                       "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}}
 
     # ---- roofline of the dominant tree kernel (rank 0) --------------------------------------------------------

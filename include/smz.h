@@ -180,6 +180,49 @@ int smz_prediction_epilogue(const float *policy_logits_pred_dev, const float *va
                             const uint8_t *branch_dev, int A, int S, float *policy_out_dev, float *value_out_dev,
                             int B, smz_stream stream);
 
+/* ---- fused `mlp_model` heads (neural_network_mlp_model.py:5-250 + muzero_model.py:802-909) ---------------------- */
+/* One launch evaluates, for every tree, the pair of networks its leaf needs (mcts:333-342) -- dynamics + prediction
+ * or afterstate_dynamics + afterstate_prediction -- including scale_to_bound_action, the policy softmax and the
+ * support decodes; weights are staged once per workgroup in LDS.  Available when the packed weights fit in LDS
+ * (smz_mlp_layout reports the size); otherwise the caller evaluates the heads with its own GEMMs and the epilogue
+ * kernels above.
+ *
+ * Packed weight buffer: float32, every matrix stored input-major and 4-way interleaved along the input index so
+ * that lane o reads four consecutive input weights with one 16-byte LDS read:
+ *     element (k, o) of a K x O matrix  ->  base + ((k / 4) * OP + o) * 4 + (k % 4),   OP = 64 * ceil(maxO / 64),
+ * K zero-padded to a multiple of 4, O zero-padded to OP; a bias vector is OP floats.  Matrices (off[] index):
+ *   0 dyn_in  (S+A x H)   1 ady_in (S+A x H)   2 dyn_mid (H x H)  3 ady_mid (H x H)      [mid only used when L > 0]
+ *   4 dyn_out (H x 2S: reward logits | next state)     5 ady_out (H x S: next state)
+ *   6 pre_in  (S x H)     7 apr_in (S x H)     8 pre_mid (H x H)  9 apr_mid (H x H)
+ *  10 pre_out (H x A+S: policy logits | value logits)  11 apr_out (H x A+S)
+ *  12 rep_in  (obs x H)  13 rep_mid (H x H)   14 rep_out (H x S)
+ * followed by the 15 bias vectors in the same order (off[15 + i]). */
+typedef struct {
+    int32_t obs, A, S, H, L;
+    int32_t OP;            /* padded output width */
+    int32_t total_floats;  /* size of the packed buffer */
+    int32_t off[30];       /* float offsets: 15 matrices then 15 biases */
+} smz_mlp_desc;
+/* Fills OP, total_floats and off[] from obs/A/S/H/L.  Returns SMZ_ERR_INVALID when the recurrent working set does not
+ * fit the 160 KB LDS of a CU (use the GEMM path then). */
+int smz_mlp_layout(smz_mlp_desc *desc);
+/* representation + root prediction: obs_dev [B,obs] -> hidden_out_dev [B,S] (scaled), policy_out_dev [B,A] (softmax) */
+int smz_mlp_initial(const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, float *hidden_out_dev,
+                    float *policy_out_dev, int B, smz_stream stream);
+/* recurrent step for all trees: mlp_input_dev [B,S+A] and branch_dev [B] as written by smz_select ->
+ * hidden_out_dev [B,S], reward_out_dev [B] (0 on the afterstate branch), policy_out_dev [B,A], value_out_dev [B] */
+int smz_mlp_recurrent(const smz_mlp_desc *desc, const float *weights_dev, const float *mlp_input_dev,
+                      const uint8_t *branch_dev, float *hidden_out_dev, float *reward_out_dev, float *policy_out_dev,
+                      float *value_out_dev, int B, smz_stream stream);
+
+/* The whole Monte_carlo_tree_search.run (mcts:311-349) of every tree in ONE launch, for `mlp_model` heads that fit
+ * in LDS: representation + root prediction, root expansion and noise, then num_simulations x (select, the pair of
+ * networks the leaf needs, expansion, backup).  Network weights are staged once per workgroup; leaf hand-off and
+ * network outputs never leave LDS.  Results are read as after the step-wise calls (smz_root_stats / smz_act /
+ * smz_debug_dump_tree).  obs_dev [B,obs] f32.  SMZ_ERR_INVALID when the working set exceeds a CU's LDS. */
+int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
+                   smz_stream stream);
+
 /* ---- synthetic environment + trajectory record (self_play.py:63-98 loop body around the search) -------------- */
 /* CartPole-v1 shaped Euler step on device (float64 state, float32 observation), used for the synthetic
  * fixed-length episodes of the benchmark: state_dev [B,4] f64 in/out, action_dev [B] i32,

@@ -28,6 +28,12 @@ class Config(C.Structure):
                 ("root_exploration_fraction", C.c_double), ("rng_mode", C.c_int32), ("device", C.c_int32)]
 
 
+class MlpDesc(C.Structure):
+    """smz_mlp_desc (include/smz.h): dimensions + float offsets of the packed mlp_model weight buffer."""
+    _fields_ = [("obs", C.c_int32), ("A", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("L", C.c_int32),
+                ("OP", C.c_int32), ("total_floats", C.c_int32), ("off", C.c_int32 * 30)]
+
+
 class NodeView(C.Structure):
     _fields_ = [("visit_count", C.c_int32), ("value_sum", C.c_float), ("reward", C.c_float), ("prior", C.c_float),
                 ("child_base", C.c_int32), ("action", C.c_int32)]
@@ -57,6 +63,10 @@ SIGNATURES = {
     "smz_policy_softmax": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "smz_dynamics_epilogue": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P]),
     "smz_prediction_epilogue": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
+    "smz_mlp_layout": (C.c_int, [C.POINTER(MlpDesc)]),
+    "smz_mlp_initial": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, C.c_int, _P]),
+    "smz_mlp_recurrent": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "smz_search_mlp": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, _P]),
     "smz_cartpole_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_traj_floats": (C.c_int, [C.c_int, C.c_int]),
     "smz_traj_pack": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),

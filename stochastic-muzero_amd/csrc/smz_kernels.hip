@@ -20,6 +20,7 @@
 
 #include "../../include/smz.h"
 #include "smz_device.hpp"
+#include "smz_mlp_device.hpp"
 
 using namespace smz;
 
@@ -61,11 +62,10 @@ __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds)
 // sources of word p are p, p+1 and p+397 and at most 64 consecutive words change) -- and the tempered words go to
 // this wave's LDS tile [tree lane][word].  Global traffic is coalesced 256-byte segments.  Returns the lane's
 // packed (ready << 16 | idx) after staging.
-__device__ inline int wave_stage_rng(const Params &P, int tree, bool valid, uint32_t *lds_tile) {
+__device__ inline int wave_stage_rng_from(const Params &P, int tree, bool valid, uint32_t *lds_tile, int packed) {
     constexpr int U = 16;   // trees in flight: their loads are all issued before the first dependent store
     const int lane = threadIdx.x & (kWave - 1);
     const int tree0 = tree - lane;
-    const int packed = valid ? P.rng_pos[tree] : 0;
     for (int t0 = 0; t0 < P.tpw; t0 += U) {
         uint32_t w[U], b[U], c[U];
         int pos[U];
@@ -101,6 +101,10 @@ __device__ inline int wave_stage_rng(const Params &P, int tree, bool valid, uint
     }
     const int idx = packed & 0xffff, ready = packed >> 16;
     return ((ready > kRngStage ? ready : kRngStage) << 16) | idx;
+}
+
+__device__ inline int wave_stage_rng(const Params &P, int tree, bool valid, uint32_t *lds_tile) {
+    return wave_stage_rng_from(P, tree, valid, lds_tile, valid ? P.rng_pos[tree] : 0);
 }
 
 // Row moves.  `lpr` consecutive lanes move one row of `width` floats; the rows of the wave's 64 trees are handed
@@ -295,6 +299,96 @@ __global__ void __launch_bounds__(kWave) k_expand_backup(Params P, const float *
         P.rng_pos[tree] = rng.pack();
         P.hdr[tree] = h;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Whole search in ONE launch (mlp_model heads): Monte_carlo_tree_search.run (mcts:311-349) for every tree.
+// A workgroup = 8 wavefronts sharing one LDS copy of the network weights; a wavefront owns `tpw` trees: the first
+// tpw lanes run the per-tree search code (root, select, expand, backup), then all 64 lanes evaluate the networks for
+// the wave's leaves one row at a time (smz_mlp_device.hpp).  Leaf/parent hand-off, policies, values and rewards stay
+// in LDS; only the child blocks, hidden rows and MT words touch global memory.  No inter-wave communication at all.
+// ---------------------------------------------------------------------------------------------------------------
+extern __shared__ float4 smz_search_lds4[];
+
+template <int MAXA, int U>
+__global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, const float *weights, const float *obs,
+                                                    int train) {
+    float *lds = reinterpret_cast<float *>(smz_search_lds4);
+    smz_mlp::stage_all_weights(lds, weights, d);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, waves = blockDim.x / kWave;
+    const int A = P.A, S = P.S, tpw = P.tpw;
+    // LDS carve: weights | pbc table (doubles) | per wave: mlp scratch, rng tile, head outputs (policy[A], value, reward)
+    double *pbc_lds = reinterpret_cast<double *>(lds + ((d.total_floats + 1) & ~1));
+    const int n_pbc = P.sims + 2;
+    for (int i = threadIdx.x; i < n_pbc; i += blockDim.x) pbc_lds[i] = P.pbc_sqrt[i];
+    float *wbase = reinterpret_cast<float *>(pbc_lds + n_pbc);
+    const int slot = A + 2;
+    const int per_wave = smz_mlp::scratch_floats(d) + tpw * kRngStride + tpw * slot;
+    float *scratch = wbase + wave * per_wave;
+    uint32_t *rng_tile = reinterpret_cast<uint32_t *>(scratch + smz_mlp::scratch_floats(d));
+    float *outs = reinterpret_cast<float *>(rng_tile + tpw * kRngStride);      // [tpw][A + 2]: policy | value | reward
+    __syncthreads();
+
+    const int tree0 = (blockIdx.x * waves + wave) * tpw;
+    const int tree = tree0 + lane;
+    const bool valid = lane < tpw && tree < P.B;
+
+    // ---- root: representation + prediction per row, then root expansion per lane ---------------------------------
+    for (int t = 0; t < tpw; t++) {
+        const int row = tree0 + t;
+        if (row >= P.B) break;                                   // wave-uniform
+        smz_mlp::initial_row<U>(lds, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * S, nullptr,
+                                outs + t * slot);
+    }
+    int packed = wave_stage_rng(P, tree, valid, rng_tile);
+    Rng rng;
+    TreeHdr h = {0, 0, 0.f, 0.f, 0, 0.f, 0, 0};
+    if (valid) {
+        rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
+        root_init_tree<MAXA>(P, tree, rng, outs + lane * slot, nullptr, train != 0);
+        h = P.hdr[tree];
+        packed = rng.pack();
+    }
+    unsigned n_dec = 0, n_chance = 0, n_children = 0, n_desc = 0;
+    // ---- simulations -------------------------------------------------------------------------------------------------
+    for (int s = 0; s < P.sims; s++) {
+        packed = wave_stage_rng_from(P, tree, valid, rng_tile, packed);
+        Leaf L = {0, 0, 0, 0};
+        if (valid) {
+            rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
+            if (s > 0) expand_backup_tree<MAXA>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
+                                                outs[lane * slot + A]);
+            int len = 0;
+            L = select_tree<MAXA>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children);
+            h.path_len = len;
+            n_desc++;
+            packed = rng.pack();
+        }
+        // hidden rows written in earlier rounds (by any lane of this wave) may be this round's parent rows
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int t = 0; t < tpw; t++) {
+            const int row = tree0 + t;
+            if (row >= P.B) break;                               // wave-uniform
+            const int leaf = __shfl(L.leaf_id, t), parent = __shfl(L.parent_id, t), act = __shfl(L.action, t);
+            const bool dyn = __shfl(L.branch, t) != 0;
+            float reward, value;
+            smz_mlp::recurrent_row<U>(lds, d, scratch, P.hidden + ((size_t)row * P.N + parent) * S, nullptr, act, dyn,
+                                      P.hidden + ((size_t)row * P.N + leaf) * S, nullptr, outs + t * slot, reward, value);
+            if (lane == 0) { outs[t * slot + A] = value; outs[t * slot + A + 1] = reward; }
+        }
+        smz_mlp::lds_sync();
+    }
+    if (P.sims > 0) packed = wave_stage_rng_from(P, tree, valid, rng_tile, packed);   // words for the last expansion
+    if (valid) {
+        if (P.sims > 0) {
+            rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
+            expand_backup_tree<MAXA>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A]);
+            packed = rng.pack();
+        }
+        P.rng_pos[tree] = packed;
+        P.hdr[tree] = h;
+    }
+    wave_add_stats(P.stats, n_dec, n_chance, n_desc, n_children);
 }
 
 __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits, double *priors, float *root_value,
@@ -821,6 +915,43 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
     SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, true>), wave_grid(h->P), dim3(kWave), pbc_lds_bytes(h->P),
                                              (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev,
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
+    return launch_check();
+}
+
+int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
+                   smz_stream stream) {
+    if (!h || !desc || !weights_dev || !obs_dev) return fail(SMZ_ERR_INVALID, "smz_search_mlp: null argument%s");
+    smz_mlp_desc t = *desc;
+    if (smz_mlp_layout(&t) != SMZ_OK || t.total_floats != desc->total_floats)
+        return fail(SMZ_ERR_INVALID, "smz_search_mlp: descriptor does not describe an LDS-resident network%s");
+    if (desc->A != h->P.A || desc->S != h->P.S)
+        return fail(SMZ_ERR_INVALID, "smz_search_mlp: network dimensions differ from the handle's%s");
+    if (train && h->cfg.num_simulations > 0 && !(h->cfg.root_dirichlet_alpha > 0))
+        return fail(SMZ_ERR_INVALID, "root_dirichlet_alpha must be > 0 to draw noise (numpy raises ValueError)%s");
+    DeviceGuard guard(h->cfg.device);
+    constexpr int kWaves = 8;
+    Params P = h->P;
+    // trees per wave: the smallest power of two that covers B with 256 workgroups of 8 waves
+    int tpw = 1;
+    while (tpw < kWave && (size_t)256 * kWaves * tpw < (size_t)P.B) tpw <<= 1;
+    P.tpw = tpw;
+    const int per_wave = smz_mlp::scratch_floats(*desc) + tpw * kRngStride + tpw * (P.A + 2);
+    const size_t lds = ((size_t)((desc->total_floats + 1) & ~1) + (size_t)kWaves * per_wave) * sizeof(float) +
+                       (size_t)(P.sims + 2) * sizeof(double);
+    if (lds > 160 * 1024) return fail(SMZ_ERR_INVALID, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
+    const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
+#define SMZ_LAUNCH_SEARCH(UU)                                                                                          \
+    SMZ_DISPATCH(h->maxa, {                                                                                            \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, UU>),                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                   \
+            return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                                \
+        hipLaunchKernelGGL((k_search_mlp<MA, UU>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream, P,   \
+                           *desc, weights_dev, obs_dev, train);                                                        \
+    })
+    if (desc->OP == kWave) { SMZ_LAUNCH_SEARCH(1); } else { SMZ_LAUNCH_SEARCH(2); }
+#undef SMZ_LAUNCH_SEARCH
+    h->root_ready = true;
+    h->selected = false;
     return launch_check();
 }
 

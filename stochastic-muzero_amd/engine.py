@@ -144,6 +144,12 @@ class SearchEngine:
             _ptr(self.branch), _ptr(self.mlp_input) if (want_mlp_input and self.S > 0) else None, self._stream()))
         return self.parent_hidden, self.last_action, self.branch, self.mlp_input
 
+    def search_mlp(self, mlp_desc, weights, obs, train=True):
+        """Whole search (root + num_simulations rounds) in one launch with LDS-resident mlp_model heads."""
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[0] == self.B
+        _lib.check(self.lib.smz_search_mlp(self.h, C.byref(mlp_desc), _ptr(weights), _ptr(obs), int(bool(train)),
+                                           self._stream()))
+
     def root_stats(self):
         _lib.check(self.lib.smz_root_stats(self.h, _ptr(self.visits), _ptr(self.priors), _ptr(self.root_value),
                                            _ptr(self.child_reward), self._stream()))

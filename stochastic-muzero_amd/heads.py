@@ -145,6 +145,68 @@ class FusedMlpHeads:
         return hidden, reward, policy, value
 
 
+class HipMlpHeads:
+    """`mlp_model` heads evaluated by ONE hand-written HIP kernel per phase (smz_mlp_initial / smz_mlp_recurrent):
+    weights packed once into the LDS layout described in include/smz.h, no library GEMMs, no torch ops.
+    Raises ValueError when the networks do not fit a CU's LDS (use FusedMlpHeads then)."""
+    wants_mlp_input, wants_parent_hidden = True, False
+    # off[] order of smz_mlp_desc: (name of the input-major matrix, [names of the output heads concatenated])
+    _MATS = [("dyn_in", ["dyn_in"]), ("ady_in", ["ady_in"]), ("dyn_mid", ["dyn_mid"]), ("ady_mid", ["ady_mid"]),
+             ("dyn_out", ["dyn_rw", "dyn_st"]), ("ady_out", ["ady_st"]), ("pre_in", ["pre_in"]), ("apr_in", ["apr_in"]),
+             ("pre_mid", ["pre_mid"]), ("apr_mid", ["apr_mid"]), ("pre_out", ["pre_pol", "pre_val"]),
+             ("apr_out", ["apr_pol", "apr_val"]), ("rep_in", ["rep_in"]), ("rep_mid", ["rep_mid"]), ("rep_out", ["rep_out"])]
+
+    def __init__(self, weights, dims, device):
+        import numpy as np
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.obs, self.A, self.S, self.H, self.L = (int(dims[k]) for k in ("obs", "A", "S", "H", "L"))
+        d = _lib.MlpDesc(self.obs, self.A, self.S, self.H, self.L)
+        if self.lib.smz_mlp_layout(C.byref(d)) != 0:
+            raise ValueError("mlp heads do not fit the LDS-resident kernel (use FusedMlpHeads)")
+        self.desc = d
+        buf = np.zeros(d.total_floats, np.float32)
+        OP = d.OP
+        for m, (_, parts) in enumerate(self._MATS):
+            if "_mid" in parts[0] and self.L == 0:
+                continue
+            W = np.concatenate([np.asarray(weights[p + "_w"], np.float32) for p in parts], 0)      # [O, K] (torch layout)
+            b = np.concatenate([np.asarray(weights[p + "_b"], np.float32) for p in parts], 0)
+            O, K = W.shape
+            K4 = (K + 3) & ~3
+            blk = np.zeros((K4 // 4, OP, 4), np.float32)
+            Wt = np.zeros((K4, OP), np.float32)
+            Wt[:K, :O] = W.T
+            blk[:] = Wt.reshape(K4 // 4, 4, OP).transpose(0, 2, 1)
+            buf[d.off[m]:d.off[m] + K4 * OP] = blk.reshape(-1)
+            buf[d.off[15 + m]:d.off[15 + m] + O] = b
+        self.weights = torch.from_numpy(buf).to(self.device)
+        self._buf = {}
+
+    def _out(self, name, shape, dtype=torch.float32):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._buf[name] = torch.empty(*shape, dtype=dtype, device=self.device)
+        return t
+
+    def initial(self, obs):
+        B = obs.shape[0]
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.obs
+        hidden, policy = self._out("h0", (B, self.S)), self._out("p0", (B, self.A))
+        _lib.check(self.lib.smz_mlp_initial(C.byref(self.desc), _ptr(self.weights), _ptr(obs), _ptr(hidden), _ptr(policy),
+                                            B, _stream(self.device)))
+        return hidden, policy
+
+    def recurrent(self, engine):
+        x, branch = engine.mlp_input, engine.branch
+        B = x.shape[0]
+        hidden, reward = self._out("h", (B, self.S)), self._out("r", (B,))
+        policy, value = self._out("p", (B, self.A)), self._out("v", (B,))
+        _lib.check(self.lib.smz_mlp_recurrent(C.byref(self.desc), _ptr(self.weights), _ptr(x), _ptr(branch), _ptr(hidden),
+                                              _ptr(reward), _ptr(policy), _ptr(value), B, _stream(self.device)))
+        return hidden, reward, policy, value
+
+
 class ModuleHeads:
     """Heads given as five torch modules with the reference's signatures:
          representation(obs) -> hidden                                   (already scaled)

@@ -78,15 +78,16 @@ class _Hyper:
 class BatchedMCTS(_Hyper):
     def __init__(self, num_trees, pb_c_base=19652, pb_c_init=1.25, discount=0.95, root_dirichlet_alpha=0.25,
                  root_exploration_fraction=0.25, num_simulations=10, maxium_action_sample=2, number_of_player=1,
-                 custom_loop=None, device=None, use_graph=True, fused=True):
+                 custom_loop=None, device=None, use_graph=True, fused=True, single_launch=True):
         self._set_hyper(pb_c_base, pb_c_init, discount, root_dirichlet_alpha, root_exploration_fraction,
                         num_simulations, maxium_action_sample, number_of_player, custom_loop)
         self.num_trees = int(num_trees)
         self.device = device
-        self.use_graph, self.fused = bool(use_graph), bool(fused)
+        self.use_graph, self.fused, self.single_launch = bool(use_graph), bool(fused), bool(single_launch)
         self.engine = None
         self._graph = None
         self._graph_key = None
+        self._single = None
 
     def _ensure_engine(self, num_actions, hidden_size):
         if self.engine is None or (self.engine.A, self.engine.S) != (num_actions, hidden_size):
@@ -150,7 +151,22 @@ class BatchedMCTS(_Hyper):
 
     def run(self, observations, heads, train=True):
         """observations: [B, ...] float32 tensor on the engine's device.  Returns the engine; the search has been
-        enqueued on the current stream (read results with engine.root_stats() / engine.act())."""
+        enqueued on the current stream (read results with engine.root_stats() / engine.act()).
+        With HipMlpHeads the whole search is ONE kernel launch (smz_search_mlp) when it fits in LDS; otherwise the
+        step-wise kernels run, captured in a HIP graph unless use_graph is off."""
+        if self.single_launch and getattr(heads, "desc", None) is not None and self._single is not False:
+            eng = self._ensure_engine(heads.A, heads.S)
+            if getattr(self, "_pending_seed", None) is not None:
+                eng.seed(self._pending_seed)
+                self._pending_seed = None
+            try:
+                eng.search_mlp(heads.desc, heads.weights, observations, train=train)
+                self._single = True
+                return eng
+            except Exception:
+                if self._single is True:
+                    raise
+                self._single = False     # does not fit in LDS for this batch geometry: use the step-wise path
         if not self.use_graph:
             self._search(observations, heads, train)
             return self.engine

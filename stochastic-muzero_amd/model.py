@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import compat_mlp
-from .heads import MLP_ARRAYS, FusedMlpHeads, ModuleHeads
+from .heads import MLP_ARRAYS, FusedMlpHeads, HipMlpHeads, ModuleHeads
 
 _FUNCS = ("representation", "prediction", "afterstate_prediction", "afterstate_dynamics", "dynamics", "encoder")
 _FAMILY_MODULE = {"mlp_model": "neural_network_mlp_model", "lstm_model": "neural_network_lstm_model",
@@ -189,11 +189,24 @@ class Muzero:
         return m
 
     # ---- batched heads for the GPU engine -----------------------------------------------------------------------
-    def heads(self, device, instance=0):
-        """Batched evaluator on `device`.  `instance` distinguishes evaluators that must not share output buffers
-        (one per concurrently running stream group)."""
-        key = (str(device), instance)
+    def heads(self, device, instance=0, backend="auto"):
+        """Batched evaluator on `device`.  backend: "hip" = the fused LDS-resident HIP kernel (mlp_model only, when
+        the networks fit a CU's LDS), "torch" = torch-ROCm GEMMs + HIP epilogues, "auto" = hip when possible.
+        `instance` distinguishes evaluators that must not share output buffers (one per concurrent stream group)."""
+        key = (str(device), instance, backend)
         if key not in self._heads:
+            if self.model_structure == "mlp_model" and backend in ("auto", "hip"):
+                arrays = mlp_arrays_from_modules(self.representation_function, self.prediction_function,
+                                                 self.afterstate_prediction_function, self.afterstate_dynamics_function,
+                                                 self.dynamics_function)
+                dims = dict(obs=self.observation_dimension, A=self.action_dimension, S=self.state_dimension,
+                            H=self.hidden_layer_dimension, L=self.number_of_hidden_layer)
+                try:
+                    self._heads[key] = HipMlpHeads(arrays, dims, device)
+                    return self._heads[key]
+                except ValueError:
+                    if backend == "hip":
+                        raise
             if self.model_structure == "mlp_model":
                 arrays = mlp_arrays_from_modules(self.representation_function, self.prediction_function,
                                                  self.afterstate_prediction_function, self.afterstate_dynamics_function,

@@ -22,14 +22,17 @@ class _FakeEngine:
     pass
 
 
+@pytest.mark.parametrize("backend", ["hip", "torch"])
 @pytest.mark.parametrize("name,wname", [("ckpt421_sims50", "weights_ckpt421"), ("lunar_K2_sims50", "weights_lunar_L0"),
                                         ("lunarL2_K3_sims24", "weights_lunar_L2"), ("wideA11_K9_sims24", "weights_wide_A11")])
-def test_batched_heads_match_reference_head_outputs(name, wname):
-    """FusedMlpHeads (torch GEMMs + HIP epilogues) vs the torch-CPU outputs the reference produced (the tape)."""
+def test_batched_heads_match_reference_head_outputs(name, wname, backend):
+    """HipMlpHeads (one fused LDS-resident HIP kernel) and FusedMlpHeads (torch GEMMs + HIP epilogues) vs the
+    torch-CPU outputs the reference produced (the tape)."""
     _, model_mod, _, _ = _mods()
     cfg, data = gu.load(name)
     model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
-    heads = model.heads("cuda:0")
+    heads = model.heads("cuda:0", backend=backend)
+    assert type(heads).__name__ == {"hip": "HipMlpHeads", "torch": "FusedMlpHeads"}[backend]
     ncase, sims = data["tape_branch"].shape
     A = data["root_policy"].shape[-1]
     hid, pol = heads.initial(torch.from_numpy(data["obs"]).cuda())
@@ -55,7 +58,7 @@ def test_module_heads_agree_with_fused_heads():
     mcts_mod, model_mod, _, _ = _mods()
     heads_mod = import_module("stochastic-muzero_amd.heads")
     model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_lunar_L2.npz"))
-    fused = model.heads("cuda:0")
+    fused = model.heads("cuda:0", backend="torch")
     generic = heads_mod.ModuleHeads(model.representation_function, model.prediction_function,
                                     model.afterstate_prediction_function, model.afterstate_dynamics_function,
                                     model.dynamics_function, num_actions=model.action_dimension,
@@ -75,13 +78,14 @@ def test_module_heads_agree_with_fused_heads():
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-4)
 
 
+@pytest.mark.parametrize("backend", ["hip", "torch"])
 @pytest.mark.parametrize("fused", [True, False])
-def test_graph_replay_equals_eager_and_oracle(fused):
+def test_graph_replay_equals_eager_and_oracle(fused, backend):
     mcts_mod, model_mod, _, _ = _mods()
     import orc
     wpath = os.path.join(gu.GOLDEN, "weights_ckpt421.npz")
     model = model_mod.Muzero.from_arrays(wpath)
-    heads = model.heads("cuda:0")
+    heads = model.heads("cuda:0", backend=backend)
     B, sims = 512, 50
     obs = np.random.RandomState(3).uniform(-0.05, 0.05, (B, 4)).astype(np.float32)
     outs = []
@@ -195,3 +199,39 @@ def test_single_tree_drop_in_matches_reference_game():
         assert a == data["game_actions"][i]
     m.cycle.global_reset()
     assert np.random.random_sample() == data["probe"]
+
+
+@pytest.mark.parametrize("wname,B,sims,K", [("weights_ckpt421", 4096, 50, 2), ("weights_ckpt421", 100, 11, 2),
+                                            ("weights_lunar_L0", 700, 30, 4), ("weights_lunar_L2", 256, 24, 3),
+                                            ("weights_wide_A11", 130, 20, 9)])
+def test_single_launch_search_equals_stepwise_search(wname, B, sims, K):
+    """smz_search_mlp (whole search in one kernel) against the step-wise kernels driven with the same fused HIP
+    heads: same device functions, same draws -> every tree, value and stream position identical."""
+    mcts_mod, model_mod, _, _ = _mods()
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
+    heads = model.heads("cuda:0", backend="hip")
+    obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(1)).mul(0.3).cuda()
+    res = []
+    for single in (True, False):
+        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=K, discount=0.997,
+                                 root_exploration_fraction=0.25, use_graph=False, single_launch=single)
+        m.seed(np.arange(B, dtype=np.uint64) + 5)
+        for rep in range(2):
+            e = m.run(obs, heads, train=True)
+        assert m._single is (True if single else None)
+        visits, priors, rv, cr = e.root_stats()
+        action, policy, cv, _ = e.act(1.0)
+        torch.cuda.synchronize()
+        out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr, action, policy, cv)]
+        dumps = [e.dump_tree(i) for i in (0, B // 2, B - 1)]
+        states = [e.get_rng_state(i) for i in (0, B - 1)]
+        res.append((out, dumps, states))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for da, db in zip(res[0][1], res[1][1]):
+        for k in da:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+    for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
+        ra = np.random.RandomState(0); ra.set_state(("MT19937", ka, pa, 0, 0.0))
+        rb = np.random.RandomState(0); rb.set_state(("MT19937", kb, pb, 0, 0.0))
+        assert np.array_equal(ra.random_sample(700), rb.random_sample(700))
