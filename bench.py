@@ -53,29 +53,29 @@ def algorithmic_bytes(stats, A, K, S, launches):
     return k2, k5, depth
 
 
-def cpu_baseline(wl, weights_path, seconds_target=12.0):
+def cpu_baseline(wl, weights_path, seconds_target=15.0):
+    """The CPU oracle on all host cores, on a bounded sample of the same workload (about 10-30 s of CPU work)."""
     import orc
     w = orc.MlpWeights.from_npz(weights_path)
     cores = os.cpu_count() or 1
     cfg = orc.make_cfg(wl["A"], wl["K"], w.dims["S"], wl["sims"], discount=0.999, alpha=0.25, frac=0.1)
-    steps = 4
-    n_env = cores
     rs = np.random.RandomState(0)
 
-    def run(n_env):
+    def run(n_env, steps):
         obs0 = rs.uniform(-0.05, 0.05, (n_env, 4))
         t0 = time.perf_counter()
         out = orc.selfplay_cartpole(cfg, w, obs0, np.arange(n_env, dtype=np.uint32), steps, temperature=1.0,
                                     train=True, threads=cores, record=False)
         return out["simulations"], time.perf_counter() - t0
-    sims, dt = run(n_env)                                   # calibration
+    n_env = 4 * cores
+    sims, dt = run(n_env, 4)                                   # calibration pass
     rate = sims / dt
-    n_env = int(max(cores, min(4096, (rate * seconds_target) / (steps * wl["sims"]))))
-    n_env -= n_env % cores
-    sims, dt = run(max(cores, n_env))
+    steps = int(max(4, min(4096, rate * seconds_target / (n_env * wl["sims"]))))
+    sims, dt = run(n_env, steps)
     return dict(value=sims / dt, unit="simulations/s", cores=cores, kind="port",
-                sample=f"{max(cores, n_env)} envs x {steps} steps x {wl['sims']} sims, CartPole synthetic, C oracle with plain-C "
-                       f"MLP heads, {cores} threads (one game per thread), {dt:.1f} s")
+                sample=f"{n_env} envs x {steps} steps x {wl['sims']} sims of the same CartPole workload, C oracle "
+                       f"(oracle/smz_oracle.c) with plain-C MLP heads, {cores} threads (one game per thread), "
+                       f"{dt:.1f} s wall = {dt * cores:.0f} core-seconds")
 
 
 def main():
@@ -170,27 +170,45 @@ def main():
                       "stream_groups": G, "heads": type(groups[0].heads).__name__,
                       "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}}
 
-    # ---- roofline of the dominant tree kernel (rank 0) --------------------------------------------------------
+    # ---- roofline (rank 0) --------------------------------------------------------------------------------------
     if rank == 0 and not args.no_roofline:
         eng = mcts.engine
         S, A, K = eng.S, eng.A, eng.K
+        single = mcts._single is True
         # (1) level histogram of this workload (stats atomics on; not timed)
         eng.enable_stats(True)
         eng.read_stats(reset=True)
-        B = Bg
-        mcts_e = mcts_mod.BatchedMCTS(B, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
+        mcts.run(env.obs, heads, train=True) if single else None
+        mcts_e = mcts_mod.BatchedMCTS(Bg, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
                                       root_dirichlet_alpha=0.25, root_exploration_fraction=0.1, device=local_rank,
-                                      use_graph=False, fused=True)
+                                      use_graph=False, fused=True, single_launch=False)
         mcts_e.engine = eng
-        mcts_e._search(env.obs, heads, True)
+        if not single:
+            mcts_e._search(env.obs, heads, True)
+        torch.cuda.synchronize(dev)
         stats = eng.read_stats(reset=True)
         eng.enable_stats(False)
         k2, k5, depth = algorithmic_bytes(stats, A, K, S, wl["sims"])
-        # (2) mean duration of the fused expand+backup+select launch: events on the launching stream, eager replay of
-        #     the same search (each launch bracketed), over the same number of steps as the timed region
-        durs = []
+        reps = max(1, min(args.steps, 4))
+        if single:
+            # dominant kernel = k_search_mlp (the whole search, one launch per env step): event pairs around each launch
+            durs = []
+            for _ in range(reps + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); mcts.run(env.obs, heads, train=True); e1.record()
+                durs.append((e0, e1))
+            torch.cuda.synchronize(dev)
+            ms = np.array([a.elapsed_time(b) for a, b in durs[1:]])
+            mean_us = float(ms.mean() * 1e3)
+            bytes_launch = (k2 + k5) * Bg * wl["sims"]
+            kernel = "k_search_mlp<MAXA,U> (root + num_simulations x [select, heads, expand, backup] in one launch)"
+        else:
+            kernel = "k_expand_backup<MAXA,true> (expand + backup + next select)"
+            durs = []
+        # the tree kernel on its own (step-wise path): events around each fused expand+backup+select launch
         hidden, policy = heads.initial(env.obs)
-        for _ in range(max(1, min(args.steps, 4))):
+        tdurs = []
+        for _ in range(reps):
             eng.root_init(hidden, policy, train=True)
             eng.select(want_parent_hidden=False)
             for s in range(wl["sims"] - 1):
@@ -199,20 +217,26 @@ def main():
                 e0.record()
                 eng.expand_backup_select(*o, want_parent_hidden=False)
                 e1.record()
-                durs.append((e0, e1))
+                tdurs.append((e0, e1))
             eng.expand_backup(*heads.recurrent(eng))
         torch.cuda.synchronize(dev)
-        ms = np.array([a.elapsed_time(b) for a, b in durs])
-        mean_us = float(ms.mean() * 1e3)
-        bytes_launch = (k2 + k5) * B
+        tms = np.array([a.elapsed_time(b) for a, b in tdurs])
+        tree_us = float(tms.mean() * 1e3)
+        tree_bytes = (k2 + k5) * Bg
+        if not single:
+            ms, mean_us, bytes_launch = tms, tree_us, tree_bytes
         achieved = bytes_launch / (mean_us * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_expand_backup<MAXA,true> (expand + backup + next select)",
-                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None, "bytes_per_launch": bytes_launch, "mean_launch_us": mean_us,
-                           "median_launch_us": float(np.median(ms) * 1e3), "launches_timed": int(ms.size),
-                           "bytes_per_tree_select": k2, "bytes_per_tree_expand_backup": k5, "mean_depth": depth,
-                           "method": "event pairs on the launching (torch current) stream around each launch, eager "
-                                     "replay of the same search after the timed region"}
+        out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_launch,
+                           "mean_launch_us": mean_us, "median_launch_us": float(np.median(ms) * 1e3),
+                           "launches_timed": int(ms.size), "bytes_per_tree_select": k2,
+                           "bytes_per_tree_expand_backup": k5, "mean_depth": depth,
+                           "tree_kernel_alone": {"kernel": "k_expand_backup<MAXA,true>", "mean_launch_us": tree_us,
+                                                 "bytes_per_launch": tree_bytes,
+                                                 "achieved": tree_bytes / (tree_us * 1e-6) / 1e9,
+                                                 "frac": tree_bytes / (tree_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                           "method": "HIP event pairs on the launching (torch current) stream around each launch, "
+                                     "after the timed region; bytes = SURVEY 8d formula on this run's level histogram"}
     if rank == 0 and not args.no_cpu_baseline and wl["env"] == "cartpole":
         out["cpu_baseline"] = cpu_baseline(wl, wpath)
     if rank == 0:

@@ -929,7 +929,8 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     if (train && h->cfg.num_simulations > 0 && !(h->cfg.root_dirichlet_alpha > 0))
         return fail(SMZ_ERR_INVALID, "root_dirichlet_alpha must be > 0 to draw noise (numpy raises ValueError)%s");
     DeviceGuard guard(h->cfg.device);
-    constexpr int kWaves = 8;
+    int kWaves = 8;
+    if (const char *e = getenv("SMZ_SEARCH_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) kWaves = v; }
     Params P = h->P;
     // trees per wave: the smallest power of two that covers B with 256 workgroups of 8 waves
     int tpw = 1;
