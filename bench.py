@@ -67,10 +67,12 @@ def cpu_baseline(wl, weights_path, seconds_target=15.0):
         out = orc.selfplay_cartpole(cfg, w, obs0, np.arange(n_env, dtype=np.uint32), steps, temperature=1.0,
                                     train=True, threads=cores, record=False)
         return out["simulations"], time.perf_counter() - t0
-    n_env = 4 * cores
-    sims, dt = run(n_env, 4)                                   # calibration pass
+    steps = 64                                                 # the synthetic episode length of the workload
+    n_env = 2 * cores
+    sims, dt = run(n_env, steps)                               # calibration pass (also warms the thread pool)
     rate = sims / dt
-    steps = int(max(4, min(4096, rate * seconds_target / (n_env * wl["sims"]))))
+    n_env = int(max(cores, min(64 * cores, rate * seconds_target / (steps * wl["sims"]))))
+    n_env -= n_env % cores
     sims, dt = run(n_env, steps)
     return dict(value=sims / dt, unit="simulations/s", cores=cores, kind="port",
                 sample=f"{n_env} envs x {steps} steps x {wl['sims']} sims of the same CartPole workload, C oracle "
@@ -91,6 +93,7 @@ def main():
     ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--heads", default="auto", choices=["auto", "hip", "torch"],
                     help="hip: fused LDS-resident HIP heads kernel; torch: torch-ROCm GEMMs + HIP epilogues")
+    ap.add_argument("--stepwise", action="store_true", help="never use the single-launch search kernel")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SMZ_STREAM_GROUPS", "1")),
                     help="independent env groups per GPU, each on its own HIP stream")
     args = ap.parse_args()
@@ -134,7 +137,7 @@ def main():
             env = envs_mod.SyntheticVec(Bg, wl["obs"], wl["A"], dev, seed=0, first_env=glo, total_envs=total)
         m = mcts_mod.BatchedMCTS(Bg, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
                                  root_dirichlet_alpha=0.25, root_exploration_fraction=0.1, device=local_rank,
-                                 use_graph=not args.no_graph, fused=True)
+                                 use_graph=not args.no_graph, fused=True, single_launch=not args.stepwise)
         m.seed(np.arange(glo, glo + Bg, dtype=np.uint64))
         env.reset()
         groups.append(sp.StreamGroup(env, model.heads(dev, instance=gi, backend=args.heads), m, T))

@@ -37,6 +37,7 @@ struct TreeHdr {          // one 32-byte record per tree
 
 struct Params {
     int32_t B, A, K, S, N, P, sims;
+    int32_t dbg;        // timing-ablation switches (SMZ_DEBUG_SKIP, diagnostics only; results are then meaningless)
     int32_t tpw;        // trees per wavefront (power of two <= 64): lanes >= tpw only help in the cooperative phases
     int32_t rb_words;   // words in a root block (multiple of 16)
     int32_t eb_words;   // words in an expansion block (multiple of 16)
@@ -271,12 +272,14 @@ struct Leaf {
     int32_t leaf_id, parent_id, action, branch;
 };
 
+// `path` receives the (block << 8 | slot) entries; when `pathvals` is given (LDS, one uint4 per level) the chosen
+// child's visit count, value sum and reward are recorded too, so that the backup needs no loads at all.
 template <int MAXA>
 __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const TreeHdr &h, const double *pbc_sqrt,
-                                   int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children) {
+                                   int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children,
+                                   int32_t *path, uint4 *pathvals = nullptr) {
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
-    int32_t *path = P.path + (size_t)tree * P.P;
     const float mn = h.mn, mx = h.mx;
     const bool norm = mx > mn;
     const float span = mx - mn;
@@ -345,10 +348,12 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
             n_children += (unsigned)cnt;
         }
         int c = 0;
+        float pv = 0.f, pr = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXA; j++) if (j == pick) { c = chd[j]; cur_visit = vis[j]; action = act[j]; }
+        for (int j = 0; j < MAXA; j++) if (j == pick) { c = chd[j]; cur_visit = vis[j]; action = act[j]; pv = vsum[j]; pr = rew[j]; }
         const int loc = (blk << 8) | pick;
         path[depth] = loc;
+        if (pathvals) pathvals[depth] = make_uint4((uint32_t)loc, (uint32_t)cur_visit, __float_as_uint(pv), __float_as_uint(pr));
         parent_id = leaf_id;
         leaf_id = loc_node_id(P, loc);
         depth++;
@@ -370,11 +375,10 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
 // ---------------------------------------------------------------------------------------------------------------
 template <int MAXA>
 __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, TreeHdr &h, const float *policy_row,
-                                         float reward, float value) {
+                                         float reward, float value, const int32_t *path, const uint4 *pathvals = nullptr) {
     constexpr int CH = 8;   // path nodes gathered per round trip
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
-    const int32_t *path = P.path + (size_t)tree * P.P;
     const int len = h.path_len;
     // ---- gather the path (independent loads) -------------------------------------------------------------------
     const int leaf_loc = path[len - 1];
@@ -419,6 +423,25 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, Tr
     // ---- backup, leaf -> root, CH nodes per round trip ------------------------------------------------------------
     float v = value;
     float mn = h.mn, mx = h.mx;
+    if (pathvals) {
+        // the select that recorded this path also recorded each node's (visit, value_sum, reward): stores only
+        for (int i = len - 1; i >= 0; i--) {
+            const uint4 e = pathvals[i];
+            const int b = (int)e.x >> 8, sl = (int)e.x & 0xff;
+            const int cnt = (b == 0) ? A : K;
+            uint32_t *np = block_ptr(P, tb, b) + sl;
+            const float r = (i == len - 1) ? leaf_reward : __uint_as_float(e.w);
+            const float nvs = __uint_as_float(e.z) + v;
+            const int nvc = (int)e.y + 1;
+            np[0] = (uint32_t)nvc;
+            np[cnt] = __float_as_uint(nvs);
+            const float qv = nvs / (float)nvc;
+            if (qv > mx) mx = qv;
+            if (qv < mn) mn = qv;
+            const float dv = P.disc32 * v;
+            v = r + dv;
+        }
+    } else
     for (int i0 = len - 1; i0 >= 0; i0 -= CH) {
         int locs[CH];
         uint32_t *np_[CH];

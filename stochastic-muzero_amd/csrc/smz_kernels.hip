@@ -236,7 +236,7 @@ __device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &
     unsigned n_dec = 0, n_chance = 0, n_children = 0;
     if (valid) {
         int len = 0;
-        L = select_tree<MAXA>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children);
+        L = select_tree<MAXA>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, P.path + (size_t)tree * P.P);
         h.path_len = len;
         if (last_action) last_action[tree] = L.action;
         if (branch) branch[tree] = (uint8_t)L.branch;
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(kWave) k_expand_backup(Params P, const float *
         rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + threadIdx.x * kRngStride, kRngStage);
         h = P.hdr[tree];
         leaf = expand_backup_tree<MAXA>(P, tree, rng, h, policy + (size_t)tree * P.A, reward ? reward[tree] : 0.0f,
-                                        value[tree]);
+                                        value[tree], P.path + (size_t)tree * P.P);
     }
     if (P.S > 0 && hidden) {
         const int t = valid ? tree : 0;
@@ -310,6 +310,26 @@ __global__ void __launch_bounds__(kWave) k_expand_backup(Params P, const float *
 // ---------------------------------------------------------------------------------------------------------------
 extern __shared__ float4 smz_search_lds4[];
 
+// LDS map of k_search_mlp (floats): weights | pbc table (doubles) | per wave, every part padded to 16 bytes:
+//   mlp scratch | network inputs [tpw][K4in] | path records [tpw][P] uint4 | path [tpw][P] | rng tile | head outputs
+struct MegaLds {
+    int pbc_off, wave_off, per_wave;                       // float offsets from the LDS base
+    int x_off, pv_off, path_off, rng_off, out_off;         // float offsets inside a wave's region
+};
+__host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params &P, int tpw) {
+    MegaLds m;
+    m.pbc_off = r4(d.total_floats);
+    m.wave_off = m.pbc_off + r4(2 * (P.sims + 2));
+    m.x_off = r4(smz_mlp::scratch_floats(d));
+    m.pv_off = m.x_off + tpw * smz_mlp::up4(P.S + P.A);
+    m.path_off = m.pv_off + tpw * P.P * 4;
+    m.rng_off = m.path_off + r4(tpw * P.P);
+    m.out_off = m.rng_off + r4(tpw * kRngStride);
+    m.per_wave = m.out_off + r4(tpw * (P.A + 2));
+    return m;
+}
+
 template <int MAXA, int U>
 __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train) {
@@ -317,16 +337,18 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
     smz_mlp::stage_all_weights(lds, weights, d);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, waves = blockDim.x / kWave;
     const int A = P.A, S = P.S, tpw = P.tpw;
-    // LDS carve: weights | pbc table (doubles) | per wave: mlp scratch, rng tile, head outputs (policy[A], value, reward)
-    double *pbc_lds = reinterpret_cast<double *>(lds + ((d.total_floats + 1) & ~1));
+    const MegaLds ml = mega_lds(d, P, tpw);
+    double *pbc_lds = reinterpret_cast<double *>(lds + ml.pbc_off);
     const int n_pbc = P.sims + 2;
     for (int i = threadIdx.x; i < n_pbc; i += blockDim.x) pbc_lds[i] = P.pbc_sqrt[i];
-    float *wbase = reinterpret_cast<float *>(pbc_lds + n_pbc);
     const int slot = A + 2;
-    const int per_wave = smz_mlp::scratch_floats(d) + tpw * kRngStride + tpw * slot;
-    float *scratch = wbase + wave * per_wave;
-    uint32_t *rng_tile = reinterpret_cast<uint32_t *>(scratch + smz_mlp::scratch_floats(d));
-    float *outs = reinterpret_cast<float *>(rng_tile + tpw * kRngStride);      // [tpw][A + 2]: policy | value | reward
+    const int K4in = smz_mlp::up4(S + A);
+    float *scratch = lds + ml.wave_off + wave * ml.per_wave;
+    float *xall = scratch + ml.x_off;                                           // [tpw][K4in] network inputs of the round
+    uint4 *pvals = reinterpret_cast<uint4 *>(scratch + ml.pv_off);              // [tpw][P] path records
+    int32_t *lpath = reinterpret_cast<int32_t *>(scratch + ml.path_off);        // [tpw][P]
+    uint32_t *rng_tile = reinterpret_cast<uint32_t *>(scratch + ml.rng_off);
+    float *outs = scratch + ml.out_off;                                         // [tpw][A + 2]: policy | value | reward
     __syncthreads();
 
     const int tree0 = (blockIdx.x * waves + wave) * tpw;
@@ -350,39 +372,69 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
         packed = rng.pack();
     }
     unsigned n_dec = 0, n_chance = 0, n_children = 0, n_desc = 0;
+    const bool prof = (P.dbg & 16) && P.stats;
+    unsigned long long t_stage = 0, t_expand = 0, t_select = 0, t_mlp = 0, t0 = 0, t1 = 0;
+#define SMZ_STAMP(acc) if (prof) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
     // ---- simulations -------------------------------------------------------------------------------------------------
     for (int s = 0; s < P.sims; s++) {
-        packed = wave_stage_rng_from(P, tree, valid, rng_tile, packed);
+        if (prof) t0 = __builtin_amdgcn_s_memtime();
+        if (!(P.dbg & 8)) packed = wave_stage_rng_from(P, tree, valid, rng_tile, packed);
+        SMZ_STAMP(t_stage)
         Leaf L = {0, 0, 0, 0};
         if (valid) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            if (s > 0) expand_backup_tree<MAXA>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
-                                                outs[lane * slot + A]);
+            if (s > 0 && !(P.dbg & 4)) expand_backup_tree<MAXA>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
+                                                outs[lane * slot + A], lpath + lane * P.P, pvals + lane * P.P);
+        }
+        SMZ_STAMP(t_expand)
+        if (valid) {
             int len = 0;
-            L = select_tree<MAXA>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children);
+            if (P.dbg & 2) { L.leaf_id = 1; L.parent_id = 0; L.action = 0; L.branch = 0; len = 1; }
+            else L = select_tree<MAXA>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, lpath + lane * P.P,
+                                       pvals + lane * P.P);
             h.path_len = len;
             n_desc++;
             packed = rng.pack();
         }
+        SMZ_STAMP(t_select)
         // hidden rows written in earlier rounds (by any lane of this wave) may be this round's parent rows
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // all rows' network inputs first (independent global loads, one latency), then the rows one after another
         for (int t = 0; t < tpw; t++) {
             const int row = tree0 + t;
             if (row >= P.B) break;                               // wave-uniform
-            const int leaf = __shfl(L.leaf_id, t), parent = __shfl(L.parent_id, t), act = __shfl(L.action, t);
-            const bool dyn = __shfl(L.branch, t) != 0;
-            float reward, value;
-            smz_mlp::recurrent_row<U>(lds, d, scratch, P.hidden + ((size_t)row * P.N + parent) * S, nullptr, act, dyn,
+            const int parent = __builtin_amdgcn_readlane(L.parent_id, t), act = __builtin_amdgcn_readlane(L.action, t);
+            const float *src = P.hidden + ((size_t)row * P.N + parent) * S;
+            for (int k = lane; k < K4in; k += kWave)
+                xall[t * K4in + k] = (k < S) ? src[k] : ((k < S + A && (k - S) == act) ? 1.f : 0.f);
+        }
+        smz_mlp::lds_sync();
+        for (int t = 0; t < tpw; t++) {
+            const int row = tree0 + t;
+            if (row >= P.B) break;                               // wave-uniform
+            const int leaf = __builtin_amdgcn_readlane(L.leaf_id, t);
+            const bool dyn = __builtin_amdgcn_readlane(L.branch, t) != 0;
+            float reward = 0.f, value = 0.f;
+            if (!(P.dbg & 1)) smz_mlp::recurrent_row<U>(lds, d, scratch, nullptr, xall + t * K4in, 0, dyn,
                                       P.hidden + ((size_t)row * P.N + leaf) * S, nullptr, outs + t * slot, reward, value);
             if (lane == 0) { outs[t * slot + A] = value; outs[t * slot + A + 1] = reward; }
         }
         smz_mlp::lds_sync();
+        SMZ_STAMP(t_mlp)
+    }
+#undef SMZ_STAMP
+    if (prof && lane == 0) {
+        atomicAdd(&P.stats[4], t_stage); atomicAdd(&P.stats[5], t_expand);
+        atomicAdd(&P.stats[6], t_select); atomicAdd(&P.stats[7], t_mlp);
     }
     if (P.sims > 0) packed = wave_stage_rng_from(P, tree, valid, rng_tile, packed);   // words for the last expansion
     if (valid) {
         if (P.sims > 0) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            expand_backup_tree<MAXA>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A]);
+            expand_backup_tree<MAXA>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
+                                     lpath + lane * P.P, pvals + lane * P.P);
+            // leave the last path where the step-wise entry points and the debug dump expect it
+            for (int i = 0; i < h.path_len; i++) P.path[(size_t)tree * P.P + i] = lpath[lane * P.P + i];
             packed = rng.pack();
         }
         P.rng_pos[tree] = packed;
@@ -703,6 +755,7 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     Params &P = h->P;
     memset(&P, 0, sizeof(P));
     P.B = B; P.A = A; P.K = h->K; P.S = S; P.N = h->N; P.P = h->Ppath; P.sims = sims;
+    P.dbg = getenv("SMZ_DEBUG_SKIP") ? atoi(getenv("SMZ_DEBUG_SKIP")) : 0;
     {   // trees per wavefront: spread small batches over the whole chip (>= 1 wave per SIMD before packing lanes)
         int tpw = kWave;
         while (tpw > 4 && (B + tpw - 1) / tpw < 1024) tpw >>= 1;
@@ -733,7 +786,7 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     A_(dev_alloc(h, &h->d_seeds, (size_t)B));
     A_(dev_alloc(h, &h->d_pbc, (size_t)sims + 2));
     A_(dev_alloc(h, &h->d_pow, (size_t)sims + 1));
-    A_(dev_alloc(h, &h->d_stats, (size_t)4));
+    A_(dev_alloc(h, &h->d_stats, (size_t)8));
     A_(dev_alloc(h, &h->d_mt_backup, (size_t)B * kMtN));
     A_(dev_alloc(h, &h->d_pos_backup, (size_t)B));
     h->has_backup = false;
@@ -744,7 +797,7 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     // defined contents before first use
     hipError_t e = hipMemset(P.nodes, 0, (size_t)B * (size_t)P.tree_words * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(P.hdr, 0, (size_t)B * sizeof(TreeHdr));
-    if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(P.rng_pos, 0, (size_t)B * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(P.mt, 0, (size_t)B * kMtN * sizeof(uint32_t));
     if (e != hipSuccess) { smz_destroy(h); return fail(SMZ_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e)); }
@@ -936,9 +989,8 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     int tpw = 1;
     while (tpw < kWave && (size_t)256 * kWaves * tpw < (size_t)P.B) tpw <<= 1;
     P.tpw = tpw;
-    const int per_wave = smz_mlp::scratch_floats(*desc) + tpw * kRngStride + tpw * (P.A + 2);
-    const size_t lds = ((size_t)((desc->total_floats + 1) & ~1) + (size_t)kWaves * per_wave) * sizeof(float) +
-                       (size_t)(P.sims + 2) * sizeof(double);
+    const MegaLds ml = mega_lds(*desc, P, tpw);
+    const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave) * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_INVALID, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
 #define SMZ_LAUNCH_SEARCH(UU)                                                                                          \
@@ -1109,9 +1161,11 @@ int smz_read_stats(smz_handle *h, uint64_t levels_out[4], int reset) {
     if (!h || !levels_out) return fail(SMZ_ERR_INVALID, "smz_read_stats: null argument%s");
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
-    unsigned long long v[4];
+    unsigned long long v[8];
     HIP_TRY(hipMemcpy(v, h->d_stats, sizeof(v), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) levels_out[i] = (uint64_t)v[i];
+    if (getenv("SMZ_DEBUG_SKIP") && (atoi(getenv("SMZ_DEBUG_SKIP")) & 16))
+        fprintf(stderr, "[smz phase cycles, summed over waves] stage %llu expand %llu select %llu mlp %llu\n", v[4], v[5], v[6], v[7]);
     if (reset) HIP_TRY(hipMemset(h->d_stats, 0, sizeof(v)));
     return SMZ_OK;
 }

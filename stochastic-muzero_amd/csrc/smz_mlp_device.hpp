@@ -19,29 +19,78 @@ enum { M_DYN_IN, M_ADY_IN, M_DYN_MID, M_ADY_MID, M_DYN_OUT, M_ADY_OUT, M_PRE_IN,
 
 __host__ __device__ inline int up4(int x) { return (x + 3) & ~3; }
 
-// acc[u] = bias[o] + sum_k W[k][o] * act[k]  for o = lane + 64 u
+// acc[u] = bias[o] + sum_k W[k][o] * act[k]  for o = lane + 64 u  (k ascending into one accumulator: every caller
+// rounds identically).  Four 4-wide steps per iteration with their eight 16-byte LDS reads issued back to back, so a
+// single LDS latency covers 16 inputs (the plain loop is a chain of 49 exposed LDS round trips per row).
 template <int U>
 __device__ inline void dense(const float *W, const float *bias, const float *act, int K4, int OP, int lane, float (&acc)[U]) {
 #pragma unroll
     for (int u = 0; u < U; u++) acc[u] = bias[lane + kWave * u];
-    for (int k = 0; k < K4; k += 4) {
-        const float4 a = *reinterpret_cast<const float4 *>(act + k);
+    const float4 *a4 = reinterpret_cast<const float4 *>(act);
+    const float4 *w4 = reinterpret_cast<const float4 *>(W) + lane;
+    const int n = K4 >> 2;
+    int q = 0;
+    for (; q + 4 <= n; q += 4) {
+        const float4 a0 = a4[q], a1 = a4[q + 1], a2 = a4[q + 2], a3 = a4[q + 3];
+        float4 w0[U], w1[U], w2[U], w3[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const float4 w = *reinterpret_cast<const float4 *>(W + ((size_t)(k >> 2) * OP + lane + kWave * u) * 4);
-            acc[u] = fmaf(w.x, a.x, acc[u]);
-            acc[u] = fmaf(w.y, a.y, acc[u]);
-            acc[u] = fmaf(w.z, a.z, acc[u]);
-            acc[u] = fmaf(w.w, a.w, acc[u]);
+            w0[u] = w4[(size_t)q * OP + kWave * u];
+            w1[u] = w4[(size_t)(q + 1) * OP + kWave * u];
+            w2[u] = w4[(size_t)(q + 2) * OP + kWave * u];
+            w3[u] = w4[(size_t)(q + 3) * OP + kWave * u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float r = acc[u];
+            r = fmaf(w0[u].x, a0.x, r); r = fmaf(w0[u].y, a0.y, r); r = fmaf(w0[u].z, a0.z, r); r = fmaf(w0[u].w, a0.w, r);
+            r = fmaf(w1[u].x, a1.x, r); r = fmaf(w1[u].y, a1.y, r); r = fmaf(w1[u].z, a1.z, r); r = fmaf(w1[u].w, a1.w, r);
+            r = fmaf(w2[u].x, a2.x, r); r = fmaf(w2[u].y, a2.y, r); r = fmaf(w2[u].z, a2.z, r); r = fmaf(w2[u].w, a2.w, r);
+            r = fmaf(w3[u].x, a3.x, r); r = fmaf(w3[u].y, a3.y, r); r = fmaf(w3[u].z, a3.z, r); r = fmaf(w3[u].w, a3.w, r);
+            acc[u] = r;
+        }
+    }
+    for (; q < n; q++) {
+        const float4 a = a4[q];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float4 w = w4[(size_t)q * OP + kWave * u];
+            float r = acc[u];
+            r = fmaf(w.x, a.x, r); r = fmaf(w.y, a.y, r); r = fmaf(w.z, a.z, r); r = fmaf(w.w, a.w, r);
+            acc[u] = r;
         }
     }
 }
 
-__device__ inline float elu(float x) { return x > 0.f ? x : expm1f(x); }
-__device__ inline float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
-__device__ inline float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
-__device__ inline float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-__device__ inline void lds_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// torch's ELU evaluates exp(x) - 1 (aten/src/ATen/native/cpu/Activation.cpp elu_kernel)
+__device__ inline float elu(float x) { return x > 0.f ? x : expf(x) - 1.0f; }
+// Wave-wide reductions on the DPP crossbar (VALU latency) instead of ds_bpermute round trips: row_shr 1/2/4/8 build the
+// per-16-lane-row totals in lanes 15/31/47/63, row_bcast:15 / row_bcast:31 carry them across rows, lane 63 holds the
+// result and is broadcast through an SGPR.  `ident` fills the lanes a shift has no source for.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_move(float ident, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+#define SMZ_WAVE_REDUCE(NAME, OP, IDENT)                                   \
+    __device__ inline float NAME(float v) {                                \
+        const float id = IDENT;                                            \
+        v = OP(v, dpp_move<0x111, 0xf>(id, v)); /* row_shr:1 */            \
+        v = OP(v, dpp_move<0x112, 0xf>(id, v)); /* row_shr:2 */            \
+        v = OP(v, dpp_move<0x114, 0xf>(id, v)); /* row_shr:4 */            \
+        v = OP(v, dpp_move<0x118, 0xf>(id, v)); /* row_shr:8 */            \
+        v = OP(v, dpp_move<0x142, 0xa>(id, v)); /* row_bcast:15 -> rows 1,3 */ \
+        v = OP(v, dpp_move<0x143, 0xc>(id, v)); /* row_bcast:31 -> rows 2,3 */ \
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); \
+    }
+__device__ inline float op_add(float a, float b) { return a + b; }
+SMZ_WAVE_REDUCE(wave_max, fmaxf, -__builtin_inff())
+SMZ_WAVE_REDUCE(wave_min, fminf, __builtin_inff())
+SMZ_WAVE_REDUCE(wave_sum, op_add, 0.0f)
+#undef SMZ_WAVE_REDUCE
+// Orders this wave's LDS traffic: LDS instructions of one wave execute in issue order, so other lanes' earlier writes are
+// visible once they have been issued; the asm is a compiler barrier plus an LDS-counter wait.  (A scoped fence here
+// would also drain vmcnt, i.e. wait for every outstanding GLOBAL store of the row before each layer.)
+__device__ inline void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
 // inverse_transform_with_support over the values held by the lanes whose output index is in [lo, lo+S) (muzero_model.py:575-591)
 template <int U>
