@@ -229,8 +229,17 @@ def main():
         if not single:
             ms, mean_us, bytes_launch = tms, tree_us, tree_bytes
         achieved = bytes_launch / (mean_us * 1e-6) / 1e9
+        # HBM bytes per launch from the TCC counters, when a PMC pass of this workload/kernel has been committed
+        traffic, traffic_note = None, None
+        tfile = os.path.join(ROOT, "profiles", "r01_e_traffic_k_search_mlp.json")
+        if single and Bg == 4096 and args.workload == "cartpole_mlp_4096x50" and os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            traffic = tj["hbm_bytes_per_launch_raw"]
+            traffic_note = ("(FETCH_SIZE + WRITE_SIZE) x 1024 per launch from " + os.path.basename(tfile) +
+                            "; read side may be under-counted up to 2x on gfx950 (upper bound %.0f)" % tj["hbm_bytes_per_launch_read_x2"])
         out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_launch,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                           "bytes_per_launch": bytes_launch,
                            "mean_launch_us": mean_us, "median_launch_us": float(np.median(ms) * 1e3),
                            "launches_timed": int(ms.size), "bytes_per_tree_select": k2,
                            "bytes_per_tree_expand_backup": k5, "mean_depth": depth,

@@ -409,15 +409,28 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
                 xall[t * K4in + k] = (k < S) ? src[k] : ((k < S + A && (k - S) == act) ? 1.f : 0.f);
         }
         smz_mlp::lds_sync();
-        for (int t = 0; t < tpw; t++) {
-            const int row = tree0 + t;
-            if (row >= P.B) break;                               // wave-uniform
-            const int leaf = __builtin_amdgcn_readlane(L.leaf_id, t);
-            const bool dyn = __builtin_amdgcn_readlane(L.branch, t) != 0;
-            float reward = 0.f, value = 0.f;
-            if (!(P.dbg & 1)) smz_mlp::recurrent_row<U>(lds, d, scratch, nullptr, xall + t * K4in, 0, dyn,
-                                      P.hidden + ((size_t)row * P.N + leaf) * S, nullptr, outs + t * slot, reward, value);
-            if (lane == 0) { outs[t * slot + A] = value; outs[t * slot + A + 1] = reward; }
+        for (int t = 0; t < tpw; t += smz_mlp::kRows) {
+            if (tree0 + t >= P.B) break;                         // wave-uniform
+            constexpr int R = smz_mlp::kRows;
+            const float *xin[R];
+            bool dyn[R], live[R];
+            float *dh[R], *dp[R];
+            float reward[R], value[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                live[r] = (t + r < tpw) && (tree0 + t + r < P.B);
+                const int tt = live[r] ? t + r : t;
+                const int row = tree0 + tt;
+                const int leaf = __builtin_amdgcn_readlane(L.leaf_id, tt);
+                dyn[r] = __builtin_amdgcn_readlane(L.branch, tt) != 0;
+                xin[r] = xall + tt * K4in;
+                dh[r] = P.hidden + ((size_t)row * P.N + leaf) * S;
+                dp[r] = outs + tt * slot;
+            }
+            if (!(P.dbg & 1)) smz_mlp::recurrent_rows<U, R>(lds, d, scratch, xin, dyn, live, dh, dp, reward, value);
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (live[r] && lane == 0) { outs[(t + r) * slot + A] = value[r]; outs[(t + r) * slot + A + 1] = reward[r]; }
         }
         smz_mlp::lds_sync();
         SMZ_STAMP(t_mlp)

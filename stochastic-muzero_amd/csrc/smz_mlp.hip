@@ -29,15 +29,33 @@ __global__ void __launch_bounds__(512) k_mlp_recurrent(smz_mlp_desc d, const flo
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, waves = blockDim.x / kWave;
     float *scratch = lds + d.total_floats + wave * scratch_floats(d);
     const int row0 = (blockIdx.x * waves + wave) * rows_per_wave;
-    for (int i = 0; i < rows_per_wave; i++) {
-        const int row = row0 + i;
-        if (row >= B) break;                       // wave-uniform
-        float reward, value;
-        recurrent_row<U>(lds, d, scratch, nullptr, x + (size_t)row * (d.S + d.A), 0, branch[row] != 0,
-                         hidden_out + (size_t)row * d.S, nullptr, policy_out + (size_t)row * d.A, reward, value);
-        if (lane == 0) {
-            if (reward_out) reward_out[row] = reward;
-            value_out[row] = value;
+    const int S = d.S, A = d.A, K4in = up4(S + A), rs = row_scratch_floats(d);
+    for (int i = 0; i < rows_per_wave; i += kRows) {
+        if (row0 + i >= B) break;                  // wave-uniform
+        const float *xin[kRows];
+        bool dyn[kRows], live[kRows];
+        float *dh[kRows], *dp[kRows];
+        float reward[kRows], value[kRows];
+#pragma unroll
+        for (int r = 0; r < kRows; r++) {
+            const int row = row0 + i + r;
+            live[r] = (i + r < rows_per_wave) && row < B;
+            const int rr = live[r] ? row : row0 + i;
+            float *xb = scratch + r * rs;
+            for (int k = lane; k < K4in; k += kWave) xb[k] = (k < S + A) ? x[(size_t)rr * (S + A) + k] : 0.f;
+            xin[r] = xb;
+            dyn[r] = branch[rr] != 0;
+            dh[r] = hidden_out + (size_t)rr * S;
+            dp[r] = policy_out + (size_t)rr * A;
+        }
+        lds_sync();
+        recurrent_rows<U, kRows>(lds, d, scratch, xin, dyn, live, dh, dp, reward, value);
+#pragma unroll
+        for (int r = 0; r < kRows; r++) {
+            if (live[r] && lane == 0) {
+                if (reward_out) reward_out[row0 + i + r] = reward[r];
+                value_out[row0 + i + r] = value[r];
+            }
         }
     }
 }

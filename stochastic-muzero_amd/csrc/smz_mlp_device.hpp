@@ -19,45 +19,61 @@ enum { M_DYN_IN, M_ADY_IN, M_DYN_MID, M_ADY_MID, M_DYN_OUT, M_ADY_OUT, M_PRE_IN,
 
 __host__ __device__ inline int up4(int x) { return (x + 3) & ~3; }
 
-// acc[u] = bias[o] + sum_k W[k][o] * act[k]  for o = lane + 64 u  (k ascending into one accumulator: every caller
-// rounds identically).  Four 4-wide steps per iteration with their eight 16-byte LDS reads issued back to back, so a
-// single LDS latency covers 16 inputs (the plain loop is a chain of 49 exposed LDS round trips per row).
-template <int U>
-__device__ inline void dense(const float *W, const float *bias, const float *act, int K4, int OP, int lane, float (&acc)[U]) {
+// acc[r][u] = bias_r[o] + sum_k W_r[k][o] * act_r[k]  for o = lane + 64 u, for R rows at once (each row may use a
+// different matrix: its branch's).  k ascends into one accumulator per output, so every caller rounds identically.
+// Four 4-wide steps per iteration with all their 16-byte LDS reads issued back to back, and the R rows' dependent FMA
+// chains interleaved: one LDS latency covers 16 inputs of every row (the plain loop is a chain of exposed round trips).
+template <int U, int R>
+__device__ inline void dense(const float *const (&W)[R], const float *const (&bias)[R], const float *const (&act)[R], int K4,
+                             int OP, int lane, float (&acc)[R][U]) {
+    const float4 *a4[R], *w4[R];
 #pragma unroll
-    for (int u = 0; u < U; u++) acc[u] = bias[lane + kWave * u];
-    const float4 *a4 = reinterpret_cast<const float4 *>(act);
-    const float4 *w4 = reinterpret_cast<const float4 *>(W) + lane;
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int u = 0; u < U; u++) acc[r][u] = bias[r][lane + kWave * u];
+        a4[r] = reinterpret_cast<const float4 *>(act[r]);
+        w4[r] = reinterpret_cast<const float4 *>(W[r]) + lane;
+    }
     const int n = K4 >> 2;
     int q = 0;
     for (; q + 4 <= n; q += 4) {
-        const float4 a0 = a4[q], a1 = a4[q + 1], a2 = a4[q + 2], a3 = a4[q + 3];
-        float4 w0[U], w1[U], w2[U], w3[U];
+        float4 a[R][4], w[R][U][4];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            w0[u] = w4[(size_t)q * OP + kWave * u];
-            w1[u] = w4[(size_t)(q + 1) * OP + kWave * u];
-            w2[u] = w4[(size_t)(q + 2) * OP + kWave * u];
-            w3[u] = w4[(size_t)(q + 3) * OP + kWave * u];
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                a[r][j] = a4[r][q + j];
+#pragma unroll
+                for (int u = 0; u < U; u++) w[r][u][j] = w4[r][(size_t)(q + j) * OP + kWave * u];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            float r = acc[u];
-            r = fmaf(w0[u].x, a0.x, r); r = fmaf(w0[u].y, a0.y, r); r = fmaf(w0[u].z, a0.z, r); r = fmaf(w0[u].w, a0.w, r);
-            r = fmaf(w1[u].x, a1.x, r); r = fmaf(w1[u].y, a1.y, r); r = fmaf(w1[u].z, a1.z, r); r = fmaf(w1[u].w, a1.w, r);
-            r = fmaf(w2[u].x, a2.x, r); r = fmaf(w2[u].y, a2.y, r); r = fmaf(w2[u].z, a2.z, r); r = fmaf(w2[u].w, a2.w, r);
-            r = fmaf(w3[u].x, a3.x, r); r = fmaf(w3[u].y, a3.y, r); r = fmaf(w3[u].z, a3.z, r); r = fmaf(w3[u].w, a3.w, r);
-            acc[u] = r;
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    float t = acc[r][u];
+                    t = fmaf(w[r][u][j].x, a[r][j].x, t);
+                    t = fmaf(w[r][u][j].y, a[r][j].y, t);
+                    t = fmaf(w[r][u][j].z, a[r][j].z, t);
+                    t = fmaf(w[r][u][j].w, a[r][j].w, t);
+                    acc[r][u] = t;
+                }
+            }
         }
     }
     for (; q < n; q++) {
-        const float4 a = a4[q];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const float4 w = w4[(size_t)q * OP + kWave * u];
-            float r = acc[u];
-            r = fmaf(w.x, a.x, r); r = fmaf(w.y, a.y, r); r = fmaf(w.z, a.z, r); r = fmaf(w.w, a.w, r);
-            acc[u] = r;
+        for (int r = 0; r < R; r++) {
+            const float4 av = a4[r][q];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const float4 wv = w4[r][(size_t)q * OP + kWave * u];
+                float t = acc[r][u];
+                t = fmaf(wv.x, av.x, t); t = fmaf(wv.y, av.y, t); t = fmaf(wv.z, av.z, t); t = fmaf(wv.w, av.w, t);
+                acc[r][u] = t;
+            }
         }
     }
 }
@@ -151,20 +167,31 @@ __device__ inline void softmax_lanes(const float (&v)[U], int A, int lane, float
     for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) dst[o] = expf(v[u] - m) / den; }
 }
 
-// hidden trunk: in-layer + L repeats of the shared mid layer, ELU after each; result in `bufA` (LDS, zero padded to K4h)
-template <int U>
-__device__ inline void trunk(const float *lds, const smz_mlp_desc &d, int m_in, int m_mid, const float *act_in, int K4in,
-                             float *bufA, float *bufB, int lane) {
-    float acc[U];
-    dense<U>(lds + d.off[m_in], lds + d.off[M_COUNT + m_in], act_in, K4in, d.OP, lane, acc);
+// hidden trunk for R rows: in-layer + L repeats of the shared mid layer, ELU after each; results in tA[r] (LDS, zero
+// padded to a multiple of 4).  m_in[r] / m_mid[r] pick each row's matrices.
+template <int U, int R>
+__device__ inline void trunk(const float *lds, const smz_mlp_desc &d, const int (&m_in)[R], const int (&m_mid)[R],
+                             const float *const (&act_in)[R], int K4in, float *const (&tA)[R], int lane) {
+    float acc[R][U];
+    const float *W[R], *Bv[R];
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < up4(d.H)) bufA[o] = (o < d.H) ? elu(acc[u]) : 0.f; }
+    for (int r = 0; r < R; r++) { W[r] = lds + d.off[m_in[r]]; Bv[r] = lds + d.off[M_COUNT + m_in[r]]; }
+    dense<U, R>(W, Bv, act_in, K4in, d.OP, lane, acc);
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < up4(d.H)) tA[r][o] = (o < d.H) ? elu(acc[r][u]) : 0.f; }
     lds_sync();
     for (int l = 0; l < d.L; l++) {
-        dense<U>(lds + d.off[m_mid], lds + d.off[M_COUNT + m_mid], bufA, up4(d.H), d.OP, lane, acc);
-        lds_sync();   // every lane has issued its reads of bufA (LDS is in order per wave) before it is overwritten
+        const float *Wm[R], *Bm[R], *Am[R];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < up4(d.H)) bufA[o] = (o < d.H) ? elu(acc[u]) : 0.f; }
+        for (int r = 0; r < R; r++) { Wm[r] = lds + d.off[m_mid[r]]; Bm[r] = lds + d.off[M_COUNT + m_mid[r]]; Am[r] = tA[r]; }
+        dense<U, R>(Wm, Bm, Am, up4(d.H), d.OP, lane, acc);
+        lds_sync();   // every lane has issued its reads of tA (LDS is in order per wave) before it is overwritten
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < up4(d.H)) tA[r][o] = (o < d.H) ? elu(acc[r][u]) : 0.f; }
         lds_sync();
     }
 }
@@ -192,46 +219,76 @@ __device__ inline void stage_weights(float *lds, const float *weights, const int
     __syncthreads();
 }
 
-__host__ __device__ inline int scratch_floats(const smz_mlp_desc &d) {
-    const int kin = up4(d.S + d.A) > up4(d.obs) ? up4(d.S + d.A) : up4(d.obs);
-    return kin + 2 * up4(d.H) + up4(d.S);
-}
+constexpr int kRows = 1;   // rows a wavefront evaluates together (2 was measured slower: the SIMD is issue-bound, not latency-bound)
 
-// One recurrent evaluation (monte_carlo_tree_search.py:333-342) by one wavefront.  `scratch` = this wave's LDS scratch
-// (scratch_floats() floats).  `xsrc_h` = parent hidden row (S floats, global), `action` = last action.
-// Writes hidden' to dst_hidden0 and (if non-null) dst_hidden1 (S floats each), policy (A floats), returns reward/value
-// in every lane.
-template <int U>
-__device__ inline void recurrent_row(const float *lds, const smz_mlp_desc &d, float *scratch, const float *xsrc_h,
-                                     const float *xsrc_full, int action, bool dyn, float *dst_hidden0,
-                                     float *dst_hidden1, float *dst_policy, float &reward, float &value) {
+// per-row LDS scratch: input vector | trunk activations | hidden state; a wave owns kRows of them
+__host__ __device__ inline int row_scratch_floats(const smz_mlp_desc &d) {
+    const int kin = up4(d.S + d.A) > up4(d.obs) ? up4(d.S + d.A) : up4(d.obs);
+    return kin + up4(d.H) + up4(d.S);
+}
+__host__ __device__ inline int scratch_floats(const smz_mlp_desc &d) { return kRows * row_scratch_floats(d); }
+
+// R recurrent evaluations (monte_carlo_tree_search.py:333-342) by one wavefront.  xin[r]: the row's network input
+// [hidden | one-hot], K4in floats, zero padded, in LDS.  dyn[r]: the row's branch.  live[r] = false suppresses the
+// row's global stores (odd tail).  Writes hidden' to dst_hidden[r] (S floats), the policy to dst_policy[r]; reward and
+// value are returned in every lane.
+template <int U, int R>
+__device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, float *scratch, const float *const (&xin)[R],
+                                      const bool (&dyn)[R], const bool (&live)[R], float *const (&dst_hidden)[R],
+                                      float *const (&dst_policy)[R], float (&reward)[R], float (&value)[R]) {
     const int S = d.S, A = d.A, K4in = up4(S + A), K4h = up4(d.H), K4s = up4(S);
     const int lane = threadIdx.x & (kWave - 1);
-    float *xbuf = scratch, *tA = xbuf + (up4(d.S + d.A) > up4(d.obs) ? up4(d.S + d.A) : up4(d.obs)), *tB = tA + K4h, *hbuf = tB + K4h;
-    for (int k = lane; k < K4in; k += kWave) {
-        float v = 0.f;
-        if (k < S + A) v = xsrc_full ? xsrc_full[k] : (k < S ? xsrc_h[k] : ((k - S) == action ? 1.f : 0.f));
-        xbuf[k] = v;
+    const int rs = row_scratch_floats(d), kin = rs - K4h - K4s;
+    float *tA[R], *hbuf[R];
+    int m1[R], m1m[R], m3[R], m3m[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        tA[r] = scratch + r * rs + kin;
+        hbuf[r] = tA[r] + K4h;
+        m1[r] = dyn[r] ? M_DYN_IN : M_ADY_IN;   m1m[r] = dyn[r] ? M_DYN_MID : M_ADY_MID;
+        m3[r] = dyn[r] ? M_PRE_IN : M_APR_IN;   m3m[r] = dyn[r] ? M_PRE_MID : M_APR_MID;
+        for (int k = lane; k < K4s; k += kWave) hbuf[r][k] = 0.f;
     }
-    for (int k = lane; k < K4s; k += kWave) hbuf[k] = 0.f;
-    lds_sync();
-    trunk<U>(lds, d, dyn ? M_DYN_IN : M_ADY_IN, dyn ? M_DYN_MID : M_ADY_MID, xbuf, K4in, tA, tB, lane);
-    float acc[U];
-    reward = 0.f;
-    if (dyn) {
-        dense<U>(lds + d.off[M_DYN_OUT], lds + d.off[M_COUNT + M_DYN_OUT], tA, K4h, d.OP, lane, acc);
-        reward = decode_lanes<U>(acc, 0, S, lane);
-        scale_lanes<U>(acc, S, S, lane, hbuf, dst_hidden0, dst_hidden1);
-    } else {
-        dense<U>(lds + d.off[M_ADY_OUT], lds + d.off[M_COUNT + M_ADY_OUT], tA, K4h, d.OP, lane, acc);
-        scale_lanes<U>(acc, 0, S, lane, hbuf, dst_hidden0, dst_hidden1);
+    trunk<U, R>(lds, d, m1, m1m, xin, K4in, tA, lane);
+    float acc[R][U];
+    {
+        const float *W[R], *Bv[R], *Ac[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int m = dyn[r] ? M_DYN_OUT : M_ADY_OUT;
+            W[r] = lds + d.off[m]; Bv[r] = lds + d.off[M_COUNT + m]; Ac[r] = tA[r];
+        }
+        dense<U, R>(W, Bv, Ac, K4h, d.OP, lane, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        reward[r] = 0.f;
+        if (dyn[r]) {       // [reward logits | next state]
+            reward[r] = decode_lanes<U>(acc[r], 0, S, lane);
+            scale_lanes<U>(acc[r], S, S, lane, hbuf[r], live[r] ? dst_hidden[r] : nullptr);
+        } else {
+            scale_lanes<U>(acc[r], 0, S, lane, hbuf[r], live[r] ? dst_hidden[r] : nullptr);
+        }
     }
     lds_sync();
-    trunk<U>(lds, d, dyn ? M_PRE_IN : M_APR_IN, dyn ? M_PRE_MID : M_APR_MID, hbuf, K4s, tA, tB, lane);
-    dense<U>(lds + d.off[dyn ? M_PRE_OUT : M_APR_OUT], lds + d.off[M_COUNT + (dyn ? M_PRE_OUT : M_APR_OUT)], tA, K4h,
-             d.OP, lane, acc);
-    softmax_lanes<U>(acc, A, lane, dst_policy);
-    value = decode_lanes<U>(acc, A, S, lane);
+    {
+        const float *Hc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) Hc[r] = hbuf[r];
+        trunk<U, R>(lds, d, m3, m3m, Hc, K4s, tA, lane);
+        const float *W[R], *Bv[R], *Ac[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int m = dyn[r] ? M_PRE_OUT : M_APR_OUT;
+            W[r] = lds + d.off[m]; Bv[r] = lds + d.off[M_COUNT + m]; Ac[r] = tA[r];
+        }
+        dense<U, R>(W, Bv, Ac, K4h, d.OP, lane, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (live[r]) softmax_lanes<U>(acc[r], A, lane, dst_policy[r]);
+        value[r] = decode_lanes<U>(acc[r], A, S, lane);
+    }
     lds_sync();
 }
 
@@ -241,18 +298,31 @@ __device__ inline void initial_row(const float *lds, const smz_mlp_desc &d, floa
                                    float *dst_hidden0, float *dst_hidden1, float *dst_policy) {
     const int S = d.S, A = d.A, K4o = up4(d.obs), K4h = up4(d.H), K4s = up4(S);
     const int lane = threadIdx.x & (kWave - 1);
-    float *xbuf = scratch, *tA = xbuf + (up4(d.S + d.A) > up4(d.obs) ? up4(d.S + d.A) : up4(d.obs)), *tB = tA + K4h, *hbuf = tB + K4h;
+    const int rs = row_scratch_floats(d), kin = rs - K4h - K4s;
+    float *xbuf = scratch;
+    float *tA[1] = {scratch + kin};
+    float *hbuf = tA[0] + K4h;
     for (int k = lane; k < K4o; k += kWave) xbuf[k] = (k < d.obs) ? obs_row[k] : 0.f;
     for (int k = lane; k < K4s; k += kWave) hbuf[k] = 0.f;
     lds_sync();
-    trunk<U>(lds, d, M_REP_IN, M_REP_MID, xbuf, K4o, tA, tB, lane);
-    float acc[U];
-    dense<U>(lds + d.off[M_REP_OUT], lds + d.off[M_COUNT + M_REP_OUT], tA, K4h, d.OP, lane, acc);
-    scale_lanes<U>(acc, 0, S, lane, hbuf, dst_hidden0, dst_hidden1);
+    const int mi[1] = {M_REP_IN}, mm[1] = {M_REP_MID};
+    const float *xi[1] = {xbuf};
+    trunk<U, 1>(lds, d, mi, mm, xi, K4o, tA, lane);
+    float acc[1][U];
+    {
+        const float *W[1] = {lds + d.off[M_REP_OUT]}, *Bv[1] = {lds + d.off[M_COUNT + M_REP_OUT]}, *Ac[1] = {tA[0]};
+        dense<U, 1>(W, Bv, Ac, K4h, d.OP, lane, acc);
+    }
+    scale_lanes<U>(acc[0], 0, S, lane, hbuf, dst_hidden0, dst_hidden1);
     lds_sync();
-    trunk<U>(lds, d, M_PRE_IN, M_PRE_MID, hbuf, K4s, tA, tB, lane);
-    dense<U>(lds + d.off[M_PRE_OUT], lds + d.off[M_COUNT + M_PRE_OUT], tA, K4h, d.OP, lane, acc);
-    softmax_lanes<U>(acc, A, lane, dst_policy);
+    const int pi[1] = {M_PRE_IN}, pm[1] = {M_PRE_MID};
+    const float *hi[1] = {hbuf};
+    trunk<U, 1>(lds, d, pi, pm, hi, K4s, tA, lane);
+    {
+        const float *W[1] = {lds + d.off[M_PRE_OUT]}, *Bv[1] = {lds + d.off[M_COUNT + M_PRE_OUT]}, *Ac[1] = {tA[0]};
+        dense<U, 1>(W, Bv, Ac, K4h, d.OP, lane, acc);
+    }
+    softmax_lanes<U>(acc[0], A, lane, dst_policy);
     lds_sync();
 }
 
