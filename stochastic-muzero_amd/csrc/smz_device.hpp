@@ -274,10 +274,11 @@ struct Leaf {
 
 // `path` receives the (block << 8 | slot) entries; when `pathvals` is given (LDS, one uint4 per level) the chosen
 // child's visit count, value sum and reward are recorded too, so that the backup needs no loads at all.
-template <int MAXA>
+// LDSPATH = false: entries go to `path` (global).  LDSPATH = true: `path` is ignored, records go to `pathvals`.
+template <int MAXA, bool LDSPATH = false>
 __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const TreeHdr &h, const double *pbc_sqrt,
                                    int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children,
-                                   int32_t *path, uint4 *pathvals = nullptr) {
+                                   int32_t *path, uint4 *pathvals) {
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
     const float mn = h.mn, mx = h.mx;
@@ -352,8 +353,8 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
 #pragma unroll
         for (int j = 0; j < MAXA; j++) if (j == pick) { c = chd[j]; cur_visit = vis[j]; action = act[j]; pv = vsum[j]; pr = rew[j]; }
         const int loc = (blk << 8) | pick;
-        path[depth] = loc;
-        if (pathvals) pathvals[depth] = make_uint4((uint32_t)loc, (uint32_t)cur_visit, __float_as_uint(pv), __float_as_uint(pr));
+        if (!LDSPATH) path[depth] = loc;
+        else pathvals[depth] = make_uint4((uint32_t)loc, (uint32_t)cur_visit, __float_as_uint(pv), __float_as_uint(pr));
         parent_id = leaf_id;
         leaf_id = loc_node_id(P, loc);
         depth++;
@@ -373,15 +374,15 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
 // expansion + backup (monte_carlo_tree_search.py:289-308); the leaf's hidden row is stored by the caller.
 // Returns the leaf's node id.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAXA>
+template <int MAXA, bool LDSPATH = false>
 __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, TreeHdr &h, const float *policy_row,
-                                         float reward, float value, const int32_t *path, const uint4 *pathvals = nullptr) {
+                                         float reward, float value, const int32_t *path, const uint4 *pathvals) {
     constexpr int CH = 8;   // path nodes gathered per round trip
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
     const int len = h.path_len;
     // ---- gather the path (independent loads) -------------------------------------------------------------------
-    const int leaf_loc = path[len - 1];
+    const int leaf_loc = LDSPATH ? (int)pathvals[len - 1].x : path[len - 1];
     const int pflag = depth_flag(len - 1);       // flag of the leaf's parent (depth len-1; root is depth 0)
     // ---- expansion ---------------------------------------------------------------------------------------------
     float p[MAXA], pol[MAXA];
@@ -423,7 +424,7 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, Tr
     // ---- backup, leaf -> root, CH nodes per round trip ------------------------------------------------------------
     float v = value;
     float mn = h.mn, mx = h.mx;
-    if (pathvals) {
+    if (LDSPATH) {
         // the select that recorded this path also recorded each node's (visit, value_sum, reward): stores only
         for (int i = len - 1; i >= 0; i--) {
             const uint4 e = pathvals[i];

@@ -236,7 +236,8 @@ __device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &
     unsigned n_dec = 0, n_chance = 0, n_children = 0;
     if (valid) {
         int len = 0;
-        L = select_tree<MAXA>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, P.path + (size_t)tree * P.P);
+        L = select_tree<MAXA, false>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, P.path + (size_t)tree * P.P,
+                                    (uint4 *)nullptr);
         h.path_len = len;
         if (last_action) last_action[tree] = L.action;
         if (branch) branch[tree] = (uint8_t)L.branch;
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(kWave) k_expand_backup(Params P, const float *
         rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + threadIdx.x * kRngStride, kRngStage);
         h = P.hdr[tree];
         leaf = expand_backup_tree<MAXA>(P, tree, rng, h, policy + (size_t)tree * P.A, reward ? reward[tree] : 0.0f,
-                                        value[tree], P.path + (size_t)tree * P.P);
+                                        value[tree], P.path + (size_t)tree * P.P, (const uint4 *)nullptr);
     }
     if (P.S > 0 && hidden) {
         const int t = valid ? tree : 0;
@@ -311,20 +312,19 @@ __global__ void __launch_bounds__(kWave) k_expand_backup(Params P, const float *
 extern __shared__ float4 smz_search_lds4[];
 
 // LDS map of k_search_mlp (floats): weights | pbc table (doubles) | per wave, every part padded to 16 bytes:
-//   mlp scratch | network inputs [tpw][K4in] | path records [tpw][P] uint4 | path [tpw][P] | rng tile | head outputs
+//   mlp scratch | network inputs [tpw][K4in] | path records [tpw][P] uint4 | rng tile | head outputs
 struct MegaLds {
     int pbc_off, wave_off, per_wave;                       // float offsets from the LDS base
-    int x_off, pv_off, path_off, rng_off, out_off;         // float offsets inside a wave's region
+    int x_off, pv_off, rng_off, out_off;                   // float offsets inside a wave's region
 };
 __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params &P, int tpw) {
     MegaLds m;
-    m.pbc_off = r4(d.total_floats);
+    m.pbc_off = r4(d.total_floats - smz_mlp::rep_floats(d));
     m.wave_off = m.pbc_off + r4(2 * (P.sims + 2));
     m.x_off = r4(smz_mlp::scratch_floats(d));
     m.pv_off = m.x_off + tpw * smz_mlp::up4(P.S + P.A);
-    m.path_off = m.pv_off + tpw * P.P * 4;
-    m.rng_off = m.path_off + r4(tpw * P.P);
+    m.rng_off = m.pv_off + tpw * P.P * 4;
     m.out_off = m.rng_off + r4(tpw * kRngStride);
     m.per_wave = m.out_off + r4(tpw * (P.A + 2));
     return m;
@@ -334,7 +334,8 @@ template <int MAXA, int U>
 __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train) {
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
-    smz_mlp::stage_all_weights(lds, weights, d);
+    const smz_mlp_desc dl = smz_mlp::lds_desc_without_rep(d);      // LDS copy: everything but the representation matrices
+    smz_mlp::stage_weights_without_rep(lds, weights, d);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, waves = blockDim.x / kWave;
     const int A = P.A, S = P.S, tpw = P.tpw;
     const MegaLds ml = mega_lds(d, P, tpw);
@@ -346,7 +347,6 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
     float *scratch = lds + ml.wave_off + wave * ml.per_wave;
     float *xall = scratch + ml.x_off;                                           // [tpw][K4in] network inputs of the round
     uint4 *pvals = reinterpret_cast<uint4 *>(scratch + ml.pv_off);              // [tpw][P] path records
-    int32_t *lpath = reinterpret_cast<int32_t *>(scratch + ml.path_off);        // [tpw][P]
     uint32_t *rng_tile = reinterpret_cast<uint32_t *>(scratch + ml.rng_off);
     float *outs = scratch + ml.out_off;                                         // [tpw][A + 2]: policy | value | reward
     __syncthreads();
@@ -359,8 +359,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
     for (int t = 0; t < tpw; t++) {
         const int row = tree0 + t;
         if (row >= P.B) break;                                   // wave-uniform
-        smz_mlp::initial_row<U>(lds, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * S, nullptr,
-                                outs + t * slot);
+        smz_mlp::initial_row<U>(lds, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * S,
+                                nullptr, outs + t * slot);
     }
     int packed = wave_stage_rng(P, tree, valid, rng_tile);
     Rng rng;
@@ -383,15 +383,15 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
         Leaf L = {0, 0, 0, 0};
         if (valid) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            if (s > 0 && !(P.dbg & 4)) expand_backup_tree<MAXA>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
-                                                outs[lane * slot + A], lpath + lane * P.P, pvals + lane * P.P);
+            if (s > 0 && !(P.dbg & 4)) expand_backup_tree<MAXA, true>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
+                                                outs[lane * slot + A], P.path, pvals + lane * P.P);
         }
         SMZ_STAMP(t_expand)
         if (valid) {
             int len = 0;
             if (P.dbg & 2) { L.leaf_id = 1; L.parent_id = 0; L.action = 0; L.branch = 0; len = 1; }
-            else L = select_tree<MAXA>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, lpath + lane * P.P,
-                                       pvals + lane * P.P);
+            else L = select_tree<MAXA, true>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, P.path,
+                                             pvals + lane * P.P);
             h.path_len = len;
             n_desc++;
             packed = rng.pack();
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
                 dh[r] = P.hidden + ((size_t)row * P.N + leaf) * S;
                 dp[r] = outs + tt * slot;
             }
-            if (!(P.dbg & 1)) smz_mlp::recurrent_rows<U, R>(lds, d, scratch, xin, dyn, live, dh, dp, reward, value);
+            if (!(P.dbg & 1)) smz_mlp::recurrent_rows<U, R>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
 #pragma unroll
             for (int r = 0; r < R; r++)
                 if (live[r] && lane == 0) { outs[(t + r) * slot + A] = value[r]; outs[(t + r) * slot + A + 1] = reward[r]; }
@@ -444,10 +444,10 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
     if (valid) {
         if (P.sims > 0) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            expand_backup_tree<MAXA>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
-                                     lpath + lane * P.P, pvals + lane * P.P);
+            expand_backup_tree<MAXA, true>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
+                                           P.path, pvals + lane * P.P);
             // leave the last path where the step-wise entry points and the debug dump expect it
-            for (int i = 0; i < h.path_len; i++) P.path[(size_t)tree * P.P + i] = lpath[lane * P.P + i];
+            for (int i = 0; i < h.path_len; i++) P.path[(size_t)tree * P.P + i] = (int32_t)pvals[lane * P.P + i].x;
             packed = rng.pack();
         }
         P.rng_pos[tree] = packed;

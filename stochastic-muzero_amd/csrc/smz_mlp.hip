@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(512) k_mlp_initial(smz_mlp_desc d, const float
     for (int i = 0; i < rows_per_wave; i++) {
         const int row = row0 + i;
         if (row >= B) break;
-        initial_row<U>(lds, d, scratch, obs + (size_t)row * d.obs, hidden_out + (size_t)row * d.S, nullptr,
+        initial_row<U>(lds, d, lds, d, scratch, obs + (size_t)row * d.obs, hidden_out + (size_t)row * d.S, nullptr,
                        policy_out + (size_t)row * d.A);
     }
 }

@@ -293,9 +293,12 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
 }
 
 // representation + root prediction for one observation row by one wavefront (muzero_model.py:802-841)
+// `rep`/`drep`: where the representation matrices live (LDS, or the packed buffer in global memory: they are used once
+// per search, so the whole-search kernel does not spend LDS on them); `lds`/`d`: the prediction matrices.
 template <int U>
-__device__ inline void initial_row(const float *lds, const smz_mlp_desc &d, float *scratch, const float *obs_row,
-                                   float *dst_hidden0, float *dst_hidden1, float *dst_policy) {
+__device__ inline void initial_row(const float *lds, const smz_mlp_desc &d, const float *rep, const smz_mlp_desc &drep,
+                                   float *scratch, const float *obs_row, float *dst_hidden0, float *dst_hidden1,
+                                   float *dst_policy) {
     const int S = d.S, A = d.A, K4o = up4(d.obs), K4h = up4(d.H), K4s = up4(S);
     const int lane = threadIdx.x & (kWave - 1);
     const int rs = row_scratch_floats(d), kin = rs - K4h - K4s;
@@ -307,10 +310,10 @@ __device__ inline void initial_row(const float *lds, const smz_mlp_desc &d, floa
     lds_sync();
     const int mi[1] = {M_REP_IN}, mm[1] = {M_REP_MID};
     const float *xi[1] = {xbuf};
-    trunk<U, 1>(lds, d, mi, mm, xi, K4o, tA, lane);
+    trunk<U, 1>(rep, drep, mi, mm, xi, K4o, tA, lane);
     float acc[1][U];
     {
-        const float *W[1] = {lds + d.off[M_REP_OUT]}, *Bv[1] = {lds + d.off[M_COUNT + M_REP_OUT]}, *Ac[1] = {tA[0]};
+        const float *W[1] = {rep + drep.off[M_REP_OUT]}, *Bv[1] = {rep + drep.off[M_COUNT + M_REP_OUT]}, *Ac[1] = {tA[0]};
         dense<U, 1>(W, Bv, Ac, K4h, d.OP, lane, acc);
     }
     scale_lanes<U>(acc[0], 0, S, lane, hbuf, dst_hidden0, dst_hidden1);
@@ -324,6 +327,34 @@ __device__ inline void initial_row(const float *lds, const smz_mlp_desc &d, floa
     }
     softmax_lanes<U>(acc[0], A, lane, dst_policy);
     lds_sync();
+}
+
+// Descriptor of the LDS copy that leaves the three representation matrices out: matrices 0..11 keep their offsets, the
+// bias block moves down by the size of the representation matrices (the rep entries themselves become invalid).
+__host__ __device__ inline int rep_floats(const smz_mlp_desc &d) { return d.off[M_COUNT] - d.off[M_REP_IN]; }
+__host__ __device__ inline smz_mlp_desc lds_desc_without_rep(const smz_mlp_desc &d) {
+    smz_mlp_desc l = d;
+    const int rs = rep_floats(d);
+    for (int m = 0; m < M_COUNT; m++) l.off[M_COUNT + m] = d.off[M_COUNT + m] - rs;
+    l.total_floats = d.total_floats - rs;
+    return l;
+}
+__device__ inline void stage_weights_without_rep(float *lds, const float *weights, const smz_mlp_desc &d) {
+    constexpr int UB = 8;
+    const int n_mat = d.off[M_REP_IN], n_bias = d.total_floats - d.off[M_COUNT], rs = rep_floats(d);
+    for (int pass = 0; pass < 2; pass++) {
+        const float *src = pass ? weights + d.off[M_COUNT] : weights;
+        float *dst = pass ? lds + d.off[M_COUNT] - rs : lds;
+        const int cnt = pass ? n_bias : n_mat;
+        for (int i0 = threadIdx.x * 4; i0 < cnt; i0 += blockDim.x * 4 * UB) {
+            float4 v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; u++) { const int i = i0 + u * blockDim.x * 4; if (i < cnt) v[u] = *reinterpret_cast<const float4 *>(src + i); }
+#pragma unroll
+            for (int u = 0; u < UB; u++) { const int i = i0 + u * blockDim.x * 4; if (i < cnt) *reinterpret_cast<float4 *>(dst + i) = v[u]; }
+        }
+    }
+    __syncthreads();
 }
 
 // which parts of the packed buffer each phase needs

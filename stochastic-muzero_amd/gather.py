@@ -15,6 +15,9 @@ def gather_to_learner(slab, dst=0, group=None):
         return [slab]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     slab = slab.contiguous()
+    if dist.get_backend(group) == "gloo" and slab.is_cuda:     # functional runs without RCCL: stage through the host
+        parts = gather_to_learner(slab.cpu(), dst, group)
+        return None if parts is None else [p.to(slab.device) for p in parts]
     if rank == dst:
         parts = [slab if r == dst else torch.empty_like(slab) for r in range(world)]
         ops = [dist.P2POp(dist.irecv, parts[r], r, group) for r in range(world) if r != dst]
