@@ -62,8 +62,8 @@ __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds)
 // sources of word p are p, p+1 and p+397 and at most 64 consecutive words change) -- and the tempered words go to
 // this wave's LDS tile [tree lane][word].  Global traffic is coalesced 256-byte segments.  Returns the lane's
 // packed (ready << 16 | idx) after staging.
+template <int U = 8>   // U trees in flight: their loads are all issued before the first dependent store
 __device__ inline int wave_stage_rng_from(const Params &P, int tree, bool valid, uint32_t *lds_tile, int packed) {
-    constexpr int U = 16;   // trees in flight: their loads are all issued before the first dependent store
     const int lane = threadIdx.x & (kWave - 1);
     const int tree0 = tree - lane;
     for (int t0 = 0; t0 < P.tpw; t0 += U) {
@@ -104,13 +104,13 @@ __device__ inline int wave_stage_rng_from(const Params &P, int tree, bool valid,
 }
 
 __device__ inline int wave_stage_rng(const Params &P, int tree, bool valid, uint32_t *lds_tile) {
-    return wave_stage_rng_from(P, tree, valid, lds_tile, valid ? P.rng_pos[tree] : 0);
+    return wave_stage_rng_from<8>(P, tree, valid, lds_tile, valid ? P.rng_pos[tree] : 0);
 }
 
 // Row moves.  `lpr` consecutive lanes move one row of `width` floats; the rows of the wave's 64 trees are handed
 // around with ds_bpermute.  Loads of kRowBatch rows are issued before the first store so that the (independent)
 // row reads overlap instead of each waiting behind the previous row's may-alias store.
-constexpr int kRowBatch = 16;
+constexpr int kRowBatch = 8;
 
 // Moves one row per tree of this wave.  src_row/dst_row are per-lane row pointers (of the lane's own tree).
 // Every lane executes every shuffle (a lane whose column index falls outside the row still serves as a source).
@@ -248,7 +248,7 @@ __device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &
 }
 
 template <int MAXA>
-__global__ void __launch_bounds__(kWave) k_select(Params P, float *parent_hidden, int32_t *last_action,
+__global__ void __launch_bounds__(kWave, 4) k_select(Params P, float *parent_hidden, int32_t *last_action,
                                                   uint8_t *branch, float *mlp_input) {
     __shared__ uint32_t rng_tile[kWave * kRngStride];
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(kWave) k_select(Params P, float *parent_hidden
 }
 
 template <int MAXA, bool FUSE_SELECT>
-__global__ void __launch_bounds__(kWave) k_expand_backup(Params P, const float *hidden, const float *reward,
+__global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params P, const float *hidden, const float *reward,
                                                          const float *policy, const float *value,
                                                          float *parent_hidden, int32_t *last_action, uint8_t *branch,
                                                          float *mlp_input) {
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
     // ---- simulations -------------------------------------------------------------------------------------------------
     for (int s = 0; s < P.sims; s++) {
         if (prof) t0 = __builtin_amdgcn_s_memtime();
-        if (!(P.dbg & 8)) packed = wave_stage_rng_from(P, tree, valid, rng_tile, packed);
+        if (!(P.dbg & 8)) packed = wave_stage_rng_from<4>(P, tree, valid, rng_tile, packed);
         SMZ_STAMP(t_stage)
         Leaf L = {0, 0, 0, 0};
         if (valid) {
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
         atomicAdd(&P.stats[4], t_stage); atomicAdd(&P.stats[5], t_expand);
         atomicAdd(&P.stats[6], t_select); atomicAdd(&P.stats[7], t_mlp);
     }
-    if (P.sims > 0) packed = wave_stage_rng_from(P, tree, valid, rng_tile, packed);   // words for the last expansion
+    if (P.sims > 0) packed = wave_stage_rng_from<4>(P, tree, valid, rng_tile, packed);   // words for the last expansion
     if (valid) {
         if (P.sims > 0) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
