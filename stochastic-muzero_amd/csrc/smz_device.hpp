@@ -37,6 +37,7 @@ struct TreeHdr {          // one 32-byte record per tree
 
 struct Params {
     int32_t B, A, K, S, N, P, sims;
+    int32_t lds_stage;  // 1: stage the twisted words in LDS (small batches); 0: twist ahead only, draw from L1 (occupancy)
     int32_t dbg;        // timing-ablation switches (SMZ_DEBUG_SKIP, diagnostics only; results are then meaningless)
     int32_t tpw;        // trees per wavefront (power of two <= 64): lanes >= tpw only help in the cooperative phases
     int32_t rb_words;   // words in a root block (multiple of 16)

@@ -305,3 +305,17 @@ def test_zero_simulations_and_eval_mode():
     gh.check_fixture_outputs(eng, cfg, data, prior_exact=True)
     eng, cfg, data = gh.drive_fixture("ckpt421_sims25_notrain")
     gh.check_fixture_outputs(eng, cfg, data, prior_exact=True)
+
+
+@pytest.mark.parametrize("env", [dict(SMZ_TREES_PER_WAVE="64"), dict(SMZ_TREES_PER_WAVE="64", SMZ_LDS_STAGE="1"),
+                                 dict(SMZ_TREES_PER_WAVE="1"), dict(SMZ_TREES_PER_WAVE="16", SMZ_LDS_STAGE="0")])
+@pytest.mark.parametrize("name", ["ckpt421_sims50", "lunar_K4_sims30", "wideA11_K9_sims24", "crafted_onehot_policy"])
+def test_launch_geometries_give_identical_trees(name, env, monkeypatch):
+    """Trees per wavefront and the random-word staging mode (LDS tile vs. twist-ahead + L1) are pure scheduling
+    choices: every geometry must reproduce the reference goldens bit for bit."""
+    import gpu_harness as gh
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for fused in (False, True):
+        eng, cfg, data = gh.drive_fixture(name, fused=fused)
+        gh.check_fixture_outputs(eng, cfg, data, prior_exact=False)
