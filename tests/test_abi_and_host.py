@@ -177,3 +177,26 @@ def test_loads_the_reference_checkpoint_files_without_the_reference_source():
     for k, v in got.items():
         assert np.array_equal(v.numpy(), z[k]), k
     assert (m.observation_dimension, m.action_dimension, m.state_dimension) == (4, 2, 31)
+
+
+def test_cli_argv_and_config_surface():
+    """muzero_cli.py: modes and config path by substring (reference muzero_cli.py:13-25), JSON keys of the reference."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import muzero_cli
+    modes, cfg, opts = muzero_cli.parse_argv(["muzero_cli.py", "train", "report", "play", "config/experiment_421_config.json"])
+    assert cfg == "config/experiment_421_config.json"
+    assert modes["train"] and modes["play"] and modes["report"] and not modes["benchmark"]
+    modes, cfg, opts = muzero_cli.parse_argv(["muzero_cli.py", "BENCHMARK", "x/config_a.json", "--envs", "64"])
+    assert modes["benchmark"] and not modes["train"] and opts["envs"] == 64
+    with pytest.raises(Exception):
+        muzero_cli.parse_argv(["muzero_cli.py", "train"])
+    with pytest.raises(Exception):
+        muzero_cli.parse_argv(["muzero_cli.py", "config/a.json"])
+    config = {"monte_carlo_tree_search": {"pb_c_base": 19652, "pb_c_init": 1.25, "discount": 0.999,
+                                          "root_dirichlet_alpha": 0.25, "root_exploration_fraction": 0.1,
+                                          "num_simulations": 11, "maxium_action_sample": 2, "number_of_player": 1,
+                                          "custom_loop": None}}
+    kw = muzero_cli.mcts_kwargs(config)
+    _pkg("mcts").Monte_carlo_tree_search(**kw)
+    assert muzero_cli.mcts_kwargs(config, 2)["num_simulations"] == 2

@@ -235,3 +235,93 @@ def test_single_launch_search_equals_stepwise_search(wname, B, sims, K):
         ra = np.random.RandomState(0); ra.set_state(("MT19937", ka, pa, 0, 0.0))
         rb = np.random.RandomState(0); rb.set_state(("MT19937", kb, pb, 0, 0.0))
         assert np.array_equal(ra.random_sample(700), rb.random_sample(700))
+
+
+def test_module_heads_with_image_shaped_hidden_states_and_action_planes():
+    """The generic five-module path with a vision-shaped family: hidden state [B,3,7,7], action fed as a constant
+    plane (a+1)/A (muzero_model.py:511-522).  Engine and per-tree oracle are fed the SAME module outputs, so every
+    tree must match exactly; this pins the 4-D hidden gather/scatter and the RGB action encoding."""
+    import orc
+    mcts_mod, _, _, _ = _mods()
+    heads_mod = import_module("stochastic-muzero_amd.heads")
+    torch.manual_seed(0)
+    A, S = 3, 9
+
+    class Rep(torch.nn.Module):
+        def __init__(self):
+            super().__init__(); self.c = torch.nn.Conv2d(3, 3, 3, stride=2, padding=1)
+        def forward(self, x):
+            return torch.sigmoid(self.c(x))
+    class Pred(torch.nn.Module):
+        def __init__(self):
+            super().__init__(); self.p = torch.nn.Linear(147, A); self.v = torch.nn.Linear(147, S)
+        def forward(self, h):
+            f = h.flatten(1); return self.p(f), self.v(f)
+    class ADyn(torch.nn.Module):
+        def __init__(self):
+            super().__init__(); self.c = torch.nn.Conv2d(4, 3, 3, padding=1)
+        def forward(self, h, a):
+            return torch.sigmoid(self.c(torch.cat([h, a], 1)))
+    class Dyn(ADyn):
+        def __init__(self):
+            super().__init__(); self.r = torch.nn.Linear(4 * 49, S)
+        def forward(self, h, a):
+            x = torch.cat([h, a], 1); return self.r(x.flatten(1)), torch.sigmoid(self.c(x))
+    heads = heads_mod.ModuleHeads(Rep(), Pred(), Pred(), ADyn(), Dyn(), num_actions=A, support_size=S, device="cuda:0",
+                                  is_rgb=True)
+    B, sims, K = 96, 14, 2
+    obs = torch.rand(B, 3, 14, 14, generator=torch.Generator().manual_seed(1)).cuda()
+    hidden, policy = heads.initial(obs)
+    assert hidden.shape == (B, 147)
+    eng = mcts_mod.SearchEngine(B, A, 147, num_simulations=sims, maxium_action_sample=K, discount=0.99)
+    eng.seed(np.arange(B, dtype=np.uint64))
+    trees = []
+    for i in range(B):
+        t = orc.Tree(orc.make_cfg(A, K, 147, sims, discount=0.99)); t.seed(i); trees.append(t)
+    noise = np.stack([trees[i].root_init(policy[i].cpu().numpy(), hidden=hidden[i].cpu().numpy(), train=True) for i in range(B)])
+    eng.root_init(hidden, policy, train=True, noise_override=torch.from_numpy(noise).cuda())
+    for s in range(sims):
+        eng.select(want_mlp_input=False)
+        torch.cuda.synchronize()
+        exp = [trees[i].select(want_hidden=True) for i in range(B)]
+        assert np.array_equal(eng.last_action.cpu().numpy(), [e[2] for e in exp])
+        assert np.array_equal(eng.parent_hidden.cpu().numpy(), np.stack([e[4] for e in exp]))
+        h2, rw, pol, val = heads.recurrent(eng)
+        torch.cuda.synchronize()
+        a = eng.last_action.long()
+        assert torch.equal(heads.encode_action(a, h2.view(B, 3, 7, 7))[:, 0, 0, 0], (a.float() + 1) / A)
+        for i in range(B):
+            trees[i].expand_backup(pol[i].cpu().numpy(), val[i].item(), reward=rw[i].item(), hidden=h2[i].cpu().numpy())
+        eng.expand_backup(h2, rw, pol, val)
+    visits = eng.root_stats()[0]
+    torch.cuda.synchronize()
+    for i in range(B):
+        assert np.array_equal(visits[i].cpu().numpy(), trees[i].root_stats()[0])
+
+
+def test_cli_play_from_reference_layout_checkpoint(tmp_path):
+    """muzero_cli.py play: config JSON with the reference's keys + checkpoint files in the reference's layout."""
+    import json, sys
+    _, model_mod, _, _ = _mods()
+    model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_ckpt421.npz")).save_model(str(tmp_path), tag=421)
+    cfg = {"game": {"env": "CartPole-v1", "render": None}, "random_seed": {"np_random_seed": 0, "torch_manual_seed": 0, "env_seed": 0},
+           "muzero": {"model_structure": "mlp_model", "state_space_dimensions": 31, "hidden_layer_dimensions": 64,
+                      "number_of_hidden_layer": 0, "load": True},
+           "monte_carlo_tree_search": {"pb_c_base": 19652, "pb_c_init": 1.25, "discount": 0.999, "root_dirichlet_alpha": 0.25,
+                                       "root_exploration_fraction": 0.1, "num_simulations": 11, "maxium_action_sample": 2,
+                                       "number_of_player": 1, "custom_loop": None},
+           "gameplay": {"limit_of_game_play": 500},
+           "learning_cycle": {"number_of_iteration": 100, "number_of_self_play_before_training": 1,
+                              "temperature_type": "linear_decrease_temperature", "model_tag_number": 421, "verbose": False},
+           "play_game_from_checkpoint": {"model_tag": 421, "model_device": "cpu", "mcts_with_or_without_dirichlet_noise": True,
+                                         "temperature": 0, "game_iter": 40, "verbose": False}}
+    path = tmp_path / "experiment_421_config.json"
+    path.write_text(json.dumps(cfg))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import muzero_cli
+    out = muzero_cli.main(["muzero_cli.py", "play", str(path), "--envs", "64", "--checkpoint-dir", str(tmp_path)])
+    assert out["play"]["games"] == 64 and out["play"]["steps"] == 40
+    assert out["play"]["mean_reward"] > 30        # the trained checkpoint keeps the pole up for most of 40 steps
+    out = muzero_cli.main(["muzero_cli.py", "train", str(path), "--envs", "32", "--iterations", "2", "--steps", "12",
+                           "--checkpoint-dir", str(tmp_path)])
+    assert out["train"]["games"] == 64 and len(out["train"]["rewards"]) == 2
