@@ -153,7 +153,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    sp.play_games_grouped(groups, args.temperature, args.warmup)                          # W untimed warm-up steps
+    chunks = sp.play_games_grouped(groups, args.temperature, args.warmup)                 # W untimed warm-up steps
+    if world > 1:      # the first grouped send/recv builds the RCCL communicators: keep that out of the timed region
+        gather_mod.gather_to_learner(torch.cat([c.data[:max(1, args.warmup)] for c in chunks], dim=1))
     barrier()
     t0 = time.perf_counter()
     chunks = sp.play_games_grouped(groups, args.temperature, args.steps)                  # EXACTLY K timed steps
