@@ -50,7 +50,7 @@ struct Params {
     uint32_t *nodes;        // [B][tree_words]
     float *hidden;          // [B][N][S]
     TreeHdr *hdr;           // [B]
-    int32_t *path;          // [B][P]   entries (block << 8) | slot, block 0 = root block, e + 1 = expansion e
+    uint4 *path;            // [B][P]   records (block << 8 | slot, visit, value_sum, reward); block 0 = root block
     uint32_t *mt;           // [B][624]
     int32_t *rng_pos;       // [B]  (ready << 16) | idx
     const double *pbc_sqrt; // [sims+2]  sqrt(n) * pb_c(n)
@@ -96,7 +96,7 @@ struct Rng {
     }
     __device__ int pack() const { return (ready << 16) | idx; }
     __device__ uint32_t next32() {
-        if (used < staged) {              // fast path: word was twisted and tempered by the staging pass
+        if (__builtin_expect(used < staged, 1)) {   // fast path: word was twisted and tempered by the staging pass
             const uint32_t y = stage[used++];
             --ready;
             idx = (idx + 1 == kMtN) ? 0 : idx + 1;
@@ -267,100 +267,156 @@ __device__ inline void root_init_tree(const Params &P, int tree, Rng &rng, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// selection (monte_carlo_tree_search.py:228-267): one block load per level, everything else in registers / LDS
+// selection (monte_carlo_tree_search.py:228-267): one block load per level, everything else in registers / LDS.
+// KS = 2 compiles the expansion-block code for exactly two children (maxium_action_sample's default, every reference
+// config): the block is three 16-byte loads at fixed offsets and no lane carries per-child predicates; KS = 0 is the
+// general run-time child count (<= MAXA).  The root level (A children, float64 priors) is peeled off the loop.
+// Every level appends one record (block << 8 | slot, visit, value_sum, reward of the chosen child) to `rec` (LDS in
+// the single-launch kernel, global otherwise), so the backup that follows needs no loads from the tree.
 // ---------------------------------------------------------------------------------------------------------------
 struct Leaf {
     int32_t leaf_id, parent_id, action, branch;
 };
 
-// `path` receives the (block << 8 | slot) entries; when `pathvals` is given (LDS, one uint4 per level) the chosen
-// child's visit count, value sum and reward are recorded too, so that the backup needs no loads at all.
-// LDSPATH = false: entries go to `path` (global).  LDSPATH = true: `path` is ignored, records go to `pathvals`.
-template <int MAXA, bool LDSPATH = false>
+template <int N>
+struct Kids {
+    int32_t vis[N], chd[N], act[N];
+    float vsum[N], rew[N], pri[N];
+    double pri64[N];
+};
+
+// run-time child count: predicated dword loads
+template <int N>
+__device__ inline void load_kids_dyn(const uint32_t *bp, int cnt, bool root, int rp_off, Kids<N> &k) {
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (j < cnt) {
+            k.vis[j] = (int32_t)bp[j];
+            k.vsum[j] = __uint_as_float(bp[cnt + j]);
+            k.rew[j] = __uint_as_float(bp[2 * cnt + j]);
+            k.pri[j] = __uint_as_float(bp[3 * cnt + j]);
+            k.chd[j] = (int32_t)bp[4 * cnt + j];
+            k.act[j] = root ? j : (int32_t)bp[5 * cnt + j];
+            k.pri64[j] = root ? ((const double *)(bp + rp_off))[j] : (double)k.pri[j];
+        } else {
+            k.vis[j] = 0; k.chd[j] = 0; k.act[j] = 0; k.vsum[j] = 0.f; k.rew[j] = 0.f; k.pri[j] = 0.f; k.pri64[j] = 0.0;
+        }
+    }
+}
+
+// exactly N children in an expansion block: 6N words as 16-byte loads (blocks are 64-byte aligned and padded)
+template <int N>
+__device__ inline void load_kids_static(const uint32_t *bp, Kids<N> &k) {
+    constexpr int NV = (6 * N + 3) / 4;
+    uint32_t w[NV * 4];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const uint4 q = reinterpret_cast<const uint4 *>(bp)[v];
+        w[4 * v] = q.x; w[4 * v + 1] = q.y; w[4 * v + 2] = q.z; w[4 * v + 3] = q.w;
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        k.vis[j] = (int32_t)w[j];
+        k.vsum[j] = __uint_as_float(w[N + j]);
+        k.rew[j] = __uint_as_float(w[2 * N + j]);
+        k.pri[j] = __uint_as_float(w[3 * N + j]);
+        k.chd[j] = (int32_t)w[4 * N + j];
+        k.act[j] = (int32_t)w[5 * N + j];
+        k.pri64[j] = (double)k.pri[j];
+    }
+}
+
+// chance-flagged node: sample an outcome from the smoothed priors (mcts:247-255)
+template <int N>
+__device__ inline int pick_chance(const Kids<N> &k, int cnt, Rng &rng) {
+    float tmp[N];
+    double q64[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { const float om = 1.0f - k.pri[j]; tmp[j] = om + 1e-12f; }
+    const float s = np_sum<float, N>(tmp, cnt);
+    const float r = fabsf((float)((double)s / (double)cnt));
+#pragma unroll
+    for (int j = 0; j < N; j++) tmp[j] = k.pri[j] + r;
+    const float qs = np_sum<float, N>(tmp, cnt);
+#pragma unroll
+    for (int j = 0; j < N; j++) q64[j] = (double)(tmp[j] / qs);
+    return sample_cdf<N>(q64, cnt, rng.random_sample());
+}
+
+// decision-flagged node: pUCT argmax (mcts:235-243, 257-259)
+template <int N>
+__device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool norm, float mn, float span, float disc32,
+                                    Rng &rng) {
+    double best = 0.0;
+    int pick = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (j < cnt) {
+            const int Nc = k.vis[j];
+            const double prior_score = (sp * k.pri64[j]) / (double)(Nc + 1);
+            double value_score = 0.0;
+            if (Nc > 0) {
+                const float qv = k.vsum[j] / (float)Nc;
+                const float dv = disc32 * qv;
+                float x = k.rew[j] + dv;
+                if (norm) { const float num = x - mn; x = num / span; }
+                value_score = (double)x;
+            }
+            const double jitter = 1e-7 + (2e-7 - 1e-7) * rng.random_sample();
+            const double score = (prior_score + value_score) + jitter;
+            if (j == 0 || score >= best) { best = score; pick = j; }  // exact tie -> larger action
+        }
+    }
+    return pick;
+}
+
+template <int MAXA, int KS>
 __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const TreeHdr &h, const double *pbc_sqrt,
                                    int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children,
-                                   int32_t *path, uint4 *pathvals) {
+                                   uint4 *rec) {
+    constexpr int NK = KS > 0 ? KS : MAXA;     // register arrays of the expansion levels
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
     const float mn = h.mn, mx = h.mx;
     const bool norm = mx > mn;
     const float span = mx - mn;
-    int blk = 0, depth = 0, cur_visit = h.root_visit;
-    int leaf_id = 0, parent_id = 0, action = 0;
-    for (;;) {
-        const int cnt = (blk == 0) ? A : K;
-        const uint32_t *bp = block_ptr(P, tb, blk);
-        // the whole child block: independent loads, one latency
-        int32_t vis[MAXA], chd[MAXA], act[MAXA];
-        float vsum[MAXA], rew[MAXA], pri[MAXA];
-        double pri64[MAXA];
+    int depth = 0, cur_visit = h.root_visit, action = 0, leaf_id = 0, parent_id = 0, c = 0;
+    {   // ---- root level: decision-flagged, A children, float64 priors ----------------------------------------------
+        Kids<MAXA> k;
+        load_kids_dyn<MAXA>(tb, A, true, P.rp_off, k);
+        const int pick = pick_decision<MAXA>(k, A, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng);
+        n_dec++;
+        n_children += (unsigned)A;
+        float pv = 0.f, pr = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXA; j++) {
-            if (j < cnt) {
-                vis[j] = (int32_t)bp[j];
-                vsum[j] = __uint_as_float(bp[cnt + j]);
-                rew[j] = __uint_as_float(bp[2 * cnt + j]);
-                pri[j] = __uint_as_float(bp[3 * cnt + j]);
-                chd[j] = (int32_t)bp[4 * cnt + j];
-                act[j] = (blk == 0) ? j : (int32_t)bp[5 * cnt + j];
-                pri64[j] = (blk == 0) ? ((const double *)(bp + P.rp_off))[j] : (double)pri[j];
-            } else {
-                vis[j] = 0; chd[j] = 0; act[j] = 0; vsum[j] = 0.f; rew[j] = 0.f; pri[j] = 0.f; pri64[j] = 0.0;
-            }
-        }
-        int pick = 0;
+        for (int j = 0; j < MAXA; j++) if (j == pick) { c = k.chd[j]; cur_visit = k.vis[j]; action = j; pv = k.vsum[j]; pr = k.rew[j]; }
+        rec[0] = make_uint4((uint32_t)pick, (uint32_t)cur_visit, __float_as_uint(pv), __float_as_uint(pr));
+        leaf_id = 1 + pick;
+        depth = 1;
+    }
+    while (c != 0) {
+        const int blk = c;
+        const uint32_t *bp = tb + P.rb_words + (size_t)(blk - 1) * P.eb_words;
+        Kids<NK> k;
+        if (KS > 0) load_kids_static<NK>(bp, k);
+        else load_kids_dyn<NK>(bp, K, false, 0, k);
+        const int cnt = KS > 0 ? KS : K;
+        int pick;
         if (depth_flag(depth)) {
-            // chance-flagged: sample an outcome from the smoothed priors (mcts:247-255)
-            float tmp[MAXA];
-            double q64[MAXA];
-#pragma unroll
-            for (int j = 0; j < MAXA; j++) { const float om = 1.0f - pri[j]; tmp[j] = om + 1e-12f; }
-            const float s = np_sum<float, MAXA>(tmp, cnt);
-            const float r = fabsf((float)((double)s / (double)cnt));
-#pragma unroll
-            for (int j = 0; j < MAXA; j++) tmp[j] = pri[j] + r;
-            const float qs = np_sum<float, MAXA>(tmp, cnt);
-#pragma unroll
-            for (int j = 0; j < MAXA; j++) q64[j] = (double)(tmp[j] / qs);
-            pick = sample_cdf<MAXA>(q64, cnt, rng.random_sample());
+            pick = pick_chance<NK>(k, cnt, rng);
             n_chance++;
         } else {
-            // decision-flagged: pUCT argmax (mcts:235-243, 257-259)
-            const double sp = pbc_sqrt[cur_visit];
-            double best = 0.0;
-#pragma unroll
-            for (int j = 0; j < MAXA; j++) {
-                if (j < cnt) {
-                    const int Nc = vis[j];
-                    const double prior_score = (sp * pri64[j]) / (double)(Nc + 1);
-                    double value_score = 0.0;
-                    if (Nc > 0) {
-                        const float qv = vsum[j] / (float)Nc;
-                        const float dv = P.disc32 * qv;
-                        float x = rew[j] + dv;
-                        if (norm) { const float num = x - mn; x = num / span; }
-                        value_score = (double)x;
-                    }
-                    const double jitter = 1e-7 + (2e-7 - 1e-7) * rng.random_sample();
-                    const double score = (prior_score + value_score) + jitter;
-                    if (j == 0 || score >= best) { best = score; pick = j; }  // exact tie -> larger action
-                }
-            }
+            pick = pick_decision<NK>(k, cnt, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng);
             n_dec++;
             n_children += (unsigned)cnt;
         }
-        int c = 0;
         float pv = 0.f, pr = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXA; j++) if (j == pick) { c = chd[j]; cur_visit = vis[j]; action = act[j]; pv = vsum[j]; pr = rew[j]; }
-        const int loc = (blk << 8) | pick;
-        if (!LDSPATH) path[depth] = loc;
-        else pathvals[depth] = make_uint4((uint32_t)loc, (uint32_t)cur_visit, __float_as_uint(pv), __float_as_uint(pr));
+        for (int j = 0; j < NK; j++) if (j == pick) { c = k.chd[j]; cur_visit = k.vis[j]; action = k.act[j]; pv = k.vsum[j]; pr = k.rew[j]; }
+        rec[depth] = make_uint4((uint32_t)((blk << 8) | pick), (uint32_t)cur_visit, __float_as_uint(pv), __float_as_uint(pr));
         parent_id = leaf_id;
-        leaf_id = loc_node_id(P, loc);
+        leaf_id = 1 + A + (blk - 1) * K + pick;
         depth++;
-        if (c == 0) break;
-        blk = c;
     }
     path_len_out = depth;
     Leaf L;
@@ -373,17 +429,18 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
 
 // ---------------------------------------------------------------------------------------------------------------
 // expansion + backup (monte_carlo_tree_search.py:289-308); the leaf's hidden row is stored by the caller.
-// Returns the leaf's node id.
+// The path records of the preceding select carry every visited node's (visit, value_sum, reward): the backup only
+// STORES into the tree.  Returns the leaf's node id.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAXA, bool LDSPATH = false>
+template <int MAXA, int KS>
 __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, TreeHdr &h, const float *policy_row,
-                                         float reward, float value, const int32_t *path, const uint4 *pathvals) {
-    constexpr int CH = 8;   // path nodes gathered per round trip
+                                         float reward, float value, const uint4 *rec) {
+    constexpr int CH = 8;   // path records fetched per round trip
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
     const int len = h.path_len;
-    // ---- gather the path (independent loads) -------------------------------------------------------------------
-    const int leaf_loc = LDSPATH ? (int)pathvals[len - 1].x : path[len - 1];
+    const uint4 leaf_rec = rec[len - 1];
+    const int leaf_loc = (int)leaf_rec.x;
     const int pflag = depth_flag(len - 1);       // flag of the leaf's parent (depth len-1; root is depth 0)
     // ---- expansion ---------------------------------------------------------------------------------------------
     float p[MAXA], pol[MAXA];
@@ -402,16 +459,25 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, Tr
     const int e = h.n_exp;
     h.n_exp = e + 1;
     {
-        uint32_t *nb = block_ptr(P, tb, e + 1);
-        for (int j = 0; j < K; j++) {
-            nb[j] = 0u;                                  // visit
-            nb[K + j] = __float_as_uint(0.f);            // value_sum
-            nb[2 * K + j] = __float_as_uint(0.f);        // reward
-            float pj = 0.f;
-            for (int a = 0; a < A; a++) if (a == picks[j]) pj = p[a];
-            nb[3 * K + j] = __float_as_uint(pj);         // prior = un-renormalised p[a]
-            nb[4 * K + j] = 0u;                          // child
-            nb[5 * K + j] = (uint32_t)picks[j];          // action
+        uint32_t *nb = tb + P.rb_words + (size_t)e * P.eb_words;
+        if (KS == 2) {   // 12 words at fixed offsets: three 16-byte stores
+            float pj[2] = {0.f, 0.f};
+            for (int a = 0; a < A; a++) { if (a == picks[0]) pj[0] = p[a]; if (a == picks[1]) pj[1] = p[a]; }
+            uint4 *nb4 = reinterpret_cast<uint4 *>(nb);
+            nb4[0] = make_uint4(0u, 0u, 0u, 0u);                                              // visit, value_sum
+            nb4[1] = make_uint4(0u, 0u, __float_as_uint(pj[0]), __float_as_uint(pj[1]));      // reward, prior
+            nb4[2] = make_uint4(0u, 0u, (uint32_t)picks[0], (uint32_t)picks[1]);              // child, action
+        } else {
+            for (int j = 0; j < K; j++) {
+                nb[j] = 0u;                                  // visit
+                nb[K + j] = __float_as_uint(0.f);            // value_sum
+                nb[2 * K + j] = __float_as_uint(0.f);        // reward
+                float pj = 0.f;
+                for (int a = 0; a < A; a++) if (a == picks[j]) pj = p[a];
+                nb[3 * K + j] = __float_as_uint(pj);         // prior = un-renormalised p[a]
+                nb[4 * K + j] = 0u;                          // child
+                nb[5 * K + j] = (uint32_t)picks[j];          // action
+            }
         }
     }
     const float leaf_reward = pflag ? reward : 0.0f;     // the afterstate branch never assigns one (mcts:338-342)
@@ -422,57 +488,25 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, Tr
         lp[4 * lc + ls] = (uint32_t)(e + 1);             // leaf.children now live in expansion e
         lp[2 * lc + ls] = __float_as_uint(leaf_reward);
     }
-    // ---- backup, leaf -> root, CH nodes per round trip ------------------------------------------------------------
+    // ---- backup, leaf -> root: stores only -----------------------------------------------------------------------
     float v = value;
     float mn = h.mn, mx = h.mx;
-    if (LDSPATH) {
-        // the select that recorded this path also recorded each node's (visit, value_sum, reward): stores only
-        for (int i = len - 1; i >= 0; i--) {
-            const uint4 e = pathvals[i];
-            const int b = (int)e.x >> 8, sl = (int)e.x & 0xff;
-            const int cnt = (b == 0) ? A : K;
-            uint32_t *np = block_ptr(P, tb, b) + sl;
-            const float r = (i == len - 1) ? leaf_reward : __uint_as_float(e.w);
-            const float nvs = __uint_as_float(e.z) + v;
-            const int nvc = (int)e.y + 1;
-            np[0] = (uint32_t)nvc;
-            np[cnt] = __float_as_uint(nvs);
-            const float qv = nvs / (float)nvc;
-            if (qv > mx) mx = qv;
-            if (qv < mn) mn = qv;
-            const float dv = P.disc32 * v;
-            v = r + dv;
-        }
-    } else
     for (int i0 = len - 1; i0 >= 0; i0 -= CH) {
-        int locs[CH];
-        uint32_t *np_[CH];
-        int cnts[CH];
-        int32_t vi[CH];
-        float vs[CH], rw[CH];
+        uint4 r4[CH];
 #pragma unroll
-        for (int c = 0; c < CH; c++) locs[c] = (i0 - c >= 0) ? path[i0 - c] : 0;
+        for (int q = 0; q < CH; q++) r4[q] = (i0 - q >= 0) ? rec[i0 - q] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const int b = locs[c] >> 8, s = locs[c] & 0xff;
-            cnts[c] = (b == 0) ? A : K;
-            np_[c] = block_ptr(P, tb, b) + s;
-            if (i0 - c >= 0) {
-                vi[c] = (int32_t)np_[c][0];
-                vs[c] = __uint_as_float(np_[c][cnts[c]]);
-                rw[c] = __uint_as_float(np_[c][2 * cnts[c]]);
-            } else {
-                vi[c] = 0; vs[c] = 0.f; rw[c] = 0.f;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-            if (i0 - c >= 0) {
-                const float r = (i0 - c == len - 1) ? leaf_reward : rw[c];
-                const float nvs = vs[c] + v;
-                const int nvc = vi[c] + 1;
-                np_[c][0] = (uint32_t)nvc;
-                np_[c][cnts[c]] = __float_as_uint(nvs);
+        for (int q = 0; q < CH; q++) {
+            if (i0 - q >= 0) {
+                const uint4 e4 = r4[q];
+                const int b = (int)e4.x >> 8, sl = (int)e4.x & 0xff;
+                const int cnt = (b == 0) ? A : K;
+                uint32_t *np = block_ptr(P, tb, b) + sl;
+                const float r = (i0 - q == len - 1) ? leaf_reward : __uint_as_float(e4.w);
+                const float nvs = __uint_as_float(e4.z) + v;
+                const int nvc = (int)e4.y + 1;
+                np[0] = (uint32_t)nvc;
+                np[cnt] = __float_as_uint(nvs);
                 const float qv = nvs / (float)nvc;
                 if (qv > mx) mx = qv;
                 if (qv < mn) mn = qv;

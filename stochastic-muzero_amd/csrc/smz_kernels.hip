@@ -236,15 +236,14 @@ __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidd
     }
 }
 
-template <int MAXA>
+template <int MAXA, int KS>
 __device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &rng, TreeHdr &h, const double *pbc_lds,
                                     float *parent_hidden, int32_t *last_action, uint8_t *branch, float *mlp_input) {
     Leaf L = {0, 0, 0, 0};
     unsigned n_dec = 0, n_chance = 0, n_children = 0;
     if (valid) {
         int len = 0;
-        L = select_tree<MAXA, false>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, P.path + (size_t)tree * P.P,
-                                    (uint4 *)nullptr);
+        L = select_tree<MAXA, KS>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, P.path + (size_t)tree * P.P);
         h.path_len = len;
         if (last_action) last_action[tree] = L.action;
         if (branch) branch[tree] = (uint8_t)L.branch;
@@ -254,7 +253,7 @@ __device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &
     wave_add_stats(P.stats, n_dec, n_chance, valid ? 1u : 0u, n_children);
 }
 
-template <int MAXA>
+template <int MAXA, int KS>
 __global__ void __launch_bounds__(kWave, 4) k_select(Params P, float *parent_hidden, int32_t *last_action,
                                                   uint8_t *branch, float *mlp_input) {
     uint32_t *rng_tile = rng_tile_ptr(P);
@@ -269,14 +268,14 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params P, float *parent_hid
         rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + threadIdx.x * kRngStride, n_staged);
         h = P.hdr[tree];
     }
-    select_phase<MAXA>(P, tree, valid, rng, h, pbc_lds, parent_hidden, last_action, branch, mlp_input);
+    select_phase<MAXA, KS>(P, tree, valid, rng, h, pbc_lds, parent_hidden, last_action, branch, mlp_input);
     if (valid) {
         P.rng_pos[tree] = rng.pack();
         P.hdr[tree] = h;
     }
 }
 
-template <int MAXA, bool FUSE_SELECT>
+template <int MAXA, int KS, bool FUSE_SELECT>
 __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params P, const float *hidden, const float *reward,
                                                          const float *policy, const float *value,
                                                          float *parent_hidden, int32_t *last_action, uint8_t *branch,
@@ -293,8 +292,8 @@ __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params P, const floa
     if (valid) {
         rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + threadIdx.x * kRngStride, n_staged);
         h = P.hdr[tree];
-        leaf = expand_backup_tree<MAXA>(P, tree, rng, h, policy + (size_t)tree * P.A, reward ? reward[tree] : 0.0f,
-                                        value[tree], P.path + (size_t)tree * P.P, (const uint4 *)nullptr);
+        leaf = expand_backup_tree<MAXA, KS>(P, tree, rng, h, policy + (size_t)tree * P.A, reward ? reward[tree] : 0.0f,
+                                            value[tree], P.path + (size_t)tree * P.P);
     }
     if (P.S > 0 && hidden) {
         const int t = valid ? tree : 0;
@@ -303,7 +302,7 @@ __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params P, const floa
     if (FUSE_SELECT) {
         // the leaf rows just written by other lanes of this wave may be the next parent rows
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        select_phase<MAXA>(P, tree, valid, rng, h, pbc_lds, parent_hidden, last_action, branch, mlp_input);
+        select_phase<MAXA, KS>(P, tree, valid, rng, h, pbc_lds, parent_hidden, last_action, branch, mlp_input);
     }
     if (valid) {
         P.rng_pos[tree] = rng.pack();
@@ -339,7 +338,7 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
     return m;
 }
 
-template <int MAXA, int U>
+template <int MAXA, int KS, int U>
 __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train) {
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
@@ -392,15 +391,14 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
         Leaf L = {0, 0, 0, 0};
         if (valid) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            if (s > 0 && !(P.dbg & 4)) expand_backup_tree<MAXA, true>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
-                                                outs[lane * slot + A], P.path, pvals + lane * P.P);
+            if (s > 0 && !(P.dbg & 4)) expand_backup_tree<MAXA, KS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
+                                                outs[lane * slot + A], pvals + lane * P.P);
         }
         SMZ_STAMP(t_expand)
         if (valid) {
             int len = 0;
             if (P.dbg & 2) { L.leaf_id = 1; L.parent_id = 0; L.action = 0; L.branch = 0; len = 1; }
-            else L = select_tree<MAXA, true>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, P.path,
-                                             pvals + lane * P.P);
+            else L = select_tree<MAXA, KS>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
             h.path_len = len;
             n_desc++;
             packed = rng.pack();
@@ -453,10 +451,10 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
     if (valid) {
         if (P.sims > 0) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            expand_backup_tree<MAXA, true>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
-                                           P.path, pvals + lane * P.P);
+            expand_backup_tree<MAXA, KS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
+                                         pvals + lane * P.P);
             // leave the last path where the step-wise entry points and the debug dump expect it
-            for (int i = 0; i < h.path_len; i++) P.path[(size_t)tree * P.P + i] = (int32_t)pvals[lane * P.P + i].x;
+            for (int i = 0; i < h.path_len; i++) P.path[(size_t)tree * P.P + i] = pvals[lane * P.P + i];
             packed = rng.pack();
         }
         P.rng_pos[tree] = packed;
@@ -722,14 +720,18 @@ int launch_check() {
 }
 
 // dispatch on the per-lane scratch bucket (smallest MAXA >= A)
-#define SMZ_DISPATCH(maxa, CALL)              \
+#define SMZ_DISPATCH(maxa, ...)               \
     switch (maxa) {                           \
-        case 2: { constexpr int MA = 2; CALL; } break;   \
-        case 4: { constexpr int MA = 4; CALL; } break;   \
-        case 8: { constexpr int MA = 8; CALL; } break;   \
-        case 16: { constexpr int MA = 16; CALL; } break; \
-        default: { constexpr int MA = 32; CALL; } break; \
+        case 2: { constexpr int MA = 2; __VA_ARGS__; } break;   \
+        case 4: { constexpr int MA = 4; __VA_ARGS__; } break;   \
+        case 8: { constexpr int MA = 8; __VA_ARGS__; } break;   \
+        case 16: { constexpr int MA = 16; __VA_ARGS__; } break; \
+        default: { constexpr int MA = 32; __VA_ARGS__; } break; \
     }
+// ... and on the children-per-expansion specialisation (KS = 2: the static two-child code, 0: run-time count)
+#define SMZ_DISPATCH2(maxa, k, ...)                                          \
+    if ((k) == 2) { constexpr int KS = 2; SMZ_DISPATCH(maxa, __VA_ARGS__); }  \
+    else { constexpr int KS = 0; SMZ_DISPATCH(maxa, __VA_ARGS__); }
 
 }  // namespace
 
@@ -970,7 +972,7 @@ int smz_select(smz_handle *h, float *parent_hidden_dev, int32_t *last_action_dev
     if (!h) return fail(SMZ_ERR_INVALID, "smz_select: null handle%s");
     if (!h->root_ready) return fail(SMZ_ERR_STATE, "smz_select before smz_root_init%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_select<MA>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P), (hipStream_t)stream, h->P,
+    SMZ_DISPATCH2(h->maxa, h->K, hipLaunchKernelGGL((k_select<MA, KS>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P), (hipStream_t)stream, h->P,
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
     h->selected = true;
     return launch_check();
@@ -981,7 +983,7 @@ int smz_expand_backup(smz_handle *h, const float *hidden_dev, const float *rewar
     if (!h || !policy_dev || !value_dev) return fail(SMZ_ERR_INVALID, "smz_expand_backup: null argument%s");
     if (!h->selected) return fail(SMZ_ERR_STATE, "smz_expand_backup without a preceding smz_select%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, false>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
+    SMZ_DISPATCH2(h->maxa, h->K, hipLaunchKernelGGL((k_expand_backup<MA, KS, false>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
                                              (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev,
                                              (float *)nullptr, (int32_t *)nullptr, (uint8_t *)nullptr, (float *)nullptr));
     h->selected = false;
@@ -994,7 +996,7 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
     if (!h || !policy_dev || !value_dev) return fail(SMZ_ERR_INVALID, "smz_expand_backup_select: null argument%s");
     if (!h->selected) return fail(SMZ_ERR_STATE, "smz_expand_backup_select without a preceding smz_select%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH(h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, true>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
+    SMZ_DISPATCH2(h->maxa, h->K, hipLaunchKernelGGL((k_expand_backup<MA, KS, true>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
                                              (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev,
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
     return launch_check();
@@ -1023,11 +1025,11 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     if (lds > 160 * 1024) return fail(SMZ_ERR_INVALID, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
 #define SMZ_LAUNCH_SEARCH(UU)                                                                                          \
-    SMZ_DISPATCH(h->maxa, {                                                                                            \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, UU>),                                  \
+    SMZ_DISPATCH2(h->maxa, h->K, {                                                                                     \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU>),                              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                   \
             return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                                \
-        hipLaunchKernelGGL((k_search_mlp<MA, UU>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream, P,   \
+        hipLaunchKernelGGL((k_search_mlp<MA, KS, UU>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream, P, \
                            *desc, weights_dev, obs_dev, train);                                                        \
     })
     if (desc->OP == kWave) { SMZ_LAUNCH_SEARCH(1); } else { SMZ_LAUNCH_SEARCH(2); }
@@ -1167,11 +1169,11 @@ int smz_debug_dump_tree(smz_handle *h, int tree, smz_node_view *nodes, int cap, 
     const int plen = hdr.path_len > 0 ? hdr.path_len + 1 : 0;
     if (path_len_out) *path_len_out = plen;
     if (path_out && cap_path > 0 && plen > 0) {
-        std::vector<int32_t> locs((size_t)hdr.path_len);
-        HIP_TRY(hipMemcpy(locs.data(), P.path + (size_t)tree * P.P, (size_t)hdr.path_len * 4, hipMemcpyDeviceToHost));
+        std::vector<uint4> recs((size_t)hdr.path_len);
+        HIP_TRY(hipMemcpy(recs.data(), P.path + (size_t)tree * P.P, (size_t)hdr.path_len * sizeof(uint4), hipMemcpyDeviceToHost));
         path_out[0] = 0;
         for (int i = 0; i < hdr.path_len && i + 1 < cap_path; i++) {
-            const int blk = locs[i] >> 8, slot = locs[i] & 0xff;
+            const int blk = (int)recs[i].x >> 8, slot = (int)recs[i].x & 0xff;
             path_out[i + 1] = blk == 0 ? 1 + slot : 1 + A + (blk - 1) * K + slot;
         }
     }

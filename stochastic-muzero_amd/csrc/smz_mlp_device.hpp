@@ -20,17 +20,24 @@ enum { M_DYN_IN, M_ADY_IN, M_DYN_MID, M_ADY_MID, M_DYN_OUT, M_ADY_OUT, M_PRE_IN,
 __host__ __device__ inline int up4(int x) { return (x + 3) & ~3; }
 
 // acc[r][u] = bias_r[o] + sum_k W_r[k][o] * act_r[k]  for o = lane + 64 u, for R rows at once (each row may use a
-// different matrix: its branch's).  k ascends into one accumulator per output, so every caller rounds identically.
-// Four 4-wide steps per iteration with all their 16-byte LDS reads issued back to back, and the R rows' dependent FMA
-// chains interleaved: one LDS latency covers 16 inputs of every row (the plain loop is a chain of exposed round trips).
+// different matrix: its branch's).  Even and odd inputs accumulate in the two halves of a packed register
+// (v_pk_fma_f32: two FMAs per instruction) and are added at the end; the order is fixed, so every caller rounds
+// identically.  Four 4-wide steps per iteration with all their 16-byte LDS reads issued back to back: one LDS latency
+// covers 16 inputs (the plain loop is a chain of exposed LDS round trips).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ inline v2f pk_fma(float wx, float wy, float ax, float ay, v2f c) {
+    v2f w = {wx, wy}, a = {ax, ay};
+    return __builtin_elementwise_fma(w, a, c);
+}
 template <int U, int R>
 __device__ inline void dense(const float *const (&W)[R], const float *const (&bias)[R], const float *const (&act)[R], int K4,
                              int OP, int lane, float (&acc)[R][U]) {
     const float4 *a4[R], *w4[R];
+    v2f acc2[R][U];
 #pragma unroll
     for (int r = 0; r < R; r++) {
 #pragma unroll
-        for (int u = 0; u < U; u++) acc[r][u] = bias[r][lane + kWave * u];
+        for (int u = 0; u < U; u++) { acc2[r][u].x = bias[r][lane + kWave * u]; acc2[r][u].y = 0.f; }
         a4[r] = reinterpret_cast<const float4 *>(act[r]);
         w4[r] = reinterpret_cast<const float4 *>(W[r]) + lane;
     }
@@ -53,12 +60,10 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
             for (int r = 0; r < R; r++) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    float t = acc[r][u];
-                    t = fmaf(w[r][u][j].x, a[r][j].x, t);
-                    t = fmaf(w[r][u][j].y, a[r][j].y, t);
-                    t = fmaf(w[r][u][j].z, a[r][j].z, t);
-                    t = fmaf(w[r][u][j].w, a[r][j].w, t);
-                    acc[r][u] = t;
+                    v2f t = acc2[r][u];
+                    t = pk_fma(w[r][u][j].x, w[r][u][j].y, a[r][j].x, a[r][j].y, t);
+                    t = pk_fma(w[r][u][j].z, w[r][u][j].w, a[r][j].z, a[r][j].w, t);
+                    acc2[r][u] = t;
                 }
             }
         }
@@ -70,12 +75,17 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const float4 wv = w4[r][(size_t)q * OP + kWave * u];
-                float t = acc[r][u];
-                t = fmaf(wv.x, av.x, t); t = fmaf(wv.y, av.y, t); t = fmaf(wv.z, av.z, t); t = fmaf(wv.w, av.w, t);
-                acc[r][u] = t;
+                v2f t = acc2[r][u];
+                t = pk_fma(wv.x, wv.y, av.x, av.y, t);
+                t = pk_fma(wv.z, wv.w, av.z, av.w, t);
+                acc2[r][u] = t;
             }
         }
     }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int u = 0; u < U; u++) acc[r][u] = acc2[r][u].x + acc2[r][u].y;
 }
 
 // torch's ELU evaluates exp(x) - 1 (aten/src/ATen/native/cpu/Activation.cpp elu_kernel)

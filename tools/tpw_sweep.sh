@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
-for st in 0 1; do echo "== lds_stage $st"; for n in 65536 1048576; do SMZ_LDS_STAGE=$st python bench.py --envs $n --steps 2 --warmup 1 --no-cpu-baseline --heads hip 2>/dev/null | python3 -c "
+SMZ_DEBUG_SKIP=16 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --heads hip 2>&1 | grep "phase cycles" | tail -1
+for i in 1 2; do python bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); r=d['roofline']; t=r['tree_kernel_alone']
-print(dict(envs=d['config']['envs_per_gpu'], Msims=round(d['value']/1e6,1), tree_us=round(t['mean_launch_us'],1), tree_GBs=round(t['achieved'],1), tree_frac=round(t['frac'],4)))"; done; done
+d=json.loads(sys.stdin.read()); print('4096x50:', round(d['value']/1e6,2),'M sims/s', round(d['ms_per_step'],3))"; done
