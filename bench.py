@@ -57,9 +57,17 @@ def cpu_baseline(wl, weights_path, seconds_target=15.0):
     """The CPU oracle on all host cores, on a bounded sample of the same workload (about 10-30 s of CPU work)."""
     import orc
     w = orc.MlpWeights.from_npz(weights_path)
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))               # cores this process may actually run on
+    except AttributeError:
+        cores = os.cpu_count() or 1
     cfg = orc.make_cfg(wl["A"], wl["K"], w.dims["S"], wl["sims"], discount=0.999, alpha=0.25, frac=0.1)
     rs = np.random.RandomState(0)
+    obs1 = rs.uniform(-0.05, 0.05, (4, 4))
+    t1 = time.perf_counter()
+    one = orc.selfplay_cartpole(cfg, w, obs1, np.arange(4, dtype=np.uint32), 64, temperature=1.0, train=True, threads=1,
+                                record=False)
+    single = one["simulations"] / (time.perf_counter() - t1)
 
     def run(n_env, steps):
         obs0 = rs.uniform(-0.05, 0.05, (n_env, 4))
@@ -77,7 +85,8 @@ def cpu_baseline(wl, weights_path, seconds_target=15.0):
     return dict(value=sims / dt, unit="simulations/s", cores=cores, kind="port",
                 sample=f"{n_env} envs x {steps} steps x {wl['sims']} sims of the same CartPole workload, C oracle "
                        f"(oracle/smz_oracle.c) with plain-C MLP heads, {cores} threads (one game per thread), "
-                       f"{dt:.1f} s wall = {dt * cores:.0f} core-seconds")
+                       f"{dt:.1f} s wall = {dt * cores:.0f} core-seconds; one thread alone: {single:.0f} simulations/s "
+                       f"(os.cpu_count() = {os.cpu_count()})")
 
 
 def main():
