@@ -158,29 +158,90 @@ __device__ inline int sample_cdf(const double *p, int n, double u) {
     return k;
 }
 
+// register-array helpers: element access by a run-time index as a compare/select chain, so that small per-lane arrays
+// stay in registers (a dynamically indexed array is placed in scratch memory, i.e. behind a global round trip)
+template <typename T, int N>
+__device__ inline T reg_get(const T (&a)[N], int i) {
+    T v = a[0];
+#pragma unroll
+    for (int j = 1; j < N; j++) v = (j == i) ? a[j] : v;
+    return v;
+}
+template <typename T, int N>
+__device__ inline void reg_set(T (&a)[N], int i, T v) {
+#pragma unroll
+    for (int j = 0; j < N; j++) a[j] = (j == i) ? v : a[j];
+}
+
 // RandomState.choice(n, size, p=p, replace=False) -- picks in draw order.  `p` is clobbered.
 template <int MAXA>
-__device__ inline void choice_noreplace(Rng &rng, double *p, int n, int size, int32_t *out) {
+__device__ inline void choice_noreplace(Rng &rng, double (&p)[MAXA], int n, int size, int32_t (&out)[MAXA]) {
+    constexpr bool REG = MAXA <= 8;     // small arrays: select chains; larger ones: plain indexing
     double cdf[MAXA], x[MAXA];
     int32_t cand[MAXA];
     int n_uniq = 0;
     while (n_uniq < size) {
         const int m = size - n_uniq;
-        for (int i = 0; i < m; i++) x[i] = rng.random_sample();
-        for (int i = 0; i < n_uniq; i++) p[out[i]] = 0.0;
-        double acc = 0.0;
-        for (int i = 0; i < n; i++) { acc += p[i]; cdf[i] = acc; }
-        const double last = cdf[n - 1];
-        for (int i = 0; i < n; i++) cdf[i] = cdf[i] / last;
-        for (int i = 0; i < m; i++) {
-            int k = 0;
-            for (int j = 0; j < n; j++) k += (cdf[j] <= x[i]) ? 1 : 0;
-            cand[i] = k;
+#pragma unroll
+        for (int i = 0; i < MAXA; i++) if (i < m) x[i] = rng.random_sample();
+        if (REG) {
+#pragma unroll
+            for (int j = 0; j < MAXA; j++) {          // p[out[i]] = 0 for every pick so far
+                bool taken = false;
+#pragma unroll
+                for (int i = 0; i < MAXA; i++) taken = taken || (i < n_uniq && out[i] == j);
+                if (taken) p[j] = 0.0;
+            }
+        } else {
+            for (int i = 0; i < n_uniq; i++) p[out[i]] = 0.0;
         }
-        for (int i = 0; i < m; i++) {
-            bool dup = false;
-            for (int j = 0; j < i; j++) dup = dup || (cand[j] == cand[i]);
-            if (!dup) out[n_uniq++] = cand[i];
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < MAXA; i++) if (i < n) { acc += p[i]; cdf[i] = acc; }
+        const double last = acc;
+#pragma unroll
+        for (int i = 0; i < MAXA; i++) if (i < n) cdf[i] = cdf[i] / last;
+#pragma unroll
+        for (int i = 0; i < MAXA; i++) {
+            if (i < m) {
+                int k = 0;
+#pragma unroll
+                for (int j = 0; j < MAXA; j++) if (j < n) k += (cdf[j] <= x[i]) ? 1 : 0;
+                cand[i] = k;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXA; i++) {
+            if (i < m) {
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < MAXA; j++) dup = dup || (j < i && cand[j] == cand[i]);
+                if (!dup) {
+                    if (REG) reg_set<int32_t, MAXA>(out, n_uniq, cand[i]); else out[n_uniq] = cand[i];
+                    n_uniq++;
+                }
+            }
+        }
+    }
+}
+
+// np.sort of the first `size` entries (insertion sort; select chains for small arrays)
+template <int MAXA>
+__device__ inline void sort_picks(int32_t (&v)[MAXA], int size) {
+    if (MAXA <= 8) {
+#pragma unroll
+        for (int pass = 0; pass < MAXA - 1; pass++) {
+#pragma unroll
+            for (int j = 0; j + 1 < MAXA; j++) {
+                if (j + 1 < size && v[j] > v[j + 1]) { const int32_t t = v[j]; v[j] = v[j + 1]; v[j + 1] = t; }
+            }
+        }
+    } else {
+        for (int i = 1; i < size; i++) {
+            const int32_t x = v[i];
+            int j = i - 1;
+            while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; j--; }
+            v[j + 1] = x;
         }
     }
 }
@@ -450,12 +511,7 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, Tr
     normalise_policy<MAXA>(pol, A, p);
     for (int a = 0; a < A; a++) p64[a] = (double)p[a];
     choice_noreplace<MAXA>(rng, p64, A, K, picks);
-    for (int i = 1; i < K; i++) {  // np.sort of the K picks
-        const int32_t x = picks[i];
-        int j = i - 1;
-        while (j >= 0 && picks[j] > x) { picks[j + 1] = picks[j]; j--; }
-        picks[j + 1] = x;
-    }
+    sort_picks<MAXA>(picks, K);   // np.sort of the K picks
     const int e = h.n_exp;
     h.n_exp = e + 1;
     {
