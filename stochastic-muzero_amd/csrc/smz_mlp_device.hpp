@@ -169,12 +169,12 @@ __device__ inline void softmax_lanes(const float (&v)[U], int A, int lane, float
 #pragma unroll
     for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) m = fmaxf(m, v[u]); }
     m = wave_max(m);
-    float den = 0.f;
+    float e[U], den = 0.f;
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) den += expf(v[u] - m); }
+    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; e[u] = (o < A) ? expf(v[u] - m) : 0.f; den += e[u]; }
     den = wave_sum(den);
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) dst[o] = expf(v[u] - m) / den; }
+    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) dst[o] = e[u] / den; }
 }
 
 // hidden trunk for R rows: in-layer + L repeats of the shared mid layer, ELU after each; results in tA[r] (LDS, zero
