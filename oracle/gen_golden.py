@@ -402,6 +402,13 @@ def gen_selfplay(ref, mz, name, sims, temperature, limit, seed):
     probe = np.float64(np.random.random_sample())
     rb.save_game(g)   # replay_buffer.py:109-137 accepts it; record what it derived
     data = stack_cases(steps)
+    # make_target (game.py:291-314) for every position: what the training side reads from a stored game
+    U, TD = 5, 10
+    tv = np.zeros((len(g.root_values), U)); tr = np.zeros((len(g.root_values), U)); tp = np.zeros((len(g.root_values), U, 2))
+    for i in range(len(g.root_values)):
+        for u, (val, rew, pol) in enumerate(g.make_target(i, U, TD)):
+            tv[i, u], tr[i, u], tp[i, u] = val, rew, pol
+    data.update(target_values=tv, target_rewards=tr, target_policies=tp, target_unroll=np.int32(U), target_td=np.int32(TD))
     data.update(
         game_actions=np.array([int(np.argmax(a)) for a in g.action_history], np.int32),
         game_action_onehot=np.array(g.action_history, np.float64),
@@ -446,6 +453,13 @@ def main():
     torch.set_num_threads(1)
     gen_temperature_schedule(ref)
     if os.environ.get("SMZ_GOLDEN_ONLY") == "temperature":
+        return
+    if os.environ.get("SMZ_GOLDEN_ONLY") == "selfplay":
+        mz = load_ckpt(ref, 421)
+        gen_selfplay(ref, mz, "selfplay421_sims10_T1", sims=10, temperature=1.0, limit=24, seed=0)
+        gen_selfplay(ref, mz, "selfplay421_sims11_T02", sims=11, temperature=0.2, limit=24, seed=1)
+        gen_selfplay(ref, mz, "selfplay421_sims10_T05", sims=10, temperature=0.5, limit=16, seed=2)
+        gen_selfplay(ref, mz, "selfplay421_sims10_T0", sims=10, temperature=0.0, limit=16, seed=3)
         return
 
     base = dict(pb_c_base=19652, pb_c_init=1.25, discount=0.999, root_dirichlet_alpha=0.25,

@@ -34,3 +34,33 @@ def shard_range(total_envs, rank, world):
     per = (total_envs + world - 1) // world
     lo = min(total_envs, rank * per)
     return lo, min(total_envs, lo + per)
+
+
+def broadcast_model(model, src=0, group=None, device=None):
+    """Learner -> actors weight hand-off after a training step (replaces Ray re-pickling the whole model into every
+    task, self_play.py:249-256): every parameter/buffer of the six head modules is broadcast from rank `src` in one
+    flattened message per module (checkpoint 421: 115 KB in total), then the cached batched evaluators are dropped so
+    the next search packs the new weights.  "nccl" (= RCCL) broadcasts from device memory; "gloo" from the host."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return model
+    use_cuda = dist.get_backend(group) == "nccl"
+    dev = torch.device(device if device is not None else ("cuda" if use_cuda else "cpu"))
+    for name in ("representation", "prediction", "afterstate_prediction", "afterstate_dynamics", "dynamics", "encoder"):
+        module = getattr(model, name + "_function")
+        tensors, seen = [], set()
+        for t in list(module.parameters()) + list(module.buffers()):
+            if id(t) not in seen and t.is_floating_point():          # shared trunks appear once
+                seen.add(id(t))
+                tensors.append(t)
+        if not tensors:
+            continue
+        flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors]).to(dev)
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        with torch.no_grad():
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].reshape(t.shape).to(t.device, t.dtype))
+                off += n
+    model._heads = {}
+    return model

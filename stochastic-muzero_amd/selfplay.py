@@ -81,6 +81,23 @@ class GameRecord:
     def game_length(self):
         return len(self.action_history)
 
+    def make_target(self, state_index, num_unroll, td_steps):
+        """[value target, last reward, child_visits] for num_unroll consecutive positions (game.py:291-314):
+        n-step return bootstrapped from the search value td_steps ahead; positions past the end are absorbing."""
+        n = len(self.root_values)
+        targets = []
+        for cur in range(state_index, state_index + num_unroll):
+            b = cur + td_steps
+            value = self.root_values[b] * self.discount ** td_steps if b < n else 0.0
+            for i, reward in enumerate(self.rewards[cur:b]):
+                value += reward * self.discount ** i
+            last_reward = self.rewards[cur - 1] if 0 < cur <= len(self.rewards) else 0.0
+            if cur < n:
+                targets.append([value, last_reward, self.child_visits[cur]])
+            else:
+                targets.append([0.0, last_reward, np.zeros(self.action_space_size, dtype=np.float64)])
+        return targets
+
     def make_priority(self, td_steps):
         """|root value - n-step return| ** priority_scale per position, and its maximum (game.py:316-337)."""
         n = len(self.root_values)
@@ -177,6 +194,37 @@ def play_games_grouped(groups, temperature, steps, train=True):
     for g in groups:
         cur.wait_stream(g.stream)
     return [g.chunk for g in groups]
+
+
+def reanalyse_games(games, model, mcts, device, train=False):
+    """MuZero-Reanalyse on stored games: every stored position is searched again with the CURRENT networks by the
+    same batched engine (pure search, no environment) and its root value / child-visit target is refreshed.
+    The first position of a game is not in the record (game.py stores post-step observations, :264), so position t
+    re-searches observations[t-1] for t >= 1 and position 0 keeps its stored statistics.
+    `mcts.num_trees` must be >= the number of positions searched per call (the batch is padded)."""
+    heads = model.heads(device)
+    obs, index = [], []
+    for gi, g in enumerate(games):
+        for t in range(1, g.game_length):
+            obs.append(g.observations[t - 1].reshape(-1))
+            index.append((gi, t))
+    if not obs:
+        return 0
+    B = mcts.num_trees
+    done = 0
+    for lo in range(0, len(obs), B):
+        rows = obs[lo:lo + B]
+        batch = torch.stack(rows + [rows[-1]] * (B - len(rows))).to(device=device, dtype=torch.float32).contiguous()
+        eng = mcts.run(batch, heads, train=train)
+        _, _, child_visits, root_value = eng.act(0.0)
+        torch.cuda.synchronize(device)
+        cv, rv = child_visits.cpu().numpy(), root_value.cpu().numpy()
+        for k, (gi, t) in enumerate(index[lo:lo + B]):
+            games[gi].child_visits[t] = cv[k].copy()
+            games[gi].root_values[t] = np.float32(rv[k])
+            games[gi].reanalyzed = True
+        done += len(rows)
+    return done
 
 
 def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None, gather=None, priority_scale=1,

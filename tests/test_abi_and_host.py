@@ -105,6 +105,14 @@ def test_trajectory_chunk_to_game_records_and_priorities(name):
     pos, top = g.make_priority(50)
     np.testing.assert_allclose(pos, data["buffer_prio_position"], rtol=1e-12)
     np.testing.assert_allclose(top, data["buffer_prio_game"], rtol=1e-12)
+    # make_target (game.py:291-314) against the reference's own Game.make_target on the same game
+    U, TD = int(data["target_unroll"]), int(data["target_td"])
+    for i in range(T):
+        tgt = g.make_target(i, U, TD)
+        assert len(tgt) == U
+        np.testing.assert_allclose([t[0] for t in tgt], data["target_values"][i], rtol=1e-12, atol=1e-12)
+        assert [float(t[1]) for t in tgt] == list(data["target_rewards"][i])
+        assert np.array_equal(np.array([t[2] for t in tgt]), data["target_policies"][i])
 
 
 def test_checkpoint_surface_roundtrip(tmp_path):

@@ -325,3 +325,36 @@ def test_cli_play_from_reference_layout_checkpoint(tmp_path):
     out = muzero_cli.main(["muzero_cli.py", "train", str(path), "--envs", "32", "--iterations", "2", "--steps", "12",
                            "--checkpoint-dir", str(tmp_path)])
     assert out["train"]["games"] == 64 and len(out["train"]["rewards"]) == 2
+
+
+def test_reanalyse_refreshes_targets_with_the_same_engine():
+    """Stored positions re-searched by the batched engine: with unchanged weights, noise off and the same per-tree
+    seeds the refreshed value targets equal a direct search of the stored observations."""
+    mcts_mod, model_mod, envs_mod, sp = _mods()
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_ckpt421.npz"))
+    B, T = 64, 6
+    env = envs_mod.CartPoleVec(B, "cuda:0", seed=3); env.reset()
+    m = mcts_mod.BatchedMCTS(B, num_simulations=12, discount=0.999, root_exploration_fraction=0.1)
+    m.seed(np.arange(B, dtype=np.uint64))
+    chunk = sp.play_games(env, model.heads("cuda:0"), m, 1.0, T)
+    torch.cuda.synchronize()
+    games = sp.chunk_to_games(chunk.data, 4, 2, 0.999, limit_of_game_play=T)
+    n_pos = B * (T - 1)
+    r = mcts_mod.BatchedMCTS(n_pos, num_simulations=12, discount=0.999, root_exploration_fraction=0.1)
+    r.seed(np.arange(n_pos, dtype=np.uint64))
+    old = [list(g.root_values) for g in games]
+    assert sp.reanalyse_games(games, model, r, "cuda:0", train=False) == n_pos
+    assert all(g.reanalyzed for g in games)
+    # direct search of the same observations with the same seeds
+    d = mcts_mod.BatchedMCTS(n_pos, num_simulations=12, discount=0.999, root_exploration_fraction=0.1)
+    d.seed(np.arange(n_pos, dtype=np.uint64))
+    obs = torch.stack([g.observations[t - 1].reshape(-1) for g in games for t in range(1, T)]).cuda()
+    e = d.run(obs, model.heads("cuda:0"), train=False)
+    _, _, cv, rv = e.act(0.0)
+    torch.cuda.synchronize()
+    k = 0
+    for g in games:
+        for t in range(1, T):
+            assert g.root_values[t] == np.float32(rv[k].item()) and np.array_equal(g.child_visits[t], cv[k].cpu().numpy())
+            k += 1
+    assert any(o != list(g.root_values) for o, g in zip(old, games))      # noise-free re-search differs from self-play
