@@ -181,7 +181,7 @@ def main():
     out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs x 50 sims",
            "value": sims_total / dt, "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32 tree values / f64 pUCT scores / i32 counts; f32 heads",
+           "vs_baseline": None, "dtype": "f32 (tree values, heads) + f64 (pUCT scores, root priors) + i32 (counts)",
            "data": "synthetic (CartPole-shaped Euler env, fixed-length episodes; checkpoint-421 weights)",
            "config": {"workload": args.workload, "envs_per_gpu": B, "num_simulations": wl["sims"],
                       "actions": wl["A"], "children_per_expansion": wl["K"], "hidden_floats": model.state_dimension,

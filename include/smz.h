@@ -189,7 +189,7 @@ int smz_prediction_epilogue(const float *policy_logits_pred_dev, const float *va
  *
  * Packed weight buffer: float32, every matrix stored input-major and 4-way interleaved along the input index so
  * that lane o reads four consecutive input weights with one 16-byte LDS read:
- *     element (k, o) of a K x O matrix  ->  base + ((k / 4) * OP + o) * 4 + (k % 4),   OP = 64 * ceil(maxO / 64),
+ *     element (k, o) of a K x O matrix  ->  base + ((k / 4) * OP + o) * 4 + (k % 4),   OP = 64 (max(H, 2S, A+S) <= 64),
  * K zero-padded to a multiple of 4, O zero-padded to OP; a bias vector is OP floats.  Matrices (off[] index):
  *   0 dyn_in  (S+A x H)   1 ady_in (S+A x H)   2 dyn_mid (H x H)  3 ady_mid (H x H)      [mid only used when L > 0]
  *   4 dyn_out (H x 2S: reward logits | next state)     5 ady_out (H x S: next state)

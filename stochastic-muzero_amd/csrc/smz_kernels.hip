@@ -1032,7 +1032,7 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
         hipLaunchKernelGGL((k_search_mlp<MA, KS, UU>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream, P, \
                            *desc, weights_dev, obs_dev, train);                                                        \
     })
-    if (desc->OP == kWave) { SMZ_LAUNCH_SEARCH(1); } else { SMZ_LAUNCH_SEARCH(2); }
+    SMZ_LAUNCH_SEARCH(1);     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane)
 #undef SMZ_LAUNCH_SEARCH
     h->root_ready = true;
     h->selected = false;

@@ -96,7 +96,7 @@ int smz_mlp_layout(smz_mlp_desc *d) {
     if (2 * d->S > maxo) maxo = 2 * d->S;
     if (d->A + d->S > maxo) maxo = d->A + d->S;
     d->OP = kWave * ((maxo + kWave - 1) / kWave);
-    if (d->OP > 2 * kWave) return SMZ_ERR_INVALID;       // at most two output neurons per lane are built
+    if (d->OP > kWave) return SMZ_ERR_INVALID;           // one output neuron per lane: wider layers cannot fit the 160 KB LDS anyway
     const int mid = d->L > 0 ? d->H : 0;     // the shared hidden layer exists only when number_of_hidden_layer > 0
     const int K[M_COUNT] = {d->S + d->A, d->S + d->A, mid, mid, d->H, d->H, d->S, d->S, mid, mid, d->H, d->H,
                             d->obs, mid, d->H};
@@ -129,13 +129,9 @@ int smz_mlp_initial(const smz_mlp_desc *d, const float *weights_dev, const float
     int blocks, rpw;
     mlp_geometry(B, blocks, rpw);
     const size_t lds = ((size_t)d->total_floats + (size_t)kWavesPerWg * scratch_floats(*d)) * sizeof(float);
-    if (allow_lds(d->OP == kWave ? k_mlp_initial<1> : k_mlp_initial<2>, lds) != SMZ_OK) return SMZ_ERR_HIP;
-    if (d->OP == kWave)
-        hipLaunchKernelGGL((k_mlp_initial<1>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
-                           weights_dev, obs_dev, hidden_out_dev, policy_out_dev, B, rpw);
-    else
-        hipLaunchKernelGGL((k_mlp_initial<2>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
-                           weights_dev, obs_dev, hidden_out_dev, policy_out_dev, B, rpw);
+    if (allow_lds(k_mlp_initial<1>, lds) != SMZ_OK) return SMZ_ERR_HIP;
+    hipLaunchKernelGGL((k_mlp_initial<1>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
+                       weights_dev, obs_dev, hidden_out_dev, policy_out_dev, B, rpw);
     return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
 }
 
@@ -148,15 +144,10 @@ int smz_mlp_recurrent(const smz_mlp_desc *d, const float *weights_dev, const flo
     int blocks, rpw;
     mlp_geometry(B, blocks, rpw);
     const size_t lds = ((size_t)d->total_floats + (size_t)kWavesPerWg * scratch_floats(*d)) * sizeof(float);
-    if (allow_lds(d->OP == kWave ? k_mlp_recurrent<1> : k_mlp_recurrent<2>, lds) != SMZ_OK) return SMZ_ERR_HIP;
-    if (d->OP == kWave)
-        hipLaunchKernelGGL((k_mlp_recurrent<1>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
-                           weights_dev, mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev,
-                           value_out_dev, B, rpw);
-    else
-        hipLaunchKernelGGL((k_mlp_recurrent<2>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
-                           weights_dev, mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev,
-                           value_out_dev, B, rpw);
+    if (allow_lds(k_mlp_recurrent<1>, lds) != SMZ_OK) return SMZ_ERR_HIP;
+    hipLaunchKernelGGL((k_mlp_recurrent<1>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
+                       weights_dev, mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev,
+                       value_out_dev, B, rpw);
     return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
 }
 

@@ -358,3 +358,28 @@ def test_reanalyse_refreshes_targets_with_the_same_engine():
             assert g.root_values[t] == np.float32(rv[k].item()) and np.array_equal(g.child_visits[t], cv[k].cpu().numpy())
             k += 1
     assert any(o != list(g.root_values) for o, g in zip(old, games))      # noise-free re-search differs from self-play
+
+
+def test_networks_too_large_for_lds_fall_back_to_gemm_heads():
+    """Checkpoint-450-like dimensions (S 61 / H 126 / L 4) do not fit a CU's LDS: smz_mlp_layout refuses, the model
+    hands out the torch-GEMM evaluator, and the step-wise search (one HIP graph) runs with it."""
+    import ctypes as C
+    import stochastic_muzero_amd as smz
+    mcts_mod, model_mod, _, _ = _mods()
+    heads_mod = import_module("stochastic-muzero_amd.heads")
+    d = smz._lib.MlpDesc(4, 2, 61, 126, 4)
+    assert smz._lib.load().smz_mlp_layout(C.byref(d)) == smz._lib.SMZ_ERR_INVALID
+    torch.manual_seed(0)
+    model = model_mod.Muzero(model_structure="mlp_model", observation_space_dimensions=4, action_space_dimensions=2,
+                             state_space_dimensions=61, hidden_layer_dimensions=126, number_of_hidden_layer=4, random_tag=450)
+    heads = model.heads("cuda:0")
+    assert isinstance(heads, heads_mod.FusedMlpHeads)
+    with pytest.raises(ValueError):
+        model.heads("cuda:0", backend="hip")
+    B = 200
+    m = mcts_mod.BatchedMCTS(B, num_simulations=8, discount=0.99)
+    m.seed(np.arange(B, dtype=np.uint64))
+    e = m.run(torch.randn(B, 4, generator=torch.Generator().manual_seed(0)).cuda(), heads)
+    v = e.root_stats()[0]
+    torch.cuda.synchronize()
+    assert m._single is None and m._graph is not None and (v.sum(1) == 8).all()
