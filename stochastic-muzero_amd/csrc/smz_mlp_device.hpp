@@ -90,29 +90,34 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
 
 // torch's ELU evaluates exp(x) - 1 (aten/src/ATen/native/cpu/Activation.cpp elu_kernel)
 __device__ inline float elu(float x) { return x > 0.f ? x : expf(x) - 1.0f; }
-// Wave-wide reductions on the DPP crossbar (VALU latency) instead of ds_bpermute round trips: row_shr 1/2/4/8 build the
-// per-16-lane-row totals in lanes 15/31/47/63, row_bcast:15 / row_bcast:31 carry them across rows, lane 63 holds the
-// result and is broadcast through an SGPR.  `ident` fills the lanes a shift has no source for.
-template <int CTRL, int ROW_MASK>
-__device__ inline float dpp_move(float ident, float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-#define SMZ_WAVE_REDUCE(NAME, OP, IDENT)                                   \
-    __device__ inline float NAME(float v) {                                \
-        const float id = IDENT;                                            \
-        v = OP(v, dpp_move<0x111, 0xf>(id, v)); /* row_shr:1 */            \
-        v = OP(v, dpp_move<0x112, 0xf>(id, v)); /* row_shr:2 */            \
-        v = OP(v, dpp_move<0x114, 0xf>(id, v)); /* row_shr:4 */            \
-        v = OP(v, dpp_move<0x118, 0xf>(id, v)); /* row_shr:8 */            \
-        v = OP(v, dpp_move<0x142, 0xa>(id, v)); /* row_bcast:15 -> rows 1,3 */ \
-        v = OP(v, dpp_move<0x143, 0xc>(id, v)); /* row_bcast:31 -> rows 2,3 */ \
-        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); \
+// Wave-wide reductions on the DPP crossbar (VALU latency, no LDS round trips), written as fused v_<op>_f32_dpp
+// instructions: row_shr 1/2/4/8 build the totals of each 16-lane row in lanes 15/31/47/63 (a lane whose source lies
+// outside its row keeps its value: bound_ctrl off), row_bcast:15 / row_bcast:31 carry them across rows, lane 63 holds
+// the result and is broadcast through an SGPR.  hipcc lowers the same chain written with __builtin_amdgcn_update_dpp
+// to 5 instructions per step (identity mov + hazard nop + v_mov_dpp + NaN canonicalisation + op), hence the asm;
+// `s_nop 1` covers the 2 wait states a DPP read needs after the VALU write of the same register.  All 64 lanes must be
+// active (the callers are wave-uniform).
+#define SMZ_DPP_REDUCE(NAME, INSN)                                                               \
+    __device__ inline float NAME(float v) {                                                      \
+        asm volatile("s_nop 1\n\t"                                                               \
+                     INSN " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"      \
+                     INSN " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"      \
+                     INSN " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"      \
+                     INSN " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"      \
+                     INSN " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"   \
+                     INSN " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"        \
+                     : "+v"(v));                                                                 \
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));                 \
     }
-__device__ inline float op_add(float a, float b) { return a + b; }
-SMZ_WAVE_REDUCE(wave_max, fmaxf, -__builtin_inff())
-SMZ_WAVE_REDUCE(wave_min, fminf, __builtin_inff())
-SMZ_WAVE_REDUCE(wave_sum, op_add, 0.0f)
-#undef SMZ_WAVE_REDUCE
+SMZ_DPP_REDUCE(wave_max, "v_max_f32_dpp")
+SMZ_DPP_REDUCE(wave_min, "v_min_f32_dpp")
+SMZ_DPP_REDUCE(wave_sum, "v_add_f32_dpp")
+#undef SMZ_DPP_REDUCE
+__device__ inline float op_max(float a, float b) { return fmaxf(a, b); }
+__device__ inline float op_min(float a, float b) { return fminf(a, b); }
+__device__ inline void wave_sum2(float &a, float &b) { a = wave_sum(a); b = wave_sum(b); }
+__device__ inline void wave_minmax(float &mn, float &mx) { mn = wave_min(mn); mx = wave_max(mx); }
+
 // Orders this wave's LDS traffic: LDS instructions of one wave execute in issue order, so other lanes' earlier writes are
 // visible once they have been issued; the asm is a compiler barrier plus an LDS-counter wait.  (A scoped fence here
 // would also drain vmcnt, i.e. wait for every outstanding GLOBAL store of the row before each layer.)
@@ -123,7 +128,7 @@ template <int U>
 __device__ inline float decode_lanes(const float (&v)[U], int lo, int S, int lane) {
     float m = -__builtin_inff();
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o >= lo && o < lo + S) m = fmaxf(m, v[u]); }
+    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o >= lo && o < lo + S) m = op_max(m, v[u]); }
     m = wave_max(m);
     float den = 0.f, num = 0.f;
     const int half = S / 2;
@@ -132,8 +137,7 @@ __device__ inline float decode_lanes(const float (&v)[U], int lo, int S, int lan
         const int o = lane + kWave * u;
         if (o >= lo && o < lo + S) { const float e = expf(v[u] - m); den += e; num += (float)(o - lo - half) * e; }
     }
-    den = wave_sum(den);
-    num = wave_sum(num);
+    wave_sum2(den, num);
     const float y = num / den;
     const float sg = (y > 0.f) ? 1.f : ((y < 0.f) ? -1.f : 0.f);
     const float r = (sqrtf(1.f + 4.f * 0.001f * (fabsf(y) + 1.f + 0.001f)) - 1.f) / (2.f * 0.001f);
@@ -146,9 +150,8 @@ __device__ inline void scale_lanes(const float (&v)[U], int lo, int S, int lane,
                                    float *dst2 = nullptr) {
     float mn = __builtin_inff(), mx = -__builtin_inff();
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o >= lo && o < lo + S) { mn = fminf(mn, v[u]); mx = fmaxf(mx, v[u]); } }
-    mn = wave_min(mn);
-    mx = wave_max(mx);
+    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o >= lo && o < lo + S) { mn = op_min(mn, v[u]); mx = op_max(mx, v[u]); } }
+    wave_minmax(mn, mx);
     float sc = mx - mn;
     if (sc < 1e-5f) sc += 1e-5f;
 #pragma unroll
@@ -167,7 +170,7 @@ template <int U>
 __device__ inline void softmax_lanes(const float (&v)[U], int A, int lane, float *dst) {
     float m = -__builtin_inff();
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) m = fmaxf(m, v[u]); }
+    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) m = op_max(m, v[u]); }
     m = wave_max(m);
     float e[U], den = 0.f;
 #pragma unroll
