@@ -115,8 +115,66 @@ SMZ_DPP_REDUCE(wave_sum, "v_add_f32_dpp")
 #undef SMZ_DPP_REDUCE
 __device__ inline float op_max(float a, float b) { return fmaxf(a, b); }
 __device__ inline float op_min(float a, float b) { return fminf(a, b); }
-__device__ inline void wave_sum2(float &a, float &b) { a = wave_sum(a); b = wave_sum(b); }
-__device__ inline void wave_minmax(float &mn, float &mx) { mn = wave_min(mn); mx = wave_max(mx); }
+// two independent sums in one chain: each instruction fills one of the other's DPP wait states
+__device__ inline void wave_sum2(float &a, float &b) {
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(a), "+v"(b));
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+}
+__device__ inline void wave_minmax(float &mn, float &mx) {
+    asm volatile("s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(mn), "+v"(mx));
+    mn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn), 63));
+    mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 63));
+}
+
+// three independent chains per step: no wait states left to pad
+#define SMZ_DPP3_STEP(I0, I1, I2, CTRL)                                                             \
+    I0 " %0, %0, %0 " CTRL "\n\t" I1 " %1, %1, %1 " CTRL "\n\t" I2 " %2, %2, %2 " CTRL "\n\t"
+#define SMZ_DPP3_REDUCE(NAME, I0, I1, I2)                                                          \
+    __device__ inline void NAME(float &a, float &b, float &c) {                                    \
+        asm volatile("s_nop 1\n\t"                                                                 \
+                     SMZ_DPP3_STEP(I0, I1, I2, "row_shr:1 row_mask:0xf bank_mask:0xf")             \
+                     SMZ_DPP3_STEP(I0, I1, I2, "row_shr:2 row_mask:0xf bank_mask:0xf")             \
+                     SMZ_DPP3_STEP(I0, I1, I2, "row_shr:4 row_mask:0xf bank_mask:0xf")             \
+                     SMZ_DPP3_STEP(I0, I1, I2, "row_shr:8 row_mask:0xf bank_mask:0xf")             \
+                     SMZ_DPP3_STEP(I0, I1, I2, "row_bcast:15 row_mask:0xa bank_mask:0xf")          \
+                     SMZ_DPP3_STEP(I0, I1, I2, "row_bcast:31 row_mask:0xc bank_mask:0xf")          \
+                     "s_nop 1"                                                                     \
+                     : "+v"(a), "+v"(b), "+v"(c));                                                 \
+        a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));                      \
+        b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));                      \
+        c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));                      \
+    }
+SMZ_DPP3_REDUCE(wave_sum3, "v_add_f32_dpp", "v_add_f32_dpp", "v_add_f32_dpp")
+SMZ_DPP3_REDUCE(wave_max_min_max, "v_max_f32_dpp", "v_min_f32_dpp", "v_max_f32_dpp")
+#undef SMZ_DPP3_REDUCE
+#undef SMZ_DPP3_STEP
+__device__ inline void wave_max2(float &a, float &b) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 0\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(a), "+v"(b));
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+}
 
 // Orders this wave's LDS traffic: LDS instructions of one wave execute in issue order, so other lanes' earlier writes are
 // visible once they have been issued; the asm is a compiler barrier plus an LDS-counter wait.  (A scoped fence here
@@ -178,6 +236,77 @@ __device__ inline void softmax_lanes(const float (&v)[U], int A, int lane, float
     den = wave_sum(den);
 #pragma unroll
     for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) dst[o] = e[u] / den; }
+}
+
+__device__ inline float support_to_scalar(float num, float den) {
+    const float y = num / den;
+    const float sg = (y > 0.f) ? 1.f : ((y < 0.f) ? -1.f : 0.f);
+    const float r = (sqrtf(1.f + 4.f * 0.001f * (fabsf(y) + 1.f + 0.001f)) - 1.f) / (2.f * 0.001f);
+    return sg * (r * r - 1.f);
+}
+
+// prediction tail in two reduction chains: softmax over lanes [0, A) to dst (if non-null) and the support decode of
+// lanes [A, A+S) -- the same arithmetic as softmax_lanes + decode_lanes (each lane belongs to one segment, the sums
+// of the other segment see exact zeros), sharing one paired max chain, one exponential and one triple sum chain
+template <int U>
+__device__ inline float softmax_decode_lanes(const float (&v)[U], int A, int S, int lane, float *dst) {
+    float mp = -__builtin_inff(), mv = -__builtin_inff();
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int o = lane + kWave * u;
+        if (o < A) mp = op_max(mp, v[u]);
+        else if (o < A + S) mv = op_max(mv, v[u]);
+    }
+    wave_max2(mp, mv);
+    float e[U], dp = 0.f, dv = 0.f, nv = 0.f;
+    const int half = S / 2;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int o = lane + kWave * u;
+        const bool pol = o < A, val = !pol && o < A + S;
+        e[u] = (pol || val) ? expf(v[u] - (pol ? mp : mv)) : 0.f;
+        if (pol) dp += e[u];
+        if (val) { dv += e[u]; nv += (float)(o - A - half) * e[u]; }
+    }
+    wave_sum3(dp, dv, nv);
+    if (dst) {
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) dst[o] = e[u] / dp; }
+    }
+    return support_to_scalar(nv, dv);
+}
+
+// dynamics tail in two chains: support decode of lanes [0, S) (reward) and scale_to_bound_action of lanes [S, 2S)
+template <int U>
+__device__ inline float decode_scale_lanes(const float (&v)[U], int S, int lane, float *act_out, float *dst) {
+    float mr = -__builtin_inff(), mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int o = lane + kWave * u;
+        if (o < S) mr = op_max(mr, v[u]);
+        else if (o < 2 * S) { mn = op_min(mn, v[u]); mx = op_max(mx, v[u]); }
+    }
+    wave_max_min_max(mr, mn, mx);
+    float den = 0.f, num = 0.f;
+    const int half = S / 2;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int o = lane + kWave * u;
+        if (o < S) { const float e = expf(v[u] - mr); den += e; num += (float)(o - half) * e; }
+    }
+    wave_sum2(den, num);
+    float sc = mx - mn;
+    if (sc < 1e-5f) sc += 1e-5f;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int o = lane + kWave * u;
+        if (o >= S && o < 2 * S) {
+            const float h = (v[u] - mn) / sc;
+            act_out[o - S] = h;
+            if (dst) dst[o - S] = h;
+        }
+    }
+    return support_to_scalar(num, den);
 }
 
 // hidden trunk for R rows: in-layer + L repeats of the shared mid layer, ELU after each; results in tA[r] (LDS, zero
@@ -277,8 +406,7 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
     for (int r = 0; r < R; r++) {
         reward[r] = 0.f;
         if (dyn[r]) {       // [reward logits | next state]
-            reward[r] = decode_lanes<U>(acc[r], 0, S, lane);
-            scale_lanes<U>(acc[r], S, S, lane, hbuf[r], live[r] ? dst_hidden[r] : nullptr);
+            reward[r] = decode_scale_lanes<U>(acc[r], S, lane, hbuf[r], live[r] ? dst_hidden[r] : nullptr);
         } else {
             scale_lanes<U>(acc[r], 0, S, lane, hbuf[r], live[r] ? dst_hidden[r] : nullptr);
         }
@@ -299,8 +427,7 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        if (live[r]) softmax_lanes<U>(acc[r], A, lane, dst_policy[r]);
-        value[r] = decode_lanes<U>(acc[r], A, S, lane);
+        value[r] = softmax_decode_lanes<U>(acc[r], A, S, lane, live[r] ? dst_policy[r] : nullptr);
     }
     lds_sync();
 }
