@@ -447,12 +447,79 @@ def gen_temperature_schedule(ref):
     print(f"wrote {path} ({len(rows)} rows)")
 
 
+def export_state_dicts(mz, path, **meta):
+    """The six head modules' state_dicts as flat "<function>/<key>" arrays (+ meta_* scalars)."""
+    out = {"meta_" + k: np.asarray(v) for k, v in meta.items()}
+    for f in ("representation", "prediction", "afterstate_prediction", "afterstate_dynamics", "dynamics", "encoder"):
+        for k, v in getattr(mz, f + "_function").state_dict().items():
+            out[f + "/" + k] = v.detach().cpu().numpy()
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def gen_vision_nets(ref):
+    """Weights of the reference's vision family + head-level input/output vectors (the reference's own
+    *_inference functions, muzero_model.py:802-909)."""
+    # (1) the net behind vision_sims50.npz: its tape already holds the head outputs for these weights
+    vz = fresh_vision(ref, A=2, L=1, seed=0)
+    export_state_dicts(vz, os.path.join(OUT, "visionnet_L1_seed0.npz"), model_structure="vision_model", A=2, S=31,
+                       H=64, L=1, obs=0, torch_seed=0)
+    # (2) a deeper net with non-trivial batch-norm statistics / affine terms (a trained net's situation)
+    A, L, H, S = 3, 2, 32, 21
+    torch.manual_seed(5)
+    np_state = np.random.get_state()
+    vz = ref.model.Muzero(model_structure="vision_model", observation_space_dimensions=ref.Box(0.0, 1.0, shape=(98, 98, 3)),
+                          action_space_dimensions=ref.Discrete(A), state_space_dimensions=S, hidden_layer_dimensions=H,
+                          number_of_hidden_layer=L, k_hypothetical_steps=5, learning_rate=1e-3, device="cpu",
+                          use_amp=False, scaler_on=False, num_of_epoch=10)
+    np.random.set_state(np_state)
+    g = torch.Generator().manual_seed(11)
+    for f in ("representation", "prediction", "afterstate_prediction", "afterstate_dynamics", "dynamics", "encoder"):
+        for m in getattr(vz, f + "_function").modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                with torch.no_grad():
+                    m.running_mean.copy_(0.1 * torch.randn(m.num_features, generator=g))
+                    m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=g))
+                    m.weight.copy_(0.5 + torch.rand(m.num_features, generator=g))
+                    m.bias.copy_(0.1 * torch.randn(m.num_features, generator=g))
+    export_state_dicts(vz, os.path.join(OUT, "visionnet_L2_bn.npz"), model_structure="vision_model", A=A, S=S, H=H,
+                       L=L, obs=0, torch_seed=5)
+    io = {"obs_seed": np.arange(4000, 4003)}
+    hs, pol, val, apol, aval, adyn, dyn_r, dyn_h = [], [], [], [], [], [], [], []
+    for sd in io["obs_seed"]:
+        obs = torch.tensor(np.random.RandomState(int(sd)).rand(1, 3, 98, 98).astype(np.float32))
+        h = vz.representation_function_inference(obs)
+        hs.append(h.numpy()[0])
+        p, v = vz.prediction_function_inference(h); pol.append(p[0]); val.append(v)
+        for a in range(A):
+            ha = vz.afterstate_dynamics_function_inference(h, a)
+            adyn.append(ha.numpy()[0])
+            p, v = vz.afterstate_prediction_function_inference(ha); apol.append(p[0]); aval.append(v)
+            r, hn = vz.dynamics_function_inference(ha, a)
+            dyn_r.append(r); dyn_h.append(hn.numpy()[0])
+    io.update(hidden=np.array(hs, np.float32), policy=np.array(pol, np.float32), value=np.array(val, np.float32),
+              afterstate=np.array(adyn, np.float32), apolicy=np.array(apol, np.float32), avalue=np.array(aval, np.float32),
+              reward=np.array(dyn_r, np.float32), next_hidden=np.array(dyn_h, np.float32))
+    kw = dict(pb_c_base=19652, pb_c_init=1.25, discount=0.997, root_dirichlet_alpha=0.25, root_exploration_fraction=0.25,
+              maxium_action_sample=2, number_of_player=1, custom_loop=None, num_simulations=16)
+    cases = [run_case(ref, vz, torch.tensor(np.random.RandomState(4100 + s).rand(1, 3, 98, 98).astype(np.float32)),
+                      s, kw, obs_dim=4) for s in range(4)]
+    for c in cases:
+        c["obs"] = c["obs"][:16]
+    save("visionL2_sims16", {k: v for k, v in kw.items() if v is not None}, cases)
+    np.savez_compressed(os.path.join(OUT, "visionnet_L2_bn_io.npz"), **io)
+    print("wrote visionnet_L2_bn_io.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = R.import_reference()
     torch.set_num_threads(1)
     gen_temperature_schedule(ref)
     if os.environ.get("SMZ_GOLDEN_ONLY") == "temperature":
+        return
+    if os.environ.get("SMZ_GOLDEN_ONLY") == "vision":
+        gen_vision_nets(ref)
         return
     if os.environ.get("SMZ_GOLDEN_ONLY") == "selfplay":
         mz = load_ckpt(ref, 421)
@@ -525,6 +592,8 @@ def main():
         save("vision_sims50", cfgd(kw), cases)
     except Exception as e:  # pragma: no cover
         print("vision goldens skipped:", repr(e))
+
+    gen_vision_nets(ref)
 
     # --- degenerate crafted cases -------------------------------------------------------------------------------
     kw = dict(base, num_simulations=40)

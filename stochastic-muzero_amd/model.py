@@ -16,7 +16,7 @@ import sys
 import numpy as np
 import torch
 
-from . import compat_mlp
+from . import compat_mlp, compat_vision
 from .heads import MLP_ARRAYS, FusedMlpHeads, HipMlpHeads, ModuleHeads
 
 _FUNCS = ("representation", "prediction", "afterstate_prediction", "afterstate_dynamics", "dynamics", "encoder")
@@ -29,11 +29,16 @@ for _n in ("Representation_function", "Prediction_function", "Afterstate_predict
            "Afterstate_dynamics_function", "Dynamics_function", "Encoder_function", "StraightThroughEstimator",
            "Onehot_argmax"):
     getattr(compat_mlp, _n).__module__ = "neural_network_mlp_model"   # the name the reference's pickles carry
+for _n in ("Representation_function", "Prediction_function", "Afterstate_prediction_function",
+           "Afterstate_dynamics_function", "Dynamics_function", "Encoder_function", "Residual_block", "Down_sample",
+           "Onehot_argmax"):
+    getattr(compat_vision, _n).__module__ = "neural_network_vision_model"
 
 
 def install_compat_modules():
     """Makes `neural_network_mlp_model.*` resolvable for torch.load when the reference's file is not importable."""
     sys.modules.setdefault("neural_network_mlp_model", compat_mlp)
+    sys.modules.setdefault("neural_network_vision_model", compat_vision)
 
 
 def _linears(seq):
@@ -87,24 +92,32 @@ class Muzero:
         self._heads = {}
         if load:
             return
-        if model_structure != "mlp_model":
-            raise NotImplementedError("fresh construction is provided for mlp_model; other families load from "
-                                      "checkpoints written by the reference")
-        self.observation_dimension = int(observation_space_dimensions)
+        if model_structure not in ("mlp_model", "vision_model"):
+            raise NotImplementedError("fresh construction is provided for mlp_model and vision_model; other "
+                                      "families load from checkpoints written by the reference")
         n_act = int(action_space_dimensions)
         self.action_dictionnary = list(action_map) if action_map is not None else list(range(n_act))
         self.action_dimension = len(self.action_dictionnary)
+        if self.is_RGB:
+            family = compat_vision
+            self.observation_dimension = compat_vision.FRAME          # muzero_model.py:400-404: fixed for vision
+        else:
+            family = compat_mlp
+            self.observation_dimension = int(observation_space_dimensions)
         kw = dict(state_dimension=self.state_dimension, action_dimension=self.action_dimension,
                   observation_space_dimensions=self.observation_dimension,
                   hidden_layer_dimensions=self.hidden_layer_dimension, number_of_hidden_layer=self.number_of_hidden_layer)
-        self.representation_function = compat_mlp.Representation_function(**kw)
-        self.prediction_function = compat_mlp.Prediction_function(**kw)
-        self.afterstate_prediction_function = compat_mlp.Afterstate_prediction_function(**kw)
-        self.afterstate_dynamics_function = compat_mlp.Afterstate_dynamics_function(**kw)
-        self.dynamics_function = compat_mlp.Dynamics_function(**kw)
-        self.encoder_function = compat_mlp.Encoder_function(**kw)
+        # construction order = muzero_model.py:300-335, so an equal torch seed gives the reference's initial weights
+        self.representation_function = family.Representation_function(**kw)
+        self.prediction_function = family.Prediction_function(**kw)
+        self.afterstate_prediction_function = family.Afterstate_prediction_function(**kw)
+        self.afterstate_dynamics_function = family.Afterstate_dynamics_function(**kw)
+        self.dynamics_function = family.Dynamics_function(**kw)
+        self.encoder_function = family.Encoder_function(**kw)
         for f in _FUNCS:
-            getattr(self, f + "_function").apply(compat_mlp.weights_init)     # muzero_model.py:350-358
+            if not self.is_RGB:
+                getattr(self, f + "_function").apply(compat_mlp.weights_init)     # muzero_model.py:350-358 (mlp only)
+            getattr(self, f + "_function").eval()                                  # inference side: :803-804
 
     # ---- checkpoint surface (muzero_model.py:911-996) ---------------------------------------------------------
     def init_variables(self):
@@ -159,6 +172,20 @@ class Muzero:
     def from_checkpoint(cls, model_directory="model_checkpoint", tag=0, device="cpu"):
         m = cls(load=True, device=device)
         return m.load_model(model_directory=model_directory, tag=tag, device=device)
+
+    @classmethod
+    def from_state_dicts(cls, path_or_dict, device="cpu"):
+        """Builds a model from the six modules' state_dicts stored flat as "<function>/<key>" arrays plus
+        `meta_*` scalars (model_structure, A, S, H, L, obs) -- the layout of tests/golden/visionnet_*.npz."""
+        z = np.load(path_or_dict) if isinstance(path_or_dict, (str, os.PathLike)) else path_or_dict
+        m = cls(model_structure=str(z["meta_model_structure"]), observation_space_dimensions=int(z["meta_obs"]),
+                action_space_dimensions=int(z["meta_A"]), state_space_dimensions=int(z["meta_S"]),
+                hidden_layer_dimensions=int(z["meta_H"]), number_of_hidden_layer=int(z["meta_L"]), device=device,
+                random_tag=0)
+        for f in _FUNCS:
+            sd = {k[len(f) + 1:]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith(f + "/")}
+            getattr(m, f + "_function").load_state_dict(sd, strict=True)
+        return m
 
     @classmethod
     def from_arrays(cls, path_or_dict, device="cpu"):
