@@ -38,6 +38,9 @@ WORKLOADS = {
     "cartpole_mlp_4096x50": dict(weights="weights_ckpt421.npz", env="cartpole", obs=4, A=2, K=2, sims=50, envs=4096),
     "lunarlander_mlp_4096x50": dict(weights="weights_lunar_L0.npz", env="synthetic", obs=8, A=4, K=2, sims=50, envs=4096),
     "cartpole_mlp_4096x100": dict(weights="weights_ckpt421.npz", env="cartpole", obs=4, A=2, K=2, sims=100, envs=4096),
+    # the reference's ResNet-v2 vision family (random init, L=1), 98x98x3 frames, hidden 3x7x7; heads run
+    # as torch-ROCm modules (MIOpen/rocBLAS) between the HIP tree kernels, captured in one HIP graph
+    "vision_resnet_1024x50": dict(weights="visionnet_L1_seed0.npz", env="image", obs=3 * 98 * 98, A=2, K=2, sims=50, envs=1024),
 }
 
 
@@ -135,7 +138,10 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     B = args.envs or wl["envs"]
     wpath = os.path.join(ROOT, "tests", "golden", wl["weights"])
-    model = model_mod.Muzero.from_arrays(wpath)          # trained ckpt-421 weights exported as plain arrays
+    if wl["env"] == "image":
+        model = model_mod.Muzero.from_state_dicts(wpath)
+    else:
+        model = model_mod.Muzero.from_arrays(wpath)      # trained ckpt-421 weights exported as plain arrays
     total = B * world
     lo = rank * B
     T = max(args.steps, args.warmup, 1)
@@ -147,6 +153,8 @@ def main():
         glo = lo + gi * Bg
         if wl["env"] == "cartpole":
             env = envs_mod.CartPoleVec(Bg, dev, seed=0, first_env=glo, total_envs=total)
+        elif wl["env"] == "image":
+            env = envs_mod.ImageVec(Bg, wl["A"], dev, seed=0, first_env=glo, total_envs=total)
         else:
             env = envs_mod.SyntheticVec(Bg, wl["obs"], wl["A"], dev, seed=0, first_env=glo, total_envs=total)
         m = mcts_mod.BatchedMCTS(Bg, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
@@ -178,11 +186,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     sims_total = total * wl["sims"] * args.steps
-    out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs x 50 sims",
+    headline = args.workload == "cartpole_mlp_4096x50" and B == 4096
+    data_note = {"cartpole": "synthetic (CartPole-shaped Euler env, fixed-length episodes; checkpoint-421 weights)",
+                 "synthetic": "synthetic (N(0,1) observations of LunarLander width; random-init weights, reference init rule)",
+                 "image": "synthetic (uniform 98x98x3 frames scrolled per step; random-init ResNet-v2 weights)"}[wl["env"]]
+    out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs x 50 sims" if headline else
+                     f"MCTS simulations/sec (whole node), {args.workload} at {B} envs/GPU",
            "value": sims_total / dt, "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32 (tree values, heads) + f64 (pUCT scores, root priors) + i32 (counts)",
-           "data": "synthetic (CartPole-shaped Euler env, fixed-length episodes; checkpoint-421 weights)",
+           "data": data_note,
            "config": {"workload": args.workload, "envs_per_gpu": B, "num_simulations": wl["sims"],
                       "actions": wl["A"], "children_per_expansion": wl["K"], "hidden_floats": model.state_dimension,
                       "rng": "per-tree MT19937 (numpy-legacy, parity mode)", "hip_graph": not args.no_graph,

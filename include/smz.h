@@ -215,6 +215,49 @@ int smz_mlp_recurrent(const smz_mlp_desc *desc, const float *weights_dev, const 
                       const uint8_t *branch_dev, float *hidden_out_dev, float *reward_out_dev, float *policy_out_dev,
                       float *value_out_dev, int B, smz_stream stream);
 
+/* ---- fused heads of the `vision_model` family (neural_network_vision_model.py:41-515) ---------------------------- */
+/* Replaces, for the reference's ResNet-v2 family on 98x98x3 frames (hidden state 3x7x7 = 147 floats, channel major),
+ * the same five *_inference calls (muzero_model.py:802-909) as the smz_mlp_* entry points do for `mlp_model`.
+ * Packed weight buffer (float32, every piece starts at a multiple of 4 floats; off[] holds the float offsets):
+ *   convolutions  : torch layout [out][in][ky][kx] flattened;
+ *   batch-norms   : eval-mode affine form, [scale(C) | shift(C)] with scale = weight / sqrt(running_var + eps),
+ *                   shift = bias - running_mean * scale (float32 arithmetic, as ATen's CPU kernel folds them);
+ *   1x1 "mix" convolutions: weight [out][in] then bias [out] as separate pieces;
+ *   towers        : three Linear layers (147 -> H, H -> H (shared, applied L times), H -> n_out) each as
+ *                   W in the 4-way interleaved input-major layout of smz_mlp_desc (Wp[k/4][o][k%4], o padded to OP)
+ *                   followed by its bias piece (OP floats).
+ * Indices into off[]: transition nets (dynamics, afterstate dynamics) at SMZ_V_TRANS_BASE + net * SMZ_V_TRANS_STRIDE +
+ * SMZ_VT_*; prediction nets (prediction, afterstate prediction) at SMZ_V_PRED_BASE + net * SMZ_V_PRED_STRIDE + SMZ_VP_*;
+ * representation at SMZ_V_REP_BASE + SMZ_VR_*.  The afterstate dynamics net has no reward branch: its SMZ_VT_MIX_* and
+ * tower pieces stay zero. */
+enum { SMZ_V_DYN = 0, SMZ_V_ADY = 1, SMZ_V_PRE = 2, SMZ_V_APR = 3 };
+enum { SMZ_VT_CONV_IN = 0, SMZ_VT_BN_IN, SMZ_VT_RES_A, SMZ_VT_RES_B, SMZ_VT_RES_BN, SMZ_VT_MIX_W, SMZ_VT_MIX_B,
+       SMZ_VT_TOWER /* 6 entries: W1,b1,Wm,bm,Wo,bo */, SMZ_V_TRANS_STRIDE = 13 };
+enum { SMZ_VP_RES_A = 0, SMZ_VP_RES_B, SMZ_VP_RES_BN, SMZ_VP_VMIX_W, SMZ_VP_VMIX_B, SMZ_VP_VTOWER /* 6 */,
+       SMZ_VP_PMIX_W = 11, SMZ_VP_PMIX_B, SMZ_VP_PTOWER /* 6 */, SMZ_V_PRED_STRIDE = 19 };
+enum { SMZ_VR_STEM = 0, SMZ_VR_NARROW_A, SMZ_VR_NARROW_B, SMZ_VR_NARROW_BN, SMZ_VR_WIDEN, SMZ_VR_WIDE_A, SMZ_VR_WIDE_B,
+       SMZ_VR_WIDE_BN, SMZ_VR_LAST_A, SMZ_VR_LAST_B, SMZ_VR_LAST_BN };
+enum { SMZ_V_TRANS_BASE = 0, SMZ_V_PRED_BASE = 26, SMZ_V_REP_BASE = 64, SMZ_V_OFFSETS = 80 };
+typedef struct smz_vision_desc {
+    int32_t A, S, H, L;    /* actions, support size (state_space_dimensions), tower width, number_of_hidden_layer */
+    int32_t OP;            /* padded tower output width (64) */
+    int32_t total_floats;  /* size of the packed buffer */
+    int32_t off[SMZ_V_OFFSETS];
+} smz_vision_desc;
+/* Fills OP, total_floats and off[] from A/S/H/L.  SMZ_ERR_INVALID when A, S or H exceed 64 (one neuron per lane). */
+int smz_vision_layout(smz_vision_desc *desc);
+/* representation + root prediction: frames_dev [B,3,98,98] f32 -> hidden_out_dev [B,147] (scaled per pixel across
+ * channels), policy_out_dev [B,A] (softmax).  One 256-thread workgroup per frame. */
+int smz_vision_initial(const smz_vision_desc *desc, const float *weights_dev, const float *frames_dev,
+                       float *hidden_out_dev, float *policy_out_dev, int B, smz_stream stream);
+/* recurrent step for all trees, one wavefront per leaf: parent_hidden_dev [B,ld] (first 147 floats of each row),
+ * last_action_dev [B], branch_dev [B] as written by smz_select -> hidden_out_dev [B,147], reward_out_dev [B] (0 on the
+ * afterstate branch), policy_out_dev [B,A], value_out_dev [B].  The action enters as the constant plane (a+1)/A
+ * (muzero_model.py:511-522). */
+int smz_vision_recurrent(const smz_vision_desc *desc, const float *weights_dev, const float *parent_hidden_dev, int ld,
+                         const int32_t *last_action_dev, const uint8_t *branch_dev, float *hidden_out_dev,
+                         float *reward_out_dev, float *policy_out_dev, float *value_out_dev, int B, smz_stream stream);
+
 /* The whole Monte_carlo_tree_search.run (mcts:311-349) of every tree in ONE launch, for `mlp_model` heads that fit
  * in LDS: representation + root prediction, root expansion and noise, then num_simulations x (select, the pair of
  * networks the leaf needs, expansion, backup).  Network weights are staged once per workgroup; leaf hand-off and

@@ -34,6 +34,12 @@ class MlpDesc(C.Structure):
                 ("OP", C.c_int32), ("total_floats", C.c_int32), ("off", C.c_int32 * 30)]
 
 
+class VisionDesc(C.Structure):
+    """smz_vision_desc (include/smz.h): dimensions + float offsets of the packed vision_model weight buffer."""
+    _fields_ = [("A", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("OP", C.c_int32),
+                ("total_floats", C.c_int32), ("off", C.c_int32 * 80)]
+
+
 class NodeView(C.Structure):
     _fields_ = [("visit_count", C.c_int32), ("value_sum", C.c_float), ("reward", C.c_float), ("prior", C.c_float),
                 ("child_base", C.c_int32), ("action", C.c_int32)]
@@ -66,6 +72,9 @@ SIGNATURES = {
     "smz_mlp_layout": (C.c_int, [C.POINTER(MlpDesc)]),
     "smz_mlp_initial": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, C.c_int, _P]),
     "smz_mlp_recurrent": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "smz_vision_layout": (C.c_int, [C.POINTER(VisionDesc)]),
+    "smz_vision_initial": (C.c_int, [C.POINTER(VisionDesc), _P, _P, _P, _P, C.c_int, _P]),
+    "smz_vision_recurrent": (C.c_int, [C.POINTER(VisionDesc), _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_search_mlp": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, _P]),
     "smz_cartpole_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_traj_floats": (C.c_int, [C.c_int, C.c_int]),

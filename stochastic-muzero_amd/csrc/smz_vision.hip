@@ -1,0 +1,445 @@
+// smz_vision.hip -- fused head kernels of the `vision_model` family (C ABI: smz_vision_layout / _initial / _recurrent).
+//
+// What they replace: the five *_inference calls of the reference on its ResNet-v2 family
+// (neural_network_vision_model.py:41-515 through muzero_model.py:802-909), which per leaf is a chain of ~60 tiny
+// convolutions / batch-norms / linears on a 3x7x7 hidden state -- hopelessly launch-bound as library calls (measured:
+// 4.4 ms per simulation round at 1024 trees through torch-ROCm modules).  Here one wavefront evaluates one leaf:
+//   lane p < 49 <-> pixel (p / 7, p % 7); the 3 channels of a pixel live in that lane's registers;
+//   3x3 convolutions read their 9 neighbours as 16-byte LDS loads from a zero-bordered 9x9 plane of float4
+//   (c0,c1,c2,action plane); the 81/108 convolution weights of a layer are wave-uniform and come in through SGPRs;
+//   the 147 -> H -> S/A towers reuse the MLP family's dense() (one output neuron per lane, weights streamed from
+//   L2 in the 4-way interleaved layout), ReLU instead of ELU.
+// The representation network (98x98x3 frame -> 3x7x7) runs once per search: one 256-thread workgroup per frame with
+// all feature maps in LDS.
+//
+// Eval-mode batch-norm is folded on the host to y = x * scale + shift exactly as ATen does on the CPU
+// (scale = weight / sqrt(var + eps), shift = bias - mean * scale); multiply and add stay separate instructions.
+// Floating-point parity class: 2e-5 on hidden planes / policies against the reference's recorded outputs
+// (tests/test_gpu_vision.py), like the MLP family.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/smz.h"
+#include "smz_mlp_device.hpp"
+
+using namespace smz_mlp;
+
+namespace {
+
+constexpr int kC = 3, kN = 7, kPix = kN * kN, kFlat = kC * kPix, kFlat4 = 148, kPad = kN + 2;
+constexpr int kFrame = 98;
+
+// -------------------------------------------------------------------------------------------------------------------
+// wave-per-leaf pieces
+// -------------------------------------------------------------------------------------------------------------------
+struct WaveLds {
+    float4 plane[kPad * kPad];   // zero border, interior written per layer
+    float flat[kFlat4];          // flattened 1x1-conv output, channel major (torch's Flatten of [3,7,7])
+    float hid[2][64];            // tower activations (ping-pong)
+};
+
+__device__ inline const float *uniform_ptr(const float *base, int off) {
+    return base + __builtin_amdgcn_readfirstlane(off);
+}
+
+// out[oc] = sum_{tap, ic} w[oc][ic][tap] * plane[pixel + tap][ic]; CIN = 3 or 4 (4th = action plane)
+template <int CIN>
+__device__ inline void conv3x3(const float4 *plane, int pp, const float *__restrict__ w, float (&out)[kC]) {
+#pragma unroll
+    for (int oc = 0; oc < kC; oc++) out[oc] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const float4 v = plane[pp + (t / 3 - 1) * kPad + (t % 3 - 1)];
+#pragma unroll
+        for (int oc = 0; oc < kC; oc++) {
+            out[oc] = fmaf(w[(oc * CIN + 0) * 9 + t], v.x, out[oc]);
+            out[oc] = fmaf(w[(oc * CIN + 1) * 9 + t], v.y, out[oc]);
+            out[oc] = fmaf(w[(oc * CIN + 2) * 9 + t], v.z, out[oc]);
+            if (CIN == 4) out[oc] = fmaf(w[(oc * CIN + 3) * 9 + t], v.w, out[oc]);
+        }
+    }
+}
+
+__device__ inline void bn_relu_store(float4 *plane, int pp, bool active, const float (&t)[kC], const float *__restrict__ bn) {
+    float u[kC];
+#pragma unroll
+    for (int c = 0; c < kC; c++) u[c] = fmaxf(t[c] * bn[c] + bn[kC + c], 0.f);
+    if (active) plane[pp] = make_float4(u[0], u[1], u[2], 0.f);
+    lds_sync();
+}
+
+// v2 residual block with ONE batch-norm and convA used twice (neural_network_vision_model.py:41-79)
+__device__ inline void residual_block(float4 *plane, int pp, bool active, const float *__restrict__ wa,
+                                      const float *__restrict__ wb, const float *__restrict__ bn, float (&t)[kC]) {
+    float c[kC];
+    bn_relu_store(plane, pp, active, t, bn);
+    conv3x3<kC>(plane, pp, wa, c);
+    lds_sync();                               // every lane has read its neighbours before the plane is rewritten
+    bn_relu_store(plane, pp, active, c, bn);
+    conv3x3<kC>(plane, pp, wb, c);
+    lds_sync();
+    bn_relu_store(plane, pp, active, c, bn);
+    conv3x3<kC>(plane, pp, wa, c);
+    lds_sync();
+#pragma unroll
+    for (int k = 0; k < kC; k++) t[k] = c[k] + t[k];
+}
+
+// per-pixel min-max scaling across the channels (scale_to_bound_action with dim=1 on [B,3,7,7]: :494-503)
+__device__ inline void scale_channels(float (&t)[kC]) {
+    const float mn = fminf(fminf(t[0], t[1]), t[2]), mx = fmaxf(fmaxf(t[0], t[1]), t[2]);
+    float sc = mx - mn;
+    if (sc < 1e-5f) sc += 1e-5f;
+#pragma unroll
+    for (int c = 0; c < kC; c++) t[c] = (t[c] - mn) / sc;
+}
+
+// 1x1 convolution (with bias) of CIN input channels -> flattened [3*49] activations in LDS
+template <int CIN>
+__device__ inline void mix_to_flat(float *flat, int p, bool active, const float (&x)[4], const float *__restrict__ w,
+                                   const float *__restrict__ b) {
+#pragma unroll
+    for (int oc = 0; oc < kC; oc++) {
+        float s = 0.f;
+#pragma unroll
+        for (int ic = 0; ic < CIN; ic++) s = fmaf(w[oc * CIN + ic], x[ic], s);
+        s += b[oc];
+        if (active) flat[oc * kPix + p] = s;
+    }
+    lds_sync();
+}
+
+// Linear(147,H) relu [Linear(H,H) relu] x L Linear(H,n_out): off[0..5] = W1,b1,Wm,bm,Wo,bo (float offsets)
+__device__ inline void tower(const float *weights, const int32_t *off, WaveLds &l, const smz_vision_desc &d, int lane,
+                             float (&acc)[1][1]) {
+    const int K4h = up4(d.H);
+    {
+        const float *W[1] = {weights + off[0]}, *Bv[1] = {weights + off[1]}, *Ac[1] = {l.flat};
+        dense<1, 1>(W, Bv, Ac, kFlat4, d.OP, lane, acc);
+    }
+    int cur = 0;
+    l.hid[0][lane] = lane < d.H ? fmaxf(acc[0][0], 0.f) : 0.f;
+    lds_sync();
+    for (int i = 0; i < d.L; i++) {
+        const float *W[1] = {weights + off[2]}, *Bv[1] = {weights + off[3]}, *Ac[1] = {l.hid[cur]};
+        dense<1, 1>(W, Bv, Ac, K4h, d.OP, lane, acc);
+        cur ^= 1;
+        l.hid[cur][lane] = lane < d.H ? fmaxf(acc[0][0], 0.f) : 0.f;
+        lds_sync();
+    }
+    const float *W[1] = {weights + off[4]}, *Bv[1] = {weights + off[5]}, *Ac[1] = {l.hid[cur]};
+    dense<1, 1>(W, Bv, Ac, K4h, d.OP, lane, acc);
+}
+
+// prediction / afterstate prediction on the hidden state in t (registers): policy (softmax) to dst_policy, returns value
+__device__ inline float predict(const float *weights, const smz_vision_desc &d, int net /*SMZ_V_PRE or SMZ_V_APR*/,
+                                WaveLds &l, int lane, int p, int pp, bool active, float (&t)[kC], float *dst_policy,
+                                bool want_value) {
+    const int32_t *o = d.off + SMZ_V_PRED_BASE + (net - SMZ_V_PRE) * SMZ_V_PRED_STRIDE;
+    const float *wa = uniform_ptr(weights, o[SMZ_VP_RES_A]), *wb = uniform_ptr(weights, o[SMZ_VP_RES_B]);
+    const float *bn = uniform_ptr(weights, o[SMZ_VP_RES_BN]);
+    for (int i = 0; i < d.L; i++) residual_block(l.plane, pp, active, wa, wb, bn, t);
+    const float x[4] = {t[0], t[1], t[2], 0.f};
+    float acc[1][1];
+    float value = 0.f;
+    if (want_value) {
+        mix_to_flat<kC>(l.flat, p, active, x, uniform_ptr(weights, o[SMZ_VP_VMIX_W]), uniform_ptr(weights, o[SMZ_VP_VMIX_B]));
+        tower(weights, o + SMZ_VP_VTOWER, l, d, lane, acc);
+        value = decode_lanes<1>(acc[0], 0, d.S, lane);
+        lds_sync();
+    }
+    mix_to_flat<kC>(l.flat, p, active, x, uniform_ptr(weights, o[SMZ_VP_PMIX_W]), uniform_ptr(weights, o[SMZ_VP_PMIX_B]));
+    tower(weights, o + SMZ_VP_PTOWER, l, d, lane, acc);
+    softmax_lanes<1>(acc[0], d.A, lane, dst_policy);
+    return value;
+}
+
+__device__ inline void zero_wave_lds(WaveLds &l, int lane) {
+    for (int i = lane; i < kPad * kPad; i += kWave) l.plane[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = lane; i < kFlat4; i += kWave) l.flat[i] = 0.f;
+    lds_sync();
+}
+
+constexpr int kRecWaves = 4;
+
+// One wavefront per leaf: (afterstate) dynamics + (afterstate) prediction, selected by the leaf's branch flag
+// (monte_carlo_tree_search.py:333-342).  parent_hidden [B, ld] (first 147 floats used), last_action [B], branch [B].
+__global__ void __launch_bounds__(kRecWaves *kWave) k_vision_recurrent(
+    smz_vision_desc d, const float *__restrict__ weights, const float *__restrict__ parent_hidden, int ld,
+    const int32_t *__restrict__ last_action, const uint8_t *__restrict__ branch, float *__restrict__ hidden_out,
+    float *__restrict__ reward_out, float *__restrict__ policy_out, float *__restrict__ value_out, int B) {
+    __shared__ WaveLds lds[kRecWaves];
+    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int row = blockIdx.x * kRecWaves + wave;
+    if (row >= B) return;                                   // wave-uniform
+    WaveLds &l = lds[wave];
+    zero_wave_lds(l, lane);
+    const bool active = lane < kPix;
+    const int p = active ? lane : kPix - 1, pp = (p / kN + 1) * kPad + (p % kN + 1);
+    const bool dyn = __builtin_amdgcn_readfirstlane((int)branch[row]) != 0;     // uniform: picks SGPR weight pointers
+    const float a_plane = (float)(last_action[row] + 1) / (float)d.A;         // muzero_model.py:511-522
+    const float *hrow = parent_hidden + (size_t)row * ld;
+    float x[4] = {hrow[p], hrow[kPix + p], hrow[2 * kPix + p], a_plane};
+    const int32_t *o = d.off + SMZ_V_TRANS_BASE + (dyn ? 0 : SMZ_V_TRANS_STRIDE);
+
+    // reward branch first (it reads x only): conv1x1(4->3) -> flatten -> tower -> support decode
+    float reward = 0.f;
+    if (dyn) {
+        float acc[1][1];
+        mix_to_flat<4>(l.flat, p, active, x, uniform_ptr(weights, o[SMZ_VT_MIX_W]), uniform_ptr(weights, o[SMZ_VT_MIX_B]));
+        tower(weights, o + SMZ_VT_TOWER, l, d, lane, acc);
+        reward = decode_lanes<1>(acc[0], 0, d.S, lane);
+        lds_sync();
+    }
+    // next state: conv3x3(4->3) bn relu [block] x L relu, scaled per pixel
+    if (active) l.plane[pp] = make_float4(x[0], x[1], x[2], x[3]);
+    lds_sync();
+    float t[kC];
+    conv3x3<4>(l.plane, pp, uniform_ptr(weights, o[SMZ_VT_CONV_IN]), t);
+    lds_sync();
+    {
+        const float *bn = uniform_ptr(weights, o[SMZ_VT_BN_IN]);
+#pragma unroll
+        for (int c = 0; c < kC; c++) t[c] = fmaxf(t[c] * bn[c] + bn[kC + c], 0.f);
+    }
+    {
+        const float *wa = uniform_ptr(weights, o[SMZ_VT_RES_A]), *wb = uniform_ptr(weights, o[SMZ_VT_RES_B]);
+        const float *bn = uniform_ptr(weights, o[SMZ_VT_RES_BN]);
+        for (int i = 0; i < d.L; i++) residual_block(l.plane, pp, active, wa, wb, bn, t);
+    }
+#pragma unroll
+    for (int c = 0; c < kC; c++) t[c] = fmaxf(t[c], 0.f);
+    scale_channels(t);
+    if (active) {
+        float *ho = hidden_out + (size_t)row * kFlat;
+        ho[p] = t[0]; ho[kPix + p] = t[1]; ho[2 * kPix + p] = t[2];
+    }
+    const float value = predict(weights, d, dyn ? SMZ_V_PRE : SMZ_V_APR, l, lane, p, pp, active, t,
+                                policy_out + (size_t)row * d.A, true);
+    if (lane == 0) {
+        reward_out[row] = reward;
+        value_out[row] = value;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// representation: one workgroup per frame, feature maps in LDS
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int kRepThreads = 256;
+constexpr int kMaxMap = 49 * 49;                 // largest feature map (1 channel, 49x49)
+constexpr int kMaxPad = 51 * 51;                 // same, zero bordered (3 x 27 x 27 = 2187 is smaller)
+
+struct RepLds {
+    float t[kMaxMap];      // residual stream  [C][N][N]
+    float v[kMaxMap];      // convolution output
+    float u[kMaxPad];      // zero-bordered input of the next convolution [C][N+2][N+2]
+    WaveLds head;          // root prediction (wave 0)
+};
+
+// u <- border-padded f(src) for a [C][N][N] map; f = relu(bn(.)) when bn != nullptr, identity otherwise
+template <int C>
+__device__ inline void pad_store(float *u, const float *src, int N, const float *bn) {
+    const int P = N + 2;
+    for (int i = threadIdx.x; i < C * P * P; i += kRepThreads) {
+        const int c = i / (P * P), r = i % (P * P), y = r / P - 1, x = r % P - 1;
+        float val = 0.f;
+        if (y >= 0 && y < N && x >= 0 && x < N) {
+            val = src[(c * N + y) * N + x];
+            if (bn) val = fmaxf(val * bn[c] + bn[C + c], 0.f);
+        }
+        u[i] = val;
+    }
+    __syncthreads();
+}
+
+// dst[oc][y][x] = sum w[oc][ic][ky][kx] * u[ic][y*stride + ky][x*stride + kx]  (+ res[oc][y][x] if res)
+template <int CIN, int COUT>
+__device__ inline void conv_map(float *dst, const float *u, int Nin, int Nout, int stride, const float *w, const float *res) {
+    const int P = Nin + 2;
+    for (int i = threadIdx.x; i < Nout * Nout; i += kRepThreads) {
+        const int y = i / Nout, x = i % Nout;
+        float acc[COUT];
+#pragma unroll
+        for (int oc = 0; oc < COUT; oc++) acc[oc] = 0.f;
+#pragma unroll
+        for (int ic = 0; ic < CIN; ic++)
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const float val = u[(ic * P + y * stride + t / 3) * P + x * stride + t % 3];
+#pragma unroll
+                for (int oc = 0; oc < COUT; oc++) acc[oc] = fmaf(w[(oc * CIN + ic) * 9 + t], val, acc[oc]);
+            }
+#pragma unroll
+        for (int oc = 0; oc < COUT; oc++) {
+            const int j = (oc * Nout + y) * Nout + x;
+            dst[j] = res ? acc[oc] + res[j] : acc[oc];
+        }
+    }
+    __syncthreads();
+}
+
+template <int C>
+__device__ inline void residual_map(RepLds &l, int N, const float *wa, const float *wb, const float *bn) {
+    pad_store<C>(l.u, l.t, N, bn);
+    conv_map<C, C>(l.v, l.u, N, N, 1, wa, nullptr);
+    pad_store<C>(l.u, l.v, N, bn);
+    conv_map<C, C>(l.v, l.u, N, N, 1, wb, nullptr);
+    pad_store<C>(l.u, l.v, N, bn);
+    conv_map<C, C>(l.t, l.u, N, N, 1, wa, l.t);       // each thread reads and writes only its own pixels of t
+}
+
+// AvgPool2d(3, stride 2, padding 1), count_include_pad: sum of the zero-padded window / 9
+template <int C>
+__device__ inline void pool_map(RepLds &l, int Nin, int Nout) {
+    pad_store<C>(l.u, l.t, Nin, nullptr);
+    const int P = Nin + 2;
+    for (int i = threadIdx.x; i < C * Nout * Nout; i += kRepThreads) {
+        const int c = i / (Nout * Nout), r = i % (Nout * Nout), y = r / Nout, x = r % Nout;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; t++) s += l.u[(c * P + 2 * y + t / 3) * P + 2 * x + t % 3];
+        l.t[i] = s / 9.0f;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kRepThreads) k_vision_initial(smz_vision_desc d, const float *__restrict__ weights,
+                                                                const float *__restrict__ frames,
+                                                                float *__restrict__ hidden_out,
+                                                                float *__restrict__ policy_out) {
+    __shared__ RepLds l;
+    const int row = blockIdx.x;
+    const float *f = frames + (size_t)row * 3 * kFrame * kFrame;
+    const int32_t *o = d.off + SMZ_V_REP_BASE;
+    // stem: conv3x3 stride 2 pad 1, 3 -> 1 channels, 98 -> 49, straight from global memory
+    {
+        const float *w = weights + o[SMZ_VR_STEM];
+        for (int i = threadIdx.x; i < 49 * 49; i += kRepThreads) {
+            const int y = i / 49, x = i % 49;
+            float acc = 0.f;
+#pragma unroll
+            for (int ic = 0; ic < 3; ic++)
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    const int yy = 2 * y - 1 + t / 3, xx = 2 * x - 1 + t % 3;
+                    const float val = (yy >= 0 && yy < kFrame && xx >= 0 && xx < kFrame) ? f[(ic * kFrame + yy) * kFrame + xx] : 0.f;
+                    acc = fmaf(w[ic * 9 + t], val, acc);
+                }
+            l.t[i] = acc;
+        }
+        __syncthreads();
+    }
+    {
+        const float *wa = weights + o[SMZ_VR_NARROW_A], *wb = weights + o[SMZ_VR_NARROW_B], *bn = weights + o[SMZ_VR_NARROW_BN];
+        residual_map<1>(l, 49, wa, wb, bn);
+        residual_map<1>(l, 49, wa, wb, bn);
+    }
+    // widen: conv3x3 stride 2, 1 -> 3 channels, 49 -> 25
+    pad_store<1>(l.u, l.t, 49, nullptr);
+    conv_map<1, 3>(l.v, l.u, 49, 25, 2, weights + o[SMZ_VR_WIDEN], nullptr);
+    for (int i = threadIdx.x; i < 3 * 25 * 25; i += kRepThreads) l.t[i] = l.v[i];
+    __syncthreads();
+    {
+        const float *wa = weights + o[SMZ_VR_WIDE_A], *wb = weights + o[SMZ_VR_WIDE_B], *bn = weights + o[SMZ_VR_WIDE_BN];
+        residual_map<3>(l, 25, wa, wb, bn);
+        residual_map<3>(l, 25, wa, wb, bn);
+        pool_map<3>(l, 25, 13);
+        residual_map<3>(l, 13, wa, wb, bn);
+        residual_map<3>(l, 13, wa, wb, bn);
+        residual_map<3>(l, 13, wa, wb, bn);
+        pool_map<3>(l, 13, 7);
+    }
+    residual_map<3>(l, 7, weights + o[SMZ_VR_LAST_A], weights + o[SMZ_VR_LAST_B], weights + o[SMZ_VR_LAST_BN]);
+    // wave 0: per-pixel scaling, hidden state out, root policy (the root value is discarded, mcts:319-321)
+    if (threadIdx.x < kWave) {
+        const int lane = threadIdx.x;
+        const bool active = lane < kPix;
+        const int p = active ? lane : kPix - 1, pp = (p / kN + 1) * kPad + (p % kN + 1);
+        float t[kC] = {l.t[p], l.t[kPix + p], l.t[2 * kPix + p]};
+        scale_channels(t);
+        if (active) {
+            float *ho = hidden_out + (size_t)row * kFlat;
+            ho[p] = t[0]; ho[kPix + p] = t[1]; ho[2 * kPix + p] = t[2];
+        }
+        zero_wave_lds(l.head, lane);
+        predict(weights, d, SMZ_V_PRE, l.head, lane, p, pp, active, t, policy_out + (size_t)row * d.A, false);
+    }
+}
+
+int fill_layout(smz_vision_desc *d) {
+    const int OP = kWave, K4h = up4(d->H);
+    int off = 0;
+    auto take = [&](int idx, int floats) { d->off[idx] = off; off += up4(floats); };
+    auto take_tower = [&](int base) {
+        take(base + 0, kFlat4 * OP); take(base + 1, OP);
+        take(base + 2, K4h * OP);    take(base + 3, OP);
+        take(base + 4, K4h * OP);    take(base + 5, OP);
+    };
+    for (int i = 0; i < SMZ_V_OFFSETS; i++) d->off[i] = 0;
+    for (int n = 0; n < 2; n++) {            // dynamics, afterstate dynamics
+        const int b = SMZ_V_TRANS_BASE + n * SMZ_V_TRANS_STRIDE;
+        take(b + SMZ_VT_CONV_IN, 3 * 4 * 9); take(b + SMZ_VT_BN_IN, 6);
+        take(b + SMZ_VT_RES_A, 81); take(b + SMZ_VT_RES_B, 81); take(b + SMZ_VT_RES_BN, 6);
+        take(b + SMZ_VT_MIX_W, 12); take(b + SMZ_VT_MIX_B, 3);
+        take_tower(b + SMZ_VT_TOWER);
+    }
+    for (int n = 0; n < 2; n++) {            // prediction, afterstate prediction
+        const int b = SMZ_V_PRED_BASE + n * SMZ_V_PRED_STRIDE;
+        take(b + SMZ_VP_RES_A, 81); take(b + SMZ_VP_RES_B, 81); take(b + SMZ_VP_RES_BN, 6);
+        take(b + SMZ_VP_VMIX_W, 9); take(b + SMZ_VP_VMIX_B, 3);
+        take_tower(b + SMZ_VP_VTOWER);
+        take(b + SMZ_VP_PMIX_W, 9); take(b + SMZ_VP_PMIX_B, 3);
+        take_tower(b + SMZ_VP_PTOWER);
+    }
+    const int r = SMZ_V_REP_BASE;
+    take(r + SMZ_VR_STEM, 27);
+    take(r + SMZ_VR_NARROW_A, 9); take(r + SMZ_VR_NARROW_B, 9); take(r + SMZ_VR_NARROW_BN, 2);
+    take(r + SMZ_VR_WIDEN, 27);
+    take(r + SMZ_VR_WIDE_A, 81); take(r + SMZ_VR_WIDE_B, 81); take(r + SMZ_VR_WIDE_BN, 6);
+    take(r + SMZ_VR_LAST_A, 81); take(r + SMZ_VR_LAST_B, 81); take(r + SMZ_VR_LAST_BN, 6);
+    d->OP = OP;
+    d->total_floats = off;
+    return SMZ_OK;
+}
+
+int vision_check(const smz_vision_desc *d, const void *w) {
+    if (!d || !w) return SMZ_ERR_INVALID;
+    smz_vision_desc t = *d;
+    if (smz_vision_layout(&t) != SMZ_OK || t.total_floats != d->total_floats || t.OP != d->OP) return SMZ_ERR_INVALID;
+    for (int i = 0; i < SMZ_V_OFFSETS; i++)
+        if (t.off[i] != d->off[i]) return SMZ_ERR_INVALID;
+    return SMZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smz_vision_layout(smz_vision_desc *d) {
+    // one output neuron per lane in the towers: widths up to 64; the reference's default is H = 64
+    if (!d || d->A < 1 || d->A > kWave || d->S < 1 || d->S > kWave || d->H < 1 || d->H > kWave || d->L < 0) return SMZ_ERR_INVALID;
+    return fill_layout(d);
+}
+
+int smz_vision_initial(const smz_vision_desc *d, const float *weights_dev, const float *frames_dev, float *hidden_out_dev,
+                       float *policy_out_dev, int B, smz_stream stream) {
+    if (vision_check(d, weights_dev) != SMZ_OK || !frames_dev || !hidden_out_dev || !policy_out_dev || B < 1) return SMZ_ERR_INVALID;
+    hipLaunchKernelGGL(k_vision_initial, dim3(B), dim3(kRepThreads), 0, (hipStream_t)stream, *d, weights_dev, frames_dev,
+                       hidden_out_dev, policy_out_dev);
+    return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
+}
+
+int smz_vision_recurrent(const smz_vision_desc *d, const float *weights_dev, const float *parent_hidden_dev, int ld,
+                         const int32_t *last_action_dev, const uint8_t *branch_dev, float *hidden_out_dev,
+                         float *reward_out_dev, float *policy_out_dev, float *value_out_dev, int B, smz_stream stream) {
+    if (vision_check(d, weights_dev) != SMZ_OK || !parent_hidden_dev || ld < kFlat || !last_action_dev || !branch_dev ||
+        !hidden_out_dev || !reward_out_dev || !policy_out_dev || !value_out_dev || B < 1)
+        return SMZ_ERR_INVALID;
+    hipLaunchKernelGGL(k_vision_recurrent, dim3((B + kRecWaves - 1) / kRecWaves), dim3(kRecWaves * kWave), 0,
+                       (hipStream_t)stream, *d, weights_dev, parent_hidden_dev, ld, last_action_dev, branch_dev,
+                       hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B);
+    return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
+}
+
+}  // extern "C"

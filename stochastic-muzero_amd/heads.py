@@ -207,6 +207,120 @@ class HipMlpHeads:
         return hidden, reward, policy, value
 
 
+class HipVisionHeads:
+    """`vision_model` heads (the reference's ResNet-v2 family, compat_vision.py) evaluated by hand-written HIP kernels:
+    smz_vision_initial (one workgroup per frame) and smz_vision_recurrent (one wavefront per leaf).  Weights are
+    packed once from the five modules into the layout documented at smz_vision_desc (include/smz.h)."""
+    wants_mlp_input, wants_parent_hidden = False, True
+    is_rgb = True
+    # index constants of include/smz.h
+    _T = dict(CONV_IN=0, BN_IN=1, RES_A=2, RES_B=3, RES_BN=4, MIX_W=5, MIX_B=6, TOWER=7, STRIDE=13, BASE=0)
+    _P = dict(RES_A=0, RES_B=1, RES_BN=2, VMIX_W=3, VMIX_B=4, VTOWER=5, PMIX_W=11, PMIX_B=12, PTOWER=13, STRIDE=19, BASE=26)
+    _R = dict(STEM=0, NARROW_A=1, NARROW_B=2, NARROW_BN=3, WIDEN=4, WIDE_A=5, WIDE_B=6, WIDE_BN=7, LAST_A=8, LAST_B=9,
+              LAST_BN=10, BASE=64)
+
+    def __init__(self, representation, prediction, afterstate_prediction, afterstate_dynamics, dynamics, num_actions,
+                 support_size, device):
+        import numpy as np
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        tower = dynamics.sequential_reward[2]
+        linears = [m for m in tower if isinstance(m, torch.nn.Linear)]
+        self.A, self.Ssup, self.H = int(num_actions), int(support_size), int(linears[0].out_features)
+        self.L = (len(tower) - 3) // 2                  # [Linear, relu] + [Linear, relu] * L + [Linear]
+        if linears[0].in_features != 147 or not getattr(representation, "down_sampling", True):
+            raise ValueError("the HIP vision kernels cover the down-sampling family (98x98x3 frames, 3x7x7 hidden state)")
+        d = _lib.VisionDesc(self.A, self.Ssup, self.H, self.L)
+        if self.lib.smz_vision_layout(C.byref(d)) != 0:
+            raise ValueError("vision heads outside the kernel's limits (A, S, H <= 64)")
+        self.desc, self.S = d, 147
+        buf = np.zeros(d.total_floats, np.float32)
+        OP = d.OP
+
+        def put(idx, arr):
+            a = np.asarray(arr.detach().cpu().numpy() if torch.is_tensor(arr) else arr, np.float32).reshape(-1)
+            buf[d.off[idx]:d.off[idx] + a.size] = a
+
+        def put_bn(idx, bn):
+            # ATen's CPU eval-mode batch-norm: alpha = weight * (1 / sqrt(var + eps)), beta = bias - mean * alpha (float32)
+            var, mean = bn.running_var.detach().cpu().numpy().astype(np.float32), bn.running_mean.detach().cpu().numpy().astype(np.float32)
+            invstd = (np.float32(1) / np.sqrt(var + np.float32(bn.eps))).astype(np.float32)
+            w = bn.weight.detach().cpu().numpy().astype(np.float32) if bn.affine else np.ones_like(var)
+            b = bn.bias.detach().cpu().numpy().astype(np.float32) if bn.affine else np.zeros_like(var)
+            alpha = (w * invstd).astype(np.float32)
+            put(idx, np.concatenate([alpha, (b - mean * alpha).astype(np.float32)]))
+
+        def put_linear(idx, lin):
+            W, b = lin.weight.detach().cpu().numpy().astype(np.float32), lin.bias.detach().cpu().numpy().astype(np.float32)
+            O, K = W.shape
+            K4 = (K + 3) & ~3
+            Wt = np.zeros((K4, OP), np.float32)
+            Wt[:K, :O] = W.T
+            put(idx, Wt.reshape(K4 // 4, 4, OP).transpose(0, 2, 1))
+            put(idx + 1, b)
+
+        def put_tower(idx, seq):
+            lins = [m for m in seq if isinstance(m, torch.nn.Linear)]
+            put_linear(idx, lins[0])
+            if self.L > 0:
+                put_linear(idx + 2, lins[1])
+            put_linear(idx + 4, lins[-1])
+
+        def put_block(ia, ib, ibn, block):
+            sc = block.sequential_container         # bn, relu, convA, bn, relu, convB, bn, relu, convA
+            put(ia, sc[2].weight); put(ib, sc[5].weight); put_bn(ibn, sc[0])
+
+        T, P, R = self._T, self._P, self._R
+        for n, mod in enumerate((dynamics, afterstate_dynamics)):
+            b = T["BASE"] + n * T["STRIDE"]
+            sc = mod.sequential_container           # conv, bn, relu, [block] * L, relu
+            put(b + T["CONV_IN"], sc[0].weight); put_bn(b + T["BN_IN"], sc[1])
+            if self.L > 0:
+                put_block(b + T["RES_A"], b + T["RES_B"], b + T["RES_BN"], sc[3])
+            if n == 0:
+                rw = mod.sequential_reward          # conv1x1, flatten, tower
+                put(b + T["MIX_W"], rw[0].weight); put(b + T["MIX_B"], rw[0].bias); put_tower(b + T["TOWER"], rw[2])
+        for n, mod in enumerate((prediction, afterstate_prediction)):
+            b = P["BASE"] + n * P["STRIDE"]
+            if self.L > 0:
+                put_block(b + P["RES_A"], b + P["RES_B"], b + P["RES_BN"], mod.resnet[0])
+            put(b + P["VMIX_W"], mod.nn_value[0].weight); put(b + P["VMIX_B"], mod.nn_value[0].bias)
+            put_tower(b + P["VTOWER"], mod.nn_value[2])
+            put(b + P["PMIX_W"], mod.nn_policy[0].weight); put(b + P["PMIX_B"], mod.nn_policy[0].bias)
+            put_tower(b + P["PTOWER"], mod.nn_policy[2])
+        down = representation.sequential_downsampler[0].sequential_container   # stem, R1, R1, widen, R2, R2, pool, R2 x3, pool
+        b = R["BASE"]
+        put(b + R["STEM"], down[0].weight); put_block(b + R["NARROW_A"], b + R["NARROW_B"], b + R["NARROW_BN"], down[1])
+        put(b + R["WIDEN"], down[3].weight); put_block(b + R["WIDE_A"], b + R["WIDE_B"], b + R["WIDE_BN"], down[4])
+        put_block(b + R["LAST_A"], b + R["LAST_B"], b + R["LAST_BN"], representation.sequential_downsampler[1])
+        self.weights = torch.from_numpy(buf).to(self.device)
+        self._buf = {}
+
+    def _out(self, name, shape, dtype=torch.float32):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._buf[name] = torch.empty(*shape, dtype=dtype, device=self.device)
+        return t
+
+    def initial(self, obs):
+        B = obs.shape[0]
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and tuple(obs.shape[1:]) == (3, 98, 98)
+        hidden, policy = self._out("h0", (B, 147)), self._out("p0", (B, self.A))
+        _lib.check(self.lib.smz_vision_initial(C.byref(self.desc), _ptr(self.weights), _ptr(obs), _ptr(hidden),
+                                               _ptr(policy), B, _stream(self.device)))
+        return hidden, policy
+
+    def recurrent(self, engine):
+        ph = engine.parent_hidden
+        B = ph.shape[0]
+        hidden, reward = self._out("h", (B, 147)), self._out("r", (B,))
+        policy, value = self._out("p", (B, self.A)), self._out("v", (B,))
+        _lib.check(self.lib.smz_vision_recurrent(C.byref(self.desc), _ptr(self.weights), _ptr(ph), ph.stride(0),
+                                                 _ptr(engine.last_action), _ptr(engine.branch), _ptr(hidden), _ptr(reward),
+                                                 _ptr(policy), _ptr(value), B, _stream(self.device)))
+        return hidden, reward, policy, value
+
+
 class ModuleHeads:
     """Heads given as five torch modules with the reference's signatures:
          representation(obs) -> hidden                                   (already scaled)

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import compat_mlp, compat_vision
-from .heads import MLP_ARRAYS, FusedMlpHeads, HipMlpHeads, ModuleHeads
+from .heads import MLP_ARRAYS, FusedMlpHeads, HipMlpHeads, HipVisionHeads, ModuleHeads
 
 _FUNCS = ("representation", "prediction", "afterstate_prediction", "afterstate_dynamics", "dynamics", "encoder")
 _FAMILY_MODULE = {"mlp_model": "neural_network_mlp_model", "lstm_model": "neural_network_lstm_model",
@@ -242,6 +242,10 @@ class Muzero:
                             H=self.hidden_layer_dimension, L=self.number_of_hidden_layer)
                 assert set(n + s for n in MLP_ARRAYS for s in ("_w", "_b")) <= set(arrays)
                 self._heads[key] = FusedMlpHeads(arrays, dims, device)
+            elif self.model_structure == "vision_model" and backend in ("auto", "hip"):
+                mods = [getattr(self, f + "_function") for f in _FUNCS[:5]]
+                self._heads[key] = HipVisionHeads(*mods, num_actions=self.action_dimension,
+                                                  support_size=self.state_dimension, device=device)
             else:
                 import copy
                 mods = [copy.deepcopy(getattr(self, f + "_function")) for f in _FUNCS[:5]]

@@ -383,3 +383,88 @@ def test_networks_too_large_for_lds_fall_back_to_gemm_heads():
     v = e.root_stats()[0]
     torch.cuda.synchronize()
     assert m._single is None and m._graph is not None and (v.sum(1) == 8).all()
+
+
+def _frame(seed):
+    return torch.tensor(np.random.RandomState(int(seed)).rand(1, 3, 98, 98).astype(np.float32))
+
+
+@pytest.mark.parametrize("backend", ["hip", "torch"])
+def test_vision_family_heads_on_gpu_match_the_reference_tape(backend):
+    """a22: the reference's ResNet-v2 family on the GPU -- the hand-written HIP kernels (HipVisionHeads:
+    smz_vision_initial / smz_vision_recurrent) and the torch-ROCm module path (ModuleHeads) -- vs every network call the
+    reference (torch CPU) recorded in vision_sims50.npz.  Accumulation orders differ from ATen's CPU kernels: 2e-5 on
+    hidden planes and policies, 5e-4 on decoded scalars (inverse-transform cancellation)."""
+    _, model_mod, _, _ = _mods()
+    cfg, data = gu.load("vision_sims50")
+    model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L1_seed0.npz"))
+    heads = model.heads("cuda:0", backend=backend)
+    assert type(heads).__name__ == {"hip": "HipVisionHeads", "torch": "ModuleHeads"}[backend] and heads.is_rgb
+    ncase, sims = data["tape_branch"].shape
+    obs = torch.cat([_frame(3000 + int(s)) for s in data["seed"]]).cuda()
+    hid, pol = heads.initial(obs)
+    torch.testing.assert_close(hid.cpu(), torch.from_numpy(data["root_hidden"]), rtol=0, atol=2e-5)
+    torch.testing.assert_close(pol.cpu(), torch.from_numpy(data["root_policy"]), rtol=0, atol=2e-5)
+    fe = _FakeEngine()
+    fe.B, fe.S = ncase * sims, 147
+    fe.parent_hidden = torch.from_numpy(data["tape_hidden_in"].reshape(fe.B, -1)).cuda().contiguous()
+    fe.last_action = torch.from_numpy(data["tape_action"].reshape(-1).astype(np.int32)).cuda()
+    fe.branch = torch.from_numpy(data["tape_branch"].reshape(-1).astype(np.uint8)).cuda()
+    h2, rw, p2, v2 = heads.recurrent(fe)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(fe.B, -1)), rtol=0, atol=2e-5)
+    torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(fe.B, -1)), rtol=0, atol=2e-5)
+    torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=1e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("backend", ["hip", "torch"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_vision_search_reproduces_the_reference_visit_counts(use_graph, backend):
+    """Whole searches (frames -> representation -> 16 simulations -> root statistics) with the L=2 batch-norm net:
+    tree i under numpy seed i on frame 4100+i, against the reference's own run (visionL2_sims16.npz).  Visit counts
+    are integers: equal unless a GPU/CPU rounding difference flips an arg-max, which these cases do not hit."""
+    mcts_mod, model_mod, _, _ = _mods()
+    cfg, data = gu.load("visionL2_sims16")
+    model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L2_bn.npz"))
+    B = data["seed"].shape[0]
+    obs = torch.cat([_frame(4100 + int(s)) for s in data["seed"]]).cuda()
+    m = mcts_mod.BatchedMCTS(B, num_simulations=int(cfg["num_simulations"]), maxium_action_sample=2,
+                             discount=float(cfg["discount"]), root_dirichlet_alpha=float(cfg["root_dirichlet_alpha"]),
+                             root_exploration_fraction=float(cfg["root_exploration_fraction"]), use_graph=use_graph)
+    m.seed(data["seed"].astype(np.uint64))
+    for _ in range(2 if use_graph else 1):       # second pass replays the captured graph
+        m.seed(data["seed"].astype(np.uint64))
+        eng = m.run(obs, model.heads("cuda:0", backend=backend), train=True)
+    visits, priors, root_value, _ = eng.root_stats()
+    torch.cuda.synchronize()
+    assert np.array_equal(visits.cpu().numpy(), data["root_visits"])
+    np.testing.assert_allclose(priors.cpu().numpy(), data["root_priors"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(root_value.cpu().numpy(), data["root_value"], rtol=1e-4, atol=5e-4)
+
+
+def test_hip_vision_heads_agree_with_the_torch_modules_on_a_large_batch():
+    """The L=2 net with non-trivial batch-norm statistics and 3 action planes: HIP kernels vs the same modules run by
+    torch-ROCm, 700 random leaves (both branches) and 64 frames.  Float tolerance 2e-5 / 5e-4 (decoded scalars)."""
+    _, model_mod, _, _ = _mods()
+    model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L2_bn.npz"))
+    hip, ref = model.heads("cuda:0", backend="hip"), model.heads("cuda:0", backend="torch")
+    g = torch.Generator().manual_seed(7)
+    frames = torch.rand(64, 3, 98, 98, generator=g).cuda()
+    h_hip, p_hip = hip.initial(frames)
+    h_ref, p_ref = ref.initial(frames)
+    torch.testing.assert_close(h_hip, h_ref, rtol=0, atol=2e-5)
+    torch.testing.assert_close(p_hip, p_ref, rtol=0, atol=2e-5)
+    fe = _FakeEngine()
+    fe.B, fe.S = 700, 147
+    fe.parent_hidden = torch.rand(700, 147, generator=g).cuda()
+    fe.last_action = torch.randint(0, 3, (700,), generator=g).int().cuda()
+    fe.branch = torch.randint(0, 2, (700,), generator=g).to(torch.uint8).cuda()
+    a = [t.clone() for t in hip.recurrent(fe)]
+    b = [t.clone() for t in ref.recurrent(fe)]
+    torch.cuda.synchronize()
+    torch.testing.assert_close(a[0], b[0], rtol=0, atol=2e-5)
+    torch.testing.assert_close(a[2], b[2], rtol=0, atol=2e-5)
+    torch.testing.assert_close(a[1], b[1], rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(a[3], b[3], rtol=1e-4, atol=5e-4)
+    assert (a[1][fe.branch == 0] == 0).all() and (a[1][fe.branch == 1] != 0).any()
