@@ -197,7 +197,7 @@ def main():
            "vs_baseline": None, "dtype": "f32 (tree values, heads) + f64 (pUCT scores, root priors) + i32 (counts)",
            "data": data_note,
            "config": {"workload": args.workload, "envs_per_gpu": B, "num_simulations": wl["sims"],
-                      "actions": wl["A"], "children_per_expansion": wl["K"], "hidden_floats": model.state_dimension,
+                      "actions": wl["A"], "children_per_expansion": wl["K"], "hidden_floats": int(groups[0].heads.S) if hasattr(groups[0].heads, "S") else model.state_dimension,
                       "rng": "per-tree MT19937 (numpy-legacy, parity mode)", "hip_graph": not args.no_graph,
                       "stream_groups": G, "heads": type(groups[0].heads).__name__,
                       "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}}

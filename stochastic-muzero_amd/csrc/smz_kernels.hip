@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/smz.h"
@@ -615,22 +616,30 @@ __global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int3
 
 // record layout per (step, env):
 //   [obs(obs_dim) | reward | terminated | policy(A) | action one-hot(A) | root_value | child_visits(A)]
+// One thread per float64 of the step's [B][F] slab: writes are contiguous across the whole slab and the observation
+// reads are contiguous per row, whatever obs_dim is (4 for CartPole, 28812 for a 98x98x3 frame).
 __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, int obs_dim, int A, const float *obs,
                                                    const float *reward, const uint8_t *terminated, const int32_t *action,
                                                    const double *policy, const double *child_visits,
                                                    const float *root_value, int B) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= B) return;
     const int F = obs_dim + 3 * A + 3;
-    double *r = traj + ((size_t)t * B + e) * F;
-    for (int i = 0; i < obs_dim; i++) r[i] = (double)obs[(size_t)e * obs_dim + i];
-    r[obs_dim] = reward ? (double)reward[e] : 0.0;
-    r[obs_dim + 1] = (terminated && terminated[e]) ? 1.0 : 0.0;
-    double *p = r + obs_dim + 2;
-    for (int a = 0; a < A; a++) p[a] = policy[(size_t)e * A + a];
-    for (int a = 0; a < A; a++) p[A + a] = (a == action[e]) ? 1.0 : 0.0;
-    p[2 * A] = (double)root_value[e];
-    for (int a = 0; a < A; a++) p[2 * A + 1 + a] = child_visits[(size_t)e * A + a];
+    const size_t total = (size_t)B * F;
+    double *slab = traj + (size_t)t * total;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i / F), k = (int)(i % F);
+        double v;
+        if (k < obs_dim) v = (double)obs[(size_t)e * obs_dim + k];
+        else if (k == obs_dim) v = reward ? (double)reward[e] : 0.0;
+        else if (k == obs_dim + 1) v = (terminated && terminated[e]) ? 1.0 : 0.0;
+        else {
+            const int j = k - obs_dim - 2;
+            if (j < A) v = policy[(size_t)e * A + j];
+            else if (j < 2 * A) v = (j - A == action[e]) ? 1.0 : 0.0;
+            else if (j == 2 * A) v = (double)root_value[e];
+            else v = child_visits[(size_t)e * A + (j - 2 * A - 1)];
+        }
+        slab[i] = v;
+    }
 }
 
 }  // namespace
@@ -1126,7 +1135,9 @@ int smz_traj_pack(double *traj_dev, int T, int t, int obs_dim, int A, const floa
     if (!traj_dev || !obs_dev || !action_dev || !policy_dev || !child_visits_dev || !root_value_dev || t < 0 || t >= T ||
         B < 1 || A < 1 || obs_dim < 1)
         return fail(SMZ_ERR_INVALID, "smz_traj_pack: bad argument%s");
-    hipLaunchKernelGGL(k_traj_pack, row_grid(B), dim3(256), 0, (hipStream_t)stream, traj_dev, T, t, obs_dim, A, obs_dev,
+    const size_t slab = (size_t)B * (obs_dim + 3 * A + 3);
+    const unsigned blocks = (unsigned)std::min<size_t>((slab + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_traj_pack, dim3(blocks), dim3(256), 0, (hipStream_t)stream, traj_dev, T, t, obs_dim, A, obs_dev,
                        reward_dev, terminated_dev, action_dev, policy_dev, child_visits_dev, root_value_dev, B);
     return launch_check();
 }

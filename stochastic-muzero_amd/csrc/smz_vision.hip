@@ -110,26 +110,48 @@ __device__ inline void mix_to_flat(float *flat, int p, bool active, const float 
     lds_sync();
 }
 
+// acc = bias[lane] + sum_k W[k][lane] * act[k], the arithmetic (order, packed even/odd accumulators) of smz_mlp::dense,
+// for weights that live in global memory / L2: the 16-byte weight loads of up to CH k-groups are issued back to back
+// before the first multiply-add, so a layer costs one or two L2 round trips instead of one per four k-groups (a leaf
+// wavefront is alone on its SIMD: nothing else hides that latency).
+template <int CH>
+__device__ inline float dense_stream(const float *__restrict__ W, const float *__restrict__ bias, const float *act, int K4,
+                                     int OP, int lane) {
+    const float4 *w4 = reinterpret_cast<const float4 *>(W) + lane;
+    const float4 *a4 = reinterpret_cast<const float4 *>(act);
+    v2f acc = {bias[lane], 0.f};
+    const int n = K4 >> 2;
+    for (int q0 = 0; q0 < n; q0 += CH) {
+        float4 w[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) w[j] = w4[(size_t)min(q0 + j, n - 1) * OP];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            if (q0 + j < n) {
+                const float4 a = a4[q0 + j];
+                acc = pk_fma(w[j].x, w[j].y, a.x, a.y, acc);
+                acc = pk_fma(w[j].z, w[j].w, a.z, a.w, acc);
+            }
+        }
+    }
+    return acc.x + acc.y;
+}
+
 // Linear(147,H) relu [Linear(H,H) relu] x L Linear(H,n_out): off[0..5] = W1,b1,Wm,bm,Wo,bo (float offsets)
 __device__ inline void tower(const float *weights, const int32_t *off, WaveLds &l, const smz_vision_desc &d, int lane,
                              float (&acc)[1][1]) {
     const int K4h = up4(d.H);
-    {
-        const float *W[1] = {weights + off[0]}, *Bv[1] = {weights + off[1]}, *Ac[1] = {l.flat};
-        dense<1, 1>(W, Bv, Ac, kFlat4, d.OP, lane, acc);
-    }
+    float y = dense_stream<19>(weights + off[0], weights + off[1], l.flat, kFlat4, d.OP, lane);
     int cur = 0;
-    l.hid[0][lane] = lane < d.H ? fmaxf(acc[0][0], 0.f) : 0.f;
+    l.hid[0][lane] = lane < d.H ? fmaxf(y, 0.f) : 0.f;
     lds_sync();
     for (int i = 0; i < d.L; i++) {
-        const float *W[1] = {weights + off[2]}, *Bv[1] = {weights + off[3]}, *Ac[1] = {l.hid[cur]};
-        dense<1, 1>(W, Bv, Ac, K4h, d.OP, lane, acc);
+        y = dense_stream<16>(weights + off[2], weights + off[3], l.hid[cur], K4h, d.OP, lane);
         cur ^= 1;
-        l.hid[cur][lane] = lane < d.H ? fmaxf(acc[0][0], 0.f) : 0.f;
+        l.hid[cur][lane] = lane < d.H ? fmaxf(y, 0.f) : 0.f;
         lds_sync();
     }
-    const float *W[1] = {weights + off[4]}, *Bv[1] = {weights + off[5]}, *Ac[1] = {l.hid[cur]};
-    dense<1, 1>(W, Bv, Ac, K4h, d.OP, lane, acc);
+    acc[0][0] = dense_stream<16>(weights + off[4], weights + off[5], l.hid[cur], K4h, d.OP, lane);
 }
 
 // prediction / afterstate prediction on the hidden state in t (registers): policy (softmax) to dst_policy, returns value

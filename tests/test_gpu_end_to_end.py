@@ -444,27 +444,42 @@ def test_vision_search_reproduces_the_reference_visit_counts(use_graph, backend)
 
 
 def test_hip_vision_heads_agree_with_the_torch_modules_on_a_large_batch():
-    """The L=2 net with non-trivial batch-norm statistics and 3 action planes: HIP kernels vs the same modules run by
-    torch-ROCm, 700 random leaves (both branches) and 64 frames.  Float tolerance 2e-5 / 5e-4 (decoded scalars)."""
+    """The L=2 net with non-trivial batch-norm statistics and 3 action planes: HIP kernels vs the same modules evaluated
+    by torch on the CPU (the arithmetic the reference's *_inference functions run, test_vision_family.py), 700 random
+    leaves of both branches and 24 frames.  Float tolerance 2e-5 / 5e-4 (decoded scalars)."""
     _, model_mod, _, _ = _mods()
     model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L2_bn.npz"))
-    hip, ref = model.heads("cuda:0", backend="hip"), model.heads("cuda:0", backend="torch")
+    hip = model.heads("cuda:0", backend="hip")
     g = torch.Generator().manual_seed(7)
-    frames = torch.rand(64, 3, 98, 98, generator=g).cuda()
-    h_hip, p_hip = hip.initial(frames)
-    h_ref, p_ref = ref.initial(frames)
-    torch.testing.assert_close(h_hip, h_ref, rtol=0, atol=2e-5)
-    torch.testing.assert_close(p_hip, p_ref, rtol=0, atol=2e-5)
+    frames = torch.rand(24, 3, 98, 98, generator=g)
+    h_hip, p_hip = hip.initial(frames.cuda())
+    with torch.no_grad():
+        h_ref = model.representation_function(frames)
+        p_ref = torch.softmax(model.prediction_function(h_ref)[0], -1)
+    torch.testing.assert_close(h_hip.cpu(), h_ref.reshape(24, -1), rtol=0, atol=2e-5)
+    torch.testing.assert_close(p_hip.cpu(), p_ref, rtol=0, atol=2e-5)
+    B, A = 700, 3
     fe = _FakeEngine()
-    fe.B, fe.S = 700, 147
-    fe.parent_hidden = torch.rand(700, 147, generator=g).cuda()
-    fe.last_action = torch.randint(0, 3, (700,), generator=g).int().cuda()
-    fe.branch = torch.randint(0, 2, (700,), generator=g).to(torch.uint8).cuda()
-    a = [t.clone() for t in hip.recurrent(fe)]
-    b = [t.clone() for t in ref.recurrent(fe)]
-    torch.cuda.synchronize()
-    torch.testing.assert_close(a[0], b[0], rtol=0, atol=2e-5)
-    torch.testing.assert_close(a[2], b[2], rtol=0, atol=2e-5)
-    torch.testing.assert_close(a[1], b[1], rtol=1e-4, atol=5e-4)
-    torch.testing.assert_close(a[3], b[3], rtol=1e-4, atol=5e-4)
-    assert (a[1][fe.branch == 0] == 0).all() and (a[1][fe.branch == 1] != 0).any()
+    fe.B, fe.S = B, 147
+    hidden = torch.rand(B, 3, 7, 7, generator=g)
+    action = torch.randint(0, A, (B,), generator=g)
+    branch = torch.randint(0, 2, (B,), generator=g).bool()
+    fe.parent_hidden = hidden.reshape(B, -1).cuda().contiguous()
+    fe.last_action = action.int().cuda()
+    fe.branch = branch.to(torch.uint8).cuda()
+    h2, rw, pol, val = (t.cpu() for t in hip.recurrent(fe))
+    with torch.no_grad():
+        plane = ((action.float() + 1) / A).view(B, 1, 1, 1).expand(B, 1, 7, 7)
+        r_logits, h_dyn = model.dynamics_function(hidden, plane)
+        h_aft = model.afterstate_dynamics_function(hidden, plane)
+        h_ref = torch.where(branch.view(B, 1, 1, 1), h_dyn, h_aft)
+        pp, vp = model.prediction_function(h_ref)
+        pa, va = model.afterstate_prediction_function(h_ref)
+        pol_ref = torch.softmax(torch.where(branch[:, None], pp, pa), -1)
+        val_ref = model.inverse_transform_with_support(torch.where(branch[:, None], vp, va)).flatten()
+        rw_ref = torch.where(branch, model.inverse_transform_with_support(r_logits).flatten(), torch.zeros(B))
+    torch.testing.assert_close(h2, h_ref.reshape(B, -1), rtol=0, atol=2e-5)
+    torch.testing.assert_close(pol, pol_ref, rtol=0, atol=2e-5)
+    torch.testing.assert_close(rw, rw_ref, rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(val, val_ref, rtol=1e-4, atol=5e-4)
+    assert (rw[~branch] == 0).all() and (rw[branch] != 0).any()
