@@ -1035,9 +1035,14 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
 #define SMZ_LAUNCH_SEARCH(UU)                                                                                          \
     SMZ_DISPATCH2(h->maxa, h->K, {                                                                                     \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU>),                              \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                   \
-            return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                                \
+        static size_t granted_dev[64] = {}; /* per instantiation and device: the opt-in is a host-side call */           \
+        size_t &granted = granted_dev[h->cfg.device & 63];                                                             \
+        if (lds > granted) {                                                                                           \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU>),                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)               \
+                return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                            \
+            granted = lds;                                                                                             \
+        }                                                                                                              \
         hipLaunchKernelGGL((k_search_mlp<MA, KS, UU>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream, P, \
                            *desc, weights_dev, obs_dev, train);                                                        \
     })

@@ -81,9 +81,19 @@ constexpr int kWavesPerWg = 8;
 
 template <typename Kern>
 int allow_lds(Kern kern, size_t bytes) {
-    // HIP caps dynamic LDS at 64 KB unless the kernel opts in (gfx950 has 160 KB per CU)
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes) == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
+    // HIP caps dynamic LDS at 64 KB unless the kernel opts in (gfx950 has 160 KB per CU).  The opt-in is a host-side
+    // runtime call: made once per kernel and size, not per launch.
+    static size_t granted[64] = {};     // per device (the attribute belongs to the device's code object)
+    static const void *who[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SMZ_ERR_HIP;
+    if (who[dev] == reinterpret_cast<const void *>(kern) && bytes <= granted[dev]) return SMZ_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
+        return SMZ_ERR_HIP;
+    who[dev] = reinterpret_cast<const void *>(kern);
+    granted[dev] = bytes;
+    return SMZ_OK;
 }
 
 }  // namespace
