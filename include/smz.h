@@ -242,9 +242,12 @@ typedef struct smz_vision_desc {
     int32_t A, S, H, L;    /* actions, support size (state_space_dimensions), tower width, number_of_hidden_layer */
     int32_t OP;            /* padded tower output width (64) */
     int32_t total_floats;  /* size of the packed buffer */
+    int32_t small_floats;  /* [0, small_floats): convolution / batch-norm / 1x1 pieces of the four recurrent nets,
+                              contiguous (staged in LDS by smz_vision_recurrent); towers and representation follow */
     int32_t off[SMZ_V_OFFSETS];
 } smz_vision_desc;
-/* Fills OP, total_floats and off[] from A/S/H/L.  SMZ_ERR_INVALID when A, S or H exceed 64 (one neuron per lane). */
+/* Fills OP, total_floats, small_floats and off[] from A/S/H/L.  SMZ_ERR_INVALID when A, S or H exceed 64 (one neuron
+ * per lane). */
 int smz_vision_layout(smz_vision_desc *desc);
 /* representation + root prediction: frames_dev [B,3,98,98] f32 -> hidden_out_dev [B,147] (scaled per pixel across
  * channels), policy_out_dev [B,A] (softmax).  One 256-thread workgroup per frame. */

@@ -37,7 +37,7 @@ class MlpDesc(C.Structure):
 class VisionDesc(C.Structure):
     """smz_vision_desc (include/smz.h): dimensions + float offsets of the packed vision_model weight buffer."""
     _fields_ = [("A", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("OP", C.c_int32),
-                ("total_floats", C.c_int32), ("off", C.c_int32 * 80)]
+                ("total_floats", C.c_int32), ("small_floats", C.c_int32), ("off", C.c_int32 * 80)]
 
 
 class NodeView(C.Structure):

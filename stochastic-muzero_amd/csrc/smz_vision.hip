@@ -6,7 +6,8 @@
 // 4.4 ms per simulation round at 1024 trees through torch-ROCm modules).  Here one wavefront evaluates one leaf:
 //   lane p < 49 <-> pixel (p / 7, p % 7); the 3 channels of a pixel live in that lane's registers;
 //   3x3 convolutions read their 9 neighbours as 16-byte LDS loads from a zero-bordered 9x9 plane of float4
-//   (c0,c1,c2,action plane); the 81/108 convolution weights of a layer are wave-uniform and come in through SGPRs;
+//   (c0,c1,c2,action plane); the 81/108 convolution weights of a layer are wave-uniform reads of the workgroup's LDS
+//   copy of the small pieces (the towers' matrices are far too large for that);
 //   the 147 -> H -> S/A towers reuse the MLP family's dense() (one output neuron per lane, weights streamed from
 //   L2 in the 4-way interleaved layout), ReLU instead of ELU.
 // The representation network (98x98x3 frame -> 3x7x7) runs once per search: one 256-thread workgroup per frame with
@@ -29,6 +30,7 @@ namespace {
 
 constexpr int kC = 3, kN = 7, kPix = kN * kN, kFlat = kC * kPix, kFlat4 = 148, kPad = kN + 2;
 constexpr int kFrame = 98;
+constexpr int kSmallMax = 1280;   // floats of convolution / batch-norm / 1x1 pieces of the four recurrent nets (1160 used)
 
 // -------------------------------------------------------------------------------------------------------------------
 // wave-per-leaf pieces
@@ -155,23 +157,24 @@ __device__ inline void tower(const float *weights, const int32_t *off, WaveLds &
 }
 
 // prediction / afterstate prediction on the hidden state in t (registers): policy (softmax) to dst_policy, returns value
-__device__ inline float predict(const float *weights, const smz_vision_desc &d, int net /*SMZ_V_PRE or SMZ_V_APR*/,
-                                WaveLds &l, int lane, int p, int pp, bool active, float (&t)[kC], float *dst_policy,
-                                bool want_value) {
+// `small`: where the convolution / batch-norm / 1x1 pieces are read from (the workgroup's LDS copy, or `weights`)
+__device__ inline float predict(const float *weights, const float *small, const smz_vision_desc &d,
+                                int net /*SMZ_V_PRE or SMZ_V_APR*/, WaveLds &l, int lane, int p, int pp, bool active,
+                                float (&t)[kC], float *dst_policy, bool want_value) {
     const int32_t *o = d.off + SMZ_V_PRED_BASE + (net - SMZ_V_PRE) * SMZ_V_PRED_STRIDE;
-    const float *wa = uniform_ptr(weights, o[SMZ_VP_RES_A]), *wb = uniform_ptr(weights, o[SMZ_VP_RES_B]);
-    const float *bn = uniform_ptr(weights, o[SMZ_VP_RES_BN]);
+    const float *wa = uniform_ptr(small, o[SMZ_VP_RES_A]), *wb = uniform_ptr(small, o[SMZ_VP_RES_B]);
+    const float *bn = uniform_ptr(small, o[SMZ_VP_RES_BN]);
     for (int i = 0; i < d.L; i++) residual_block(l.plane, pp, active, wa, wb, bn, t);
     const float x[4] = {t[0], t[1], t[2], 0.f};
     float acc[1][1];
     float value = 0.f;
     if (want_value) {
-        mix_to_flat<kC>(l.flat, p, active, x, uniform_ptr(weights, o[SMZ_VP_VMIX_W]), uniform_ptr(weights, o[SMZ_VP_VMIX_B]));
+        mix_to_flat<kC>(l.flat, p, active, x, uniform_ptr(small, o[SMZ_VP_VMIX_W]), uniform_ptr(small, o[SMZ_VP_VMIX_B]));
         tower(weights, o + SMZ_VP_VTOWER, l, d, lane, acc);
         value = decode_lanes<1>(acc[0], 0, d.S, lane);
         lds_sync();
     }
-    mix_to_flat<kC>(l.flat, p, active, x, uniform_ptr(weights, o[SMZ_VP_PMIX_W]), uniform_ptr(weights, o[SMZ_VP_PMIX_B]));
+    mix_to_flat<kC>(l.flat, p, active, x, uniform_ptr(small, o[SMZ_VP_PMIX_W]), uniform_ptr(small, o[SMZ_VP_PMIX_B]));
     tower(weights, o + SMZ_VP_PTOWER, l, d, lane, acc);
     softmax_lanes<1>(acc[0], d.A, lane, dst_policy);
     return value;
@@ -185,6 +188,20 @@ __device__ inline void zero_wave_lds(WaveLds &l, int lane) {
 
 constexpr int kRecWaves = 4;
 
+#ifdef SMZ_VISION_STAMPS        // tools/vision_probe.hip: s_memtime phase accounting, not part of the library build
+__device__ unsigned long long smz_vision_stamps[8];
+#define SMZ_STAMP(i)                                                                                  \
+    do {                                                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                 \
+        if (lane == 0) atomicAdd(&smz_vision_stamps[i], now_ - last_);                                \
+        last_ = now_;                                                                                 \
+    } while (0)
+#define SMZ_STAMP_INIT() unsigned long long last_ = __builtin_amdgcn_s_memtime()
+#else
+#define SMZ_STAMP(i) do {} while (0)
+#define SMZ_STAMP_INIT() do {} while (0)
+#endif
+
 // One wavefront per leaf: (afterstate) dynamics + (afterstate) prediction, selected by the leaf's branch flag
 // (monte_carlo_tree_search.py:333-342).  parent_hidden [B, ld] (first 147 floats used), last_action [B], branch [B].
 __global__ void __launch_bounds__(kRecWaves *kWave) k_vision_recurrent(
@@ -192,10 +209,19 @@ __global__ void __launch_bounds__(kRecWaves *kWave) k_vision_recurrent(
     const int32_t *__restrict__ last_action, const uint8_t *__restrict__ branch, float *__restrict__ hidden_out,
     float *__restrict__ reward_out, float *__restrict__ policy_out, float *__restrict__ value_out, int B) {
     __shared__ WaveLds lds[kRecWaves];
+    __shared__ float4 small4[kSmallMax / 4];
+    // convolution / batch-norm / 1x1 weights of the four nets: one coalesced copy per workgroup.  (Read through the
+    // scalar cache instead, every layer of every leaf misses it once per launch -- the cache starts cold and all leaf
+    // wavefronts reach a layer together -- and each miss queues behind the tower weight stream in L2.)
+    for (int i = threadIdx.x; i < d.small_floats / 4; i += blockDim.x)
+        small4[i] = reinterpret_cast<const float4 *>(weights)[i];
+    __syncthreads();
+    const float *small = reinterpret_cast<const float *>(small4);
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int row = blockIdx.x * kRecWaves + wave;
-    if (row >= B) return;                                   // wave-uniform
+    if (row >= B) return;                                   // wave-uniform (after the only workgroup barrier)
     WaveLds &l = lds[wave];
+    SMZ_STAMP_INIT();
     zero_wave_lds(l, lane);
     const bool active = lane < kPix;
     const int p = active ? lane : kPix - 1, pp = (p / kN + 1) * kPad + (p % kN + 1);
@@ -209,27 +235,31 @@ __global__ void __launch_bounds__(kRecWaves *kWave) k_vision_recurrent(
     float reward = 0.f;
     if (dyn) {
         float acc[1][1];
-        mix_to_flat<4>(l.flat, p, active, x, uniform_ptr(weights, o[SMZ_VT_MIX_W]), uniform_ptr(weights, o[SMZ_VT_MIX_B]));
+        mix_to_flat<4>(l.flat, p, active, x, uniform_ptr(small, o[SMZ_VT_MIX_W]), uniform_ptr(small, o[SMZ_VT_MIX_B]));
         tower(weights, o + SMZ_VT_TOWER, l, d, lane, acc);
         reward = decode_lanes<1>(acc[0], 0, d.S, lane);
         lds_sync();
     }
+    SMZ_STAMP(0);
     // next state: conv3x3(4->3) bn relu [block] x L relu, scaled per pixel
     if (active) l.plane[pp] = make_float4(x[0], x[1], x[2], x[3]);
     lds_sync();
     float t[kC];
-    conv3x3<4>(l.plane, pp, uniform_ptr(weights, o[SMZ_VT_CONV_IN]), t);
+    SMZ_STAMP(3);
+    conv3x3<4>(l.plane, pp, uniform_ptr(small, o[SMZ_VT_CONV_IN]), t);
     lds_sync();
+    SMZ_STAMP(4);
     {
-        const float *bn = uniform_ptr(weights, o[SMZ_VT_BN_IN]);
+        const float *bn = uniform_ptr(small, o[SMZ_VT_BN_IN]);
 #pragma unroll
         for (int c = 0; c < kC; c++) t[c] = fmaxf(t[c] * bn[c] + bn[kC + c], 0.f);
     }
     {
-        const float *wa = uniform_ptr(weights, o[SMZ_VT_RES_A]), *wb = uniform_ptr(weights, o[SMZ_VT_RES_B]);
-        const float *bn = uniform_ptr(weights, o[SMZ_VT_RES_BN]);
+        const float *wa = uniform_ptr(small, o[SMZ_VT_RES_A]), *wb = uniform_ptr(small, o[SMZ_VT_RES_B]);
+        const float *bn = uniform_ptr(small, o[SMZ_VT_RES_BN]);
         for (int i = 0; i < d.L; i++) residual_block(l.plane, pp, active, wa, wb, bn, t);
     }
+    SMZ_STAMP(5);
 #pragma unroll
     for (int c = 0; c < kC; c++) t[c] = fmaxf(t[c], 0.f);
     scale_channels(t);
@@ -237,8 +267,10 @@ __global__ void __launch_bounds__(kRecWaves *kWave) k_vision_recurrent(
         float *ho = hidden_out + (size_t)row * kFlat;
         ho[p] = t[0]; ho[kPix + p] = t[1]; ho[2 * kPix + p] = t[2];
     }
-    const float value = predict(weights, d, dyn ? SMZ_V_PRE : SMZ_V_APR, l, lane, p, pp, active, t,
+    SMZ_STAMP(1);
+    const float value = predict(weights, small, d, dyn ? SMZ_V_PRE : SMZ_V_APR, l, lane, p, pp, active, t,
                                 policy_out + (size_t)row * d.A, true);
+    SMZ_STAMP(2);
     if (lane == 0) {
         reward_out[row] = reward;
         value_out[row] = value;
@@ -385,7 +417,7 @@ __global__ void __launch_bounds__(kRepThreads) k_vision_initial(smz_vision_desc 
             ho[p] = t[0]; ho[kPix + p] = t[1]; ho[2 * kPix + p] = t[2];
         }
         zero_wave_lds(l.head, lane);
-        predict(weights, d, SMZ_V_PRE, l.head, lane, p, pp, active, t, policy_out + (size_t)row * d.A, false);
+        predict(weights, weights, d, SMZ_V_PRE, l.head, lane, p, pp, active, t, policy_out + (size_t)row * d.A, false);
     }
 }
 
@@ -399,20 +431,26 @@ int fill_layout(smz_vision_desc *d) {
         take(base + 4, K4h * OP);    take(base + 5, OP);
     };
     for (int i = 0; i < SMZ_V_OFFSETS; i++) d->off[i] = 0;
+    // (1) the small pieces of the four recurrent nets, contiguous from offset 0: the recurrent kernel stages
+    //     [0, small_floats) into LDS once per workgroup
     for (int n = 0; n < 2; n++) {            // dynamics, afterstate dynamics
         const int b = SMZ_V_TRANS_BASE + n * SMZ_V_TRANS_STRIDE;
         take(b + SMZ_VT_CONV_IN, 3 * 4 * 9); take(b + SMZ_VT_BN_IN, 6);
         take(b + SMZ_VT_RES_A, 81); take(b + SMZ_VT_RES_B, 81); take(b + SMZ_VT_RES_BN, 6);
         take(b + SMZ_VT_MIX_W, 12); take(b + SMZ_VT_MIX_B, 3);
-        take_tower(b + SMZ_VT_TOWER);
     }
     for (int n = 0; n < 2; n++) {            // prediction, afterstate prediction
         const int b = SMZ_V_PRED_BASE + n * SMZ_V_PRED_STRIDE;
         take(b + SMZ_VP_RES_A, 81); take(b + SMZ_VP_RES_B, 81); take(b + SMZ_VP_RES_BN, 6);
         take(b + SMZ_VP_VMIX_W, 9); take(b + SMZ_VP_VMIX_B, 3);
-        take_tower(b + SMZ_VP_VTOWER);
         take(b + SMZ_VP_PMIX_W, 9); take(b + SMZ_VP_PMIX_B, 3);
-        take_tower(b + SMZ_VP_PTOWER);
+    }
+    d->small_floats = off;
+    // (2) the towers (streamed from L2) and the representation network
+    for (int n = 0; n < 2; n++) take_tower(SMZ_V_TRANS_BASE + n * SMZ_V_TRANS_STRIDE + SMZ_VT_TOWER);
+    for (int n = 0; n < 2; n++) {
+        take_tower(SMZ_V_PRED_BASE + n * SMZ_V_PRED_STRIDE + SMZ_VP_VTOWER);
+        take_tower(SMZ_V_PRED_BASE + n * SMZ_V_PRED_STRIDE + SMZ_VP_PTOWER);
     }
     const int r = SMZ_V_REP_BASE;
     take(r + SMZ_VR_STEM, 27);
@@ -422,13 +460,13 @@ int fill_layout(smz_vision_desc *d) {
     take(r + SMZ_VR_LAST_A, 81); take(r + SMZ_VR_LAST_B, 81); take(r + SMZ_VR_LAST_BN, 6);
     d->OP = OP;
     d->total_floats = off;
-    return SMZ_OK;
+    return off > 0 && d->small_floats <= kSmallMax ? SMZ_OK : SMZ_ERR_INVALID;
 }
 
 int vision_check(const smz_vision_desc *d, const void *w) {
     if (!d || !w) return SMZ_ERR_INVALID;
     smz_vision_desc t = *d;
-    if (smz_vision_layout(&t) != SMZ_OK || t.total_floats != d->total_floats || t.OP != d->OP) return SMZ_ERR_INVALID;
+    if (smz_vision_layout(&t) != SMZ_OK || t.total_floats != d->total_floats || t.OP != d->OP || t.small_floats != d->small_floats) return SMZ_ERR_INVALID;
     for (int i = 0; i < SMZ_V_OFFSETS; i++)
         if (t.off[i] != d->off[i]) return SMZ_ERR_INVALID;
     return SMZ_OK;
