@@ -289,7 +289,7 @@ def main():
                                                  "frac": tree_bytes / (tree_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
                            "method": "HIP event pairs on the launching (torch current) stream around each launch, "
                                      "after the timed region; bytes = SURVEY 8d formula on this run's level histogram"}
-    if rank == 0 and not args.no_cpu_baseline and wl["env"] == "cartpole":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl["env"] == "cartpole":    # N=1 only (contract)
         out["cpu_baseline"] = cpu_baseline(wl, wpath)
     if rank == 0:
         print(json.dumps(out), flush=True)

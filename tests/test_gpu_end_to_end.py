@@ -483,3 +483,27 @@ def test_hip_vision_heads_agree_with_the_torch_modules_on_a_large_batch():
     torch.testing.assert_close(rw, rw_ref, rtol=1e-4, atol=5e-4)
     torch.testing.assert_close(val, val_ref, rtol=1e-4, atol=5e-4)
     assert (rw[~branch] == 0).all() and (rw[branch] != 0).any()
+
+
+def test_drop_in_search_with_the_vision_family_on_its_own_inference_functions():
+    """The reference's call shape end to end for `vision_model`: np.random.seed(s); Monte_carlo_tree_search(...).run(
+    observation=frame, model=Muzero, train=True) with this package's Muzero (compat_vision modules, batch-1 CPU
+    inference exactly as muzero_model.py:802-909) and the GPU tree engine underneath -- against the reference's own run
+    on the same weights (visionL2_sims16.npz): visit counts, f64 root priors, root value, stream position."""
+    mcts_mod, model_mod, _, _ = _mods()
+    cfg, data = gu.load("visionL2_sims16")
+    model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L2_bn.npz"))
+    m = mcts_mod.Monte_carlo_tree_search(pb_c_base=int(cfg["pb_c_base"]), pb_c_init=float(cfg["pb_c_init"]),
+                                         discount=float(cfg["discount"]),
+                                         root_dirichlet_alpha=float(cfg["root_dirichlet_alpha"]),
+                                         root_exploration_fraction=float(cfg["root_exploration_fraction"]),
+                                         num_simulations=int(cfg["num_simulations"]), maxium_action_sample=2)
+    for i, seed in enumerate(data["seed"]):
+        np.random.seed(int(seed))
+        root = m.run(observation=_frame(4100 + int(seed)), model=model, train=True)
+        assert [c.visit_count for c in root.children.values()] == list(data["root_visits"][i])
+        # the network runs on THIS host's CPU (ATen picks kernels per ISA): float32 policy rounding, 1e-6 relative
+        np.testing.assert_allclose([c.prior for c in root.children.values()], data["root_priors"][i], rtol=1e-6)
+        np.testing.assert_allclose(root.value(), data["root_value"][i], rtol=1e-4, atol=5e-4)
+        assert np.random.random_sample() == data["probe"][i]          # the global stream is where the reference left it
+        m.cycle.global_reset()
