@@ -287,6 +287,17 @@ int smz_traj_pack(double *traj_dev, int T, int t, int obs_dim, int A, const floa
                   const uint8_t *terminated_dev, const int32_t *action_dev, const double *policy_dev, const double *child_visits_dev,
                   const float *root_value_dev, int B, smz_stream stream);
 
+/* Replay ingest, vectorised: for every stored position of a [T][B][F] chunk, the game length of its env
+ * (steps up to and including the first terminated one; T when ignore_termination), the n-step value target that
+ * Game.make_target / Game.make_priority compute (game.py:291-337) with the reference's scalar types (float32 chain when
+ * the bootstrap position lies inside the game, float64 past its end), and |root_value - target| (make_priority before
+ * `** priority_scale`).  discount_pow_dev [td_steps+1] f64 = discount ** i as computed by the host language (Python's
+ * float pow).  length_dev [B] i32, value_target_dev [T][B] f64, abs_td_error_dev [T][B] f64 (may be NULL); positions
+ * at or beyond the game length are 0. */
+int smz_traj_targets(const double *traj_dev, int T, int obs_dim, int A, int B, int td_steps, const double *discount_pow_dev,
+                     int ignore_termination, int32_t *length_dev, double *value_target_dev, double *abs_td_error_dev,
+                     smz_stream stream);
+
 /* ---- inspection ------------------------------------------------------------------------------------------------ */
 /* [sync] Copies one tree to the host: up to `cap` nodes into `nodes`; minmax_out[2] = {min, max} (may be NULL);
  * path_out (cap_path entries) / path_len_out = the last recorded search path; root_priors_out [A] f64.

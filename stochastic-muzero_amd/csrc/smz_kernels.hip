@@ -642,6 +642,52 @@ __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, i
     }
 }
 
+// Game length of every env of a chunk: steps up to and including the first terminated one (chunk_to_games'/play_game's
+// cut, self_play.py:79-94), or T.
+__global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T, int obs_dim, int A, int B, int ignore_term,
+                                                      int32_t *length) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    const int F = obs_dim + 3 * A + 3;
+    int n = T;
+    if (!ignore_term)
+        for (int t = 0; t < T; t++)
+            if (traj[((size_t)t * B + e) * F + obs_dim + 1] != 0.0) { n = t + 1; break; }
+    length[e] = n;
+}
+
+// n-step value target of every stored position (the value entry of Game.make_target and the target inside
+// Game.make_priority, game.py:291-337), with the reference's scalar types: root values are numpy float32, rewards and
+// discount powers Python floats, so under NEP 50 a bootstrapped chain (position + td_steps inside the game) runs in
+// float32 -- f32(root_value) * f32(discount^td), then one f32 add per reward of the f64 product reward * discount^i
+// rounded to f32 -- and a chain past the end of the game starts from a Python 0 and stays float64.
+// abs_td = |float64(root_value[t]) - target| (make_priority before ** priority_scale).  Positions t >= length are 0.
+__global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T, int obs_dim, int A, int B, int td,
+                                                      const double *disc_pow, const int32_t *length, double *target,
+                                                      double *abs_td) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * B) return;
+    const int t = (int)(i / B), e = (int)(i % B);
+    const int F = obs_dim + 3 * A + 3, n = length[e];
+    const size_t rv_off = obs_dim + 2 + 2 * A;
+    double out = 0.0, err = 0.0;
+    if (t < n) {
+        const int b = t + td;
+        if (b < n) {
+            float v = (float)traj[((size_t)b * B + e) * F + rv_off] * (float)disc_pow[td];
+            for (int k = 0; k < td; k++) v = v + (float)(traj[((size_t)(t + k) * B + e) * F + obs_dim] * disc_pow[k]);
+            out = (double)v;
+        } else {
+            double v = 0.0;
+            for (int k = 0; t + k < n; k++) v += traj[((size_t)(t + k) * B + e) * F + obs_dim] * disc_pow[k];
+            out = v;
+        }
+        err = fabs(traj[i * F + rv_off] - out);
+    }
+    target[i] = out;
+    if (abs_td) abs_td[i] = err;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1144,6 +1190,20 @@ int smz_traj_pack(double *traj_dev, int T, int t, int obs_dim, int A, const floa
     const unsigned blocks = (unsigned)std::min<size_t>((slab + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(k_traj_pack, dim3(blocks), dim3(256), 0, (hipStream_t)stream, traj_dev, T, t, obs_dim, A, obs_dev,
                        reward_dev, terminated_dev, action_dev, policy_dev, child_visits_dev, root_value_dev, B);
+    return launch_check();
+}
+
+int smz_traj_targets(const double *traj_dev, int T, int obs_dim, int A, int B, int td_steps, const double *discount_pow_dev,
+                     int ignore_termination, int32_t *length_dev, double *value_target_dev, double *abs_td_error_dev,
+                     smz_stream stream) {
+    if (!traj_dev || !discount_pow_dev || !length_dev || !value_target_dev || T < 1 || B < 1 || A < 1 || obs_dim < 1 ||
+        td_steps < 0)
+        return fail(SMZ_ERR_INVALID, "smz_traj_targets: bad argument%s");
+    hipLaunchKernelGGL(k_traj_lengths, row_grid(B), dim3(256), 0, (hipStream_t)stream, traj_dev, T, obs_dim, A, B,
+                       ignore_termination, length_dev);
+    const size_t cells = (size_t)T * B;
+    hipLaunchKernelGGL(k_traj_targets, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, (hipStream_t)stream, traj_dev, T,
+                       obs_dim, A, B, td_steps, discount_pow_dev, length_dev, value_target_dev, abs_td_error_dev);
     return launch_check();
 }
 

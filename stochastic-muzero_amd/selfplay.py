@@ -62,6 +62,27 @@ class TrajectoryChunk:
                     child_visits=d[..., o + 3 + 2 * A:o + 3 + 3 * A])
 
 
+def chunk_targets(chunk_data, obs_dim, A, discount, td_steps, ignore_termination=False):
+    """Vectorised replay ingest on the device (smz_traj_targets): for a [T][B][F] chunk returns
+    (length [B] i32, value_target [T][B] f64, abs_td_error [T][B] f64) -- per stored position the n-step return that
+    GameRecord.make_target / make_priority (game.py:291-337) compute one position at a time, bit for bit, and
+    |root value - return| (the priority before `** priority_scale`)."""
+    lib = _lib.load()
+    T, B, F = chunk_data.shape
+    assert chunk_data.is_cuda and chunk_data.dtype == torch.float64 and chunk_data.is_contiguous()
+    assert F == lib.smz_traj_floats(int(obs_dim), int(A))
+    dev = chunk_data.device
+    pows = torch.tensor([discount ** i for i in range(int(td_steps) + 1)], dtype=torch.float64).to(dev)   # Python's pow
+    length = torch.empty(B, dtype=torch.int32, device=dev)
+    target = torch.empty(T, B, dtype=torch.float64, device=dev)
+    err = torch.empty(T, B, dtype=torch.float64, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.smz_traj_targets(P(chunk_data), T, int(obs_dim), int(A), B, int(td_steps), P(pows),
+                                    int(bool(ignore_termination)), P(length), P(target), P(err),
+                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return length, target, err
+
+
 class GameRecord:
     """What self-play hands to ReplayBuffer.save_game: the trajectory lists of game.py:72-77 plus the few members
     the buffer reads (game_length, reanalyzed, make_priority: replay_buffer.py:109-137, game.py:174-177, 316-337)."""

@@ -507,3 +507,40 @@ def test_drop_in_search_with_the_vision_family_on_its_own_inference_functions():
         np.testing.assert_allclose(root.value(), data["root_value"][i], rtol=1e-4, atol=5e-4)
         assert np.random.random_sample() == data["probe"][i]          # the global stream is where the reference left it
         m.cycle.global_reset()
+
+
+@pytest.mark.parametrize("td", [1, 3, 10, 50])
+def test_vectorised_value_targets_equal_the_per_game_make_target(td):
+    """smz_traj_targets over a whole [T][B][F] chunk vs GameRecord.make_target / make_priority position by position
+    (those are pinned to the reference's Game.make_target / make_priority on the reference's own games in
+    test_abi_and_host.py).  float64 outputs, bit for bit: the kernel reproduces the reference's scalar types (float32
+    chain inside the game, float64 past its end).  Games of ragged length: random termination flags."""
+    _, _, _, sp = _mods()
+    T, B, obs, A, disc = 24, 37, 4, 3, 0.997
+    g = np.random.RandomState(td)
+    F = obs + 3 * A + 3
+    d = np.zeros((T, B, F))
+    d[..., :obs] = g.randn(T, B, obs).astype(np.float32)
+    d[..., obs] = g.randn(T, B).astype(np.float32)                          # rewards (float32 widened, as smz_traj_pack writes)
+    d[..., obs + 1] = (g.rand(T, B) < 0.04)                                  # terminated
+    d[:, 5, obs + 1] = 0                                                     # one game runs the whole chunk
+    d[0, 6, obs + 1] = 1                                                     # one game of a single step
+    pol = g.rand(T, B, A); d[..., obs + 2:obs + 2 + A] = pol / pol.sum(-1, keepdims=True)
+    d[..., obs + 2 + 2 * A] = (10 * g.randn(T, B)).astype(np.float32)        # root values
+    cv = g.rand(T, B, A); d[..., obs + 3 + 2 * A:] = cv / cv.sum(-1, keepdims=True)
+    dev = torch.from_numpy(d).cuda()
+    length, target, err = sp.chunk_targets(dev, obs, A, disc, td)
+    torch.cuda.synchronize()
+    length, target, err = length.cpu().numpy(), target.cpu().numpy(), err.cpu().numpy()
+    games = sp.chunk_to_games(d, obs, A, disc)
+    for e, game in enumerate(games):
+        n = game.game_length
+        assert length[e] == n
+        pos, top = game.make_priority(td)
+        assert np.array_equal(err[:n, e], np.asarray(pos, np.float64)), e
+        want = [game.make_target(t, 1, td)[0][0] for t in range(n)]
+        assert np.array_equal(target[:n, e], np.asarray([np.float64(w) for w in want])), e
+        assert (target[n:, e] == 0).all() and (err[n:, e] == 0).all()
+    # ignore_termination: every game spans the chunk
+    length2, _, _ = sp.chunk_targets(dev, obs, A, disc, td, ignore_termination=True)
+    assert (length2.cpu().numpy() == T).all()
