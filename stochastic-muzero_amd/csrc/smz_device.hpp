@@ -37,6 +37,7 @@ struct TreeHdr {          // one 32-byte record per tree
 
 struct Params {
     int32_t B, A, K, S, N, P, sims;
+    int32_t hs;         // floats between consecutive hidden rows: S rounded up to a 64-byte line
     int32_t lds_stage;  // 1: stage the twisted words in LDS (small batches); 0: twist ahead only, draw from L1 (occupancy)
     int32_t dbg;        // timing-ablation switches (SMZ_DEBUG_SKIP, diagnostics only; results are then meaningless)
     int32_t tpw;        // trees per wavefront (power of two <= 64): lanes >= tpw only help in the cooperative phases
@@ -48,7 +49,7 @@ struct Params {
     float keep32;       // float32(1 - root_exploration_fraction) (mcts:224-225)
     double frac, alpha;
     uint32_t *nodes;        // [B][tree_words]
-    float *hidden;          // [B][N][S]
+    float *hidden;          // [B][N][hs]
     TreeHdr *hdr;           // [B]
     uint4 *path;            // [B][P]   records (block << 8 | slot, visit, value_sum, reward); block 0 = root block
     uint32_t *mt;           // [B][624]
@@ -446,8 +447,6 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
         Kids<MAXA> k;
         load_kids_dyn<MAXA>(tb, A, true, P.rp_off, k);
         const int pick = pick_decision<MAXA>(k, A, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng);
-        n_dec++;
-        n_children += (unsigned)A;
         float pv = 0.f, pr = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXA; j++) if (j == pick) { c = k.chd[j]; cur_visit = k.vis[j]; action = j; pv = k.vsum[j]; pr = k.rew[j]; }
@@ -465,11 +464,8 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
         int pick;
         if (depth_flag(depth)) {
             pick = pick_chance<NK>(k, cnt, rng);
-            n_chance++;
         } else {
             pick = pick_decision<NK>(k, cnt, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng);
-            n_dec++;
-            n_children += (unsigned)cnt;
         }
         float pv = 0.f, pr = 0.f;
 #pragma unroll
@@ -480,6 +476,13 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
         depth++;
     }
     path_len_out = depth;
+    {   // level statistics in closed form (levels 0..depth-1 carry the flags F F T T F F T T ...): counters updated
+        // inside the descent loop were placed in scratch memory by the compiler -- a memory round trip per level
+        const unsigned d = (unsigned)depth, ch = 2u * (d >> 2) + ((d & 3u) > 2u ? (d & 3u) - 2u : 0u), dec = d - ch;
+        n_chance += ch;
+        n_dec += dec;
+        n_children += (unsigned)A + (dec - 1u) * (unsigned)(KS > 0 ? KS : K);
+    }
     Leaf L;
     L.leaf_id = leaf_id;
     L.parent_id = parent_id;

@@ -169,7 +169,7 @@ __device__ inline void wave_gather_inputs(const Params &P, int tree, bool valid,
 #pragma unroll
             for (int u = 0; u < kRowBatch; u++) {
                 v[u] = 0.f;
-                if (ok[u]) v[u] = (i < S) ? P.hidden[((size_t)tj[u] * P.N + pj[u]) * S + i] : ((i - S) == aj[u] ? 1.0f : 0.0f);
+                if (ok[u]) v[u] = (i < S) ? P.hidden[((size_t)tj[u] * P.N + pj[u]) * P.hs + i] : ((i - S) == aj[u] ? 1.0f : 0.0f);
             }
 #pragma unroll
             for (int u = 0; u < kRowBatch; u++) {
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidd
     }
     if (P.S > 0 && hidden) {
         const int t = valid ? tree : 0;
-        wave_copy_rows(hidden + (size_t)t * P.S, P.hidden + (size_t)t * P.N * P.S, valid, P.S, P.tpw);
+        wave_copy_rows(hidden + (size_t)t * P.S, P.hidden + (size_t)t * P.N * P.hs, valid, P.S, P.tpw);
     }
 }
 
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params P, const floa
     }
     if (P.S > 0 && hidden) {
         const int t = valid ? tree : 0;
-        wave_copy_rows(hidden + (size_t)t * P.S, P.hidden + ((size_t)t * P.N + leaf) * P.S, valid, P.S, P.tpw);
+        wave_copy_rows(hidden + (size_t)t * P.S, P.hidden + ((size_t)t * P.N + leaf) * P.hs, valid, P.S, P.tpw);
     }
     if (FUSE_SELECT) {
         // the leaf rows just written by other lanes of this wave may be the next parent rows
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
     for (int t = 0; t < tpw; t++) {
         const int row = tree0 + t;
         if (row >= P.B) break;                                   // wave-uniform
-        smz_mlp::initial_row<U>(lds, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * S,
+        smz_mlp::initial_row<U>(lds, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * P.hs,
                                 nullptr, outs + t * slot);
     }
     int packed = wave_stage_rng(P, tree, valid, rng_tile);
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
             const int row = tree0 + t;
             if (row >= P.B) break;                               // wave-uniform
             const int parent = __builtin_amdgcn_readlane(L.parent_id, t), act = __builtin_amdgcn_readlane(L.action, t);
-            const float *src = P.hidden + ((size_t)row * P.N + parent) * S;
+            const float *src = P.hidden + ((size_t)row * P.N + parent) * P.hs;
             for (int k = lane; k < K4in; k += kWave)
                 xall[t * K4in + k] = (k < S) ? src[k] : ((k < S + A && (k - S) == act) ? 1.f : 0.f);
         }
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
                 const int leaf = __builtin_amdgcn_readlane(L.leaf_id, tt);
                 dyn[r] = __builtin_amdgcn_readlane(L.branch, tt) != 0;
                 xin[r] = xall + tt * K4in;
-                dh[r] = P.hidden + ((size_t)row * P.N + leaf) * S;
+                dh[r] = P.hidden + ((size_t)row * P.N + leaf) * P.hs;
                 dp[r] = outs + tt * slot;
             }
             if (!(P.dbg & 1)) smz_mlp::recurrent_rows<U, R>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
@@ -864,7 +864,8 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     int rc = SMZ_OK;
     auto A_ = [&](int r) { if (rc == SMZ_OK) rc = r; };
     A_(dev_alloc(h, &P.nodes, (size_t)B * (size_t)P.tree_words));
-    A_(dev_alloc(h, &P.hidden, BN * (size_t)S));
+    P.hs = (S + 15) & ~15;        // hidden rows start on 64-byte lines (S = 31 -> 128-byte rows: two whole lines)
+    A_(dev_alloc(h, &P.hidden, BN * (size_t)P.hs));
     A_(dev_alloc(h, &P.hdr, (size_t)B));
     A_(dev_alloc(h, &P.path, (size_t)B * h->Ppath));
     A_(dev_alloc(h, &P.mt, (size_t)B * kMtN));

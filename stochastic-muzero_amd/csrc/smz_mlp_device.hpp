@@ -309,15 +309,29 @@ __device__ inline float decode_scale_lanes(const float (&v)[U], int S, int lane,
     return support_to_scalar(num, den);
 }
 
+// Float offsets of one matrix and its bias.  A descriptor's off[] must only ever be indexed with compile-time
+// constants: a run-time index (`off[dyn ? M_DYN_IN : M_ADY_IN]`) makes the compiler keep the whole table in scratch
+// memory and turns every layer's set-up into a global-memory round trip (measured: the dominant stall of a leaf
+// evaluation).  pick() selects between two constant-index entries instead.
+struct MatOff {
+    int w, b;
+};
+__device__ inline MatOff pick(const smz_mlp_desc &d, bool first, int ma, int mb) {   // ma, mb: constants at every call site
+    MatOff o;
+    o.w = first ? d.off[ma] : d.off[mb];
+    o.b = first ? d.off[M_COUNT + ma] : d.off[M_COUNT + mb];
+    return o;
+}
+
 // hidden trunk for R rows: in-layer + L repeats of the shared mid layer, ELU after each; results in tA[r] (LDS, zero
-// padded to a multiple of 4).  m_in[r] / m_mid[r] pick each row's matrices.
+// padded to a multiple of 4).  o_in[r] / o_mid[r]: each row's matrices.
 template <int U, int R>
-__device__ inline void trunk(const float *lds, const smz_mlp_desc &d, const int (&m_in)[R], const int (&m_mid)[R],
+__device__ inline void trunk(const float *lds, const smz_mlp_desc &d, const MatOff (&o_in)[R], const MatOff (&o_mid)[R],
                              const float *const (&act_in)[R], int K4in, float *const (&tA)[R], int lane) {
     float acc[R][U];
     const float *W[R], *Bv[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) { W[r] = lds + d.off[m_in[r]]; Bv[r] = lds + d.off[M_COUNT + m_in[r]]; }
+    for (int r = 0; r < R; r++) { W[r] = lds + o_in[r].w; Bv[r] = lds + o_in[r].b; }
     dense<U, R>(W, Bv, act_in, K4in, d.OP, lane, acc);
 #pragma unroll
     for (int r = 0; r < R; r++)
@@ -327,7 +341,7 @@ __device__ inline void trunk(const float *lds, const smz_mlp_desc &d, const int 
     for (int l = 0; l < d.L; l++) {
         const float *Wm[R], *Bm[R], *Am[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) { Wm[r] = lds + d.off[m_mid[r]]; Bm[r] = lds + d.off[M_COUNT + m_mid[r]]; Am[r] = tA[r]; }
+        for (int r = 0; r < R; r++) { Wm[r] = lds + o_mid[r].w; Bm[r] = lds + o_mid[r].b; Am[r] = tA[r]; }
         dense<U, R>(Wm, Bm, Am, up4(d.H), d.OP, lane, acc);
         lds_sync();   // every lane has issued its reads of tA (LDS is in order per wave) before it is overwritten
 #pragma unroll
@@ -382,13 +396,13 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
     const int lane = threadIdx.x & (kWave - 1);
     const int rs = row_scratch_floats(d), kin = rs - K4h - K4s;
     float *tA[R], *hbuf[R];
-    int m1[R], m1m[R], m3[R], m3m[R];
+    MatOff m1[R], m1m[R], m3[R], m3m[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         tA[r] = scratch + r * rs + kin;
         hbuf[r] = tA[r] + K4h;
-        m1[r] = dyn[r] ? M_DYN_IN : M_ADY_IN;   m1m[r] = dyn[r] ? M_DYN_MID : M_ADY_MID;
-        m3[r] = dyn[r] ? M_PRE_IN : M_APR_IN;   m3m[r] = dyn[r] ? M_PRE_MID : M_APR_MID;
+        m1[r] = pick(d, dyn[r], M_DYN_IN, M_ADY_IN);   m1m[r] = pick(d, dyn[r], M_DYN_MID, M_ADY_MID);
+        m3[r] = pick(d, dyn[r], M_PRE_IN, M_APR_IN);   m3m[r] = pick(d, dyn[r], M_PRE_MID, M_APR_MID);
         for (int k = lane; k < K4s; k += kWave) hbuf[r][k] = 0.f;
     }
     trunk<U, R>(lds, d, m1, m1m, xin, K4in, tA, lane);
@@ -397,8 +411,8 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         const float *W[R], *Bv[R], *Ac[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int m = dyn[r] ? M_DYN_OUT : M_ADY_OUT;
-            W[r] = lds + d.off[m]; Bv[r] = lds + d.off[M_COUNT + m]; Ac[r] = tA[r];
+            const MatOff m = pick(d, dyn[r], M_DYN_OUT, M_ADY_OUT);
+            W[r] = lds + m.w; Bv[r] = lds + m.b; Ac[r] = tA[r];
         }
         dense<U, R>(W, Bv, Ac, K4h, d.OP, lane, acc);
     }
@@ -420,8 +434,8 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         const float *W[R], *Bv[R], *Ac[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int m = dyn[r] ? M_PRE_OUT : M_APR_OUT;
-            W[r] = lds + d.off[m]; Bv[r] = lds + d.off[M_COUNT + m]; Ac[r] = tA[r];
+            const MatOff m = pick(d, dyn[r], M_PRE_OUT, M_APR_OUT);
+            W[r] = lds + m.w; Bv[r] = lds + m.b; Ac[r] = tA[r];
         }
         dense<U, R>(W, Bv, Ac, K4h, d.OP, lane, acc);
     }
@@ -448,7 +462,7 @@ __device__ inline void initial_row(const float *lds, const smz_mlp_desc &d, cons
     for (int k = lane; k < K4o; k += kWave) xbuf[k] = (k < d.obs) ? obs_row[k] : 0.f;
     for (int k = lane; k < K4s; k += kWave) hbuf[k] = 0.f;
     lds_sync();
-    const int mi[1] = {M_REP_IN}, mm[1] = {M_REP_MID};
+    const MatOff mi[1] = {pick(drep, true, M_REP_IN, M_REP_IN)}, mm[1] = {pick(drep, true, M_REP_MID, M_REP_MID)};
     const float *xi[1] = {xbuf};
     trunk<U, 1>(rep, drep, mi, mm, xi, K4o, tA, lane);
     float acc[1][U];
@@ -458,7 +472,7 @@ __device__ inline void initial_row(const float *lds, const smz_mlp_desc &d, cons
     }
     scale_lanes<U>(acc[0], 0, S, lane, hbuf, dst_hidden0, dst_hidden1);
     lds_sync();
-    const int pi[1] = {M_PRE_IN}, pm[1] = {M_PRE_MID};
+    const MatOff pi[1] = {pick(d, true, M_PRE_IN, M_PRE_IN)}, pm[1] = {pick(d, true, M_PRE_MID, M_PRE_MID)};
     const float *hi[1] = {hbuf};
     trunk<U, 1>(lds, d, pi, pm, hi, K4s, tA, lane);
     {

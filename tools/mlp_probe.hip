@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(512) probe(smz_mlp_desc d, const float *weight
         float *tA[1] = {scratch + kin};
         float *hbuf = tA[0] + K4h;
         const float *xin[1] = {xb};
-        int m1[1] = {M_DYN_IN}, m1m[1] = {M_DYN_MID}, m3[1] = {M_PRE_IN}, m3m[1] = {M_PRE_MID};
+        const MatOff m1[1] = {pick(dl, true, M_DYN_IN, M_DYN_IN)}, m1m[1] = {pick(dl, true, M_DYN_MID, M_DYN_MID)},
+                     m3[1] = {pick(dl, true, M_PRE_IN, M_PRE_IN)}, m3m[1] = {pick(dl, true, M_PRE_MID, M_PRE_MID)};
         float acc[1][1];
         a = __builtin_amdgcn_s_memtime();
         trunk<1, 1>(lds, dl, m1, m1m, xin, K4in, tA, lane);
