@@ -359,11 +359,11 @@ __device__ inline void stage_weights(float *lds, const float *weights, const int
     for (int r = 0; r < n_ranges; r++) {
         const int off = ranges[2 * r], cnt = ranges[2 * r + 1];
         for (int i0 = threadIdx.x * 4; i0 < cnt; i0 += blockDim.x * 4 * UB) {
-            float4 v[UB];
+            float4 v[UB];       // unconditional (clamped) loads: a conditionally written v[] ends up in scratch memory
 #pragma unroll
             for (int u = 0; u < UB; u++) {
                 const int i = i0 + u * blockDim.x * 4;
-                if (i < cnt) v[u] = *reinterpret_cast<const float4 *>(weights + off + i);
+                v[u] = *reinterpret_cast<const float4 *>(weights + off + (i < cnt ? i : i0));
             }
 #pragma unroll
             for (int u = 0; u < UB; u++) {
@@ -503,7 +503,7 @@ __device__ inline void stage_weights_without_rep(float *lds, const float *weight
         for (int i0 = threadIdx.x * 4; i0 < cnt; i0 += blockDim.x * 4 * UB) {
             float4 v[UB];
 #pragma unroll
-            for (int u = 0; u < UB; u++) { const int i = i0 + u * blockDim.x * 4; if (i < cnt) v[u] = *reinterpret_cast<const float4 *>(src + i); }
+            for (int u = 0; u < UB; u++) { const int i = i0 + u * blockDim.x * 4; v[u] = *reinterpret_cast<const float4 *>(src + (i < cnt ? i : i0)); }
 #pragma unroll
             for (int u = 0; u < UB; u++) { const int i = i0 + u * blockDim.x * 4; if (i < cnt) *reinterpret_cast<float4 *>(dst + i) = v[u]; }
         }
