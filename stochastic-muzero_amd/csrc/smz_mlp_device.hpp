@@ -316,10 +316,23 @@ __device__ inline float decode_scale_lanes(const float (&v)[U], int S, int lane,
 struct MatOff {
     int w, b;
 };
+// Offset of matrix m computed from the dimensions (the formula smz_mlp_layout fills off[] with: matrices in enum order,
+// up4(K_m) * OP floats each), so that the search loop keeps S, A, H, L, OP and one bias base live instead of thirty
+// table entries (the kernel is short of scalar registers: spilled SGPRs cost a v_readlane each time they are needed).
+// m is a compile-time constant at every call site, so the sum folds to a few scalar operations.
+__device__ inline int mat_off(const smz_mlp_desc &d, int m) {
+    const int kin = up4(d.S + d.A), kmid = d.L > 0 ? up4(d.H) : 0, kh = up4(d.H), ks = up4(d.S), ko = up4(d.obs);
+    const int K[M_COUNT] = {kin, kin, kmid, kmid, kh, kh, ks, ks, kmid, kmid, kh, kh, ko, kmid, kh};
+    int rows = 0;
+#pragma unroll
+    for (int j = 0; j < M_COUNT; j++) rows += j < m ? K[j] : 0;
+    return rows * d.OP;
+}
 __device__ inline MatOff pick(const smz_mlp_desc &d, bool first, int ma, int mb) {   // ma, mb: constants at every call site
     MatOff o;
-    o.w = first ? d.off[ma] : d.off[mb];
-    o.b = first ? d.off[M_COUNT + ma] : d.off[M_COUNT + mb];
+    const int bias0 = d.off[M_COUNT];            // (moved down in the LDS copy that leaves the representation out)
+    o.w = first ? mat_off(d, ma) : mat_off(d, mb);
+    o.b = bias0 + (first ? ma : mb) * d.OP;
     return o;
 }
 
