@@ -432,7 +432,7 @@ __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool n
     return pick;
 }
 
-template <int MAXA, int KS>
+template <int MAXA, int KS, bool STATS = true>
 __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const TreeHdr &h, const double *pbc_sqrt,
                                    int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children,
                                    uint4 *rec) {
@@ -476,7 +476,7 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
         depth++;
     }
     path_len_out = depth;
-    {   // level statistics in closed form (levels 0..depth-1 carry the flags F F T T F F T T ...): counters updated
+    if (STATS) {   // level statistics in closed form (levels 0..depth-1 carry the flags F F T T F F T T ...): counters updated
         // inside the descent loop were placed in scratch memory by the compiler -- a memory round trip per level
         const unsigned d = (unsigned)depth, ch = 2u * (d >> 2) + ((d & 3u) > 2u ? (d & 3u) - 2u : 0u), dec = d - ch;
         n_chance += ch;

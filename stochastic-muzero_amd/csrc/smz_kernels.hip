@@ -339,7 +339,9 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
     return m;
 }
 
-template <int MAXA, int KS, int U>
+// INSTR: instrumented build (level statistics, s_memtime phase stamps, SMZ_DEBUG_SKIP ablations); the production
+// instantiation carries none of it -- the accumulators alone cost a dozen scalar registers in a kernel that spills them.
+template <int MAXA, int KS, int U, bool INSTR>
 __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train) {
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
@@ -381,27 +383,28 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
         packed = rng.pack();
     }
     unsigned n_dec = 0, n_chance = 0, n_children = 0, n_desc = 0;
-    const bool prof = (P.dbg & 16) && P.stats;
+    const bool prof = INSTR && (P.dbg & 16) && P.stats;
+    const int dbg = INSTR ? P.dbg : 0;
     unsigned long long t_stage = 0, t_expand = 0, t_select = 0, t_mlp = 0, t0 = 0, t1 = 0;
-#define SMZ_STAMP(acc) if (prof) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
+#define SMZ_STAMP(acc) if (INSTR && prof) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
     // ---- simulations -------------------------------------------------------------------------------------------------
     for (int s = 0; s < P.sims; s++) {
-        if (prof) t0 = __builtin_amdgcn_s_memtime();
-        if (!(P.dbg & 8)) packed = wave_stage_rng_from<4>(P, tree, valid, rng_tile, packed);
+        if (INSTR && prof) t0 = __builtin_amdgcn_s_memtime();
+        if (!(dbg & 8)) packed = wave_stage_rng_from<4>(P, tree, valid, rng_tile, packed);
         SMZ_STAMP(t_stage)
         Leaf L = {0, 0, 0, 0};
         if (valid) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            if (s > 0 && !(P.dbg & 4)) expand_backup_tree<MAXA, KS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
+            if (s > 0 && !(dbg & 4)) expand_backup_tree<MAXA, KS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
                                                 outs[lane * slot + A], pvals + lane * P.P);
         }
         SMZ_STAMP(t_expand)
         if (valid) {
             int len = 0;
-            if (P.dbg & 2) { L.leaf_id = 1; L.parent_id = 0; L.action = 0; L.branch = 0; len = 1; }
-            else L = select_tree<MAXA, KS>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
+            if (dbg & 2) { L.leaf_id = 1; L.parent_id = 0; L.action = 0; L.branch = 0; len = 1; }
+            else L = select_tree<MAXA, KS, INSTR>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
             h.path_len = len;
-            n_desc++;
+            if (INSTR) n_desc++;
             packed = rng.pack();
         }
         SMZ_STAMP(t_select)
@@ -435,7 +438,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
                 dh[r] = P.hidden + ((size_t)row * P.N + leaf) * P.hs;
                 dp[r] = outs + tt * slot;
             }
-            if (!(P.dbg & 1)) smz_mlp::recurrent_rows<U, R>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
+            if (!(dbg & 1)) smz_mlp::recurrent_rows<U, R>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
 #pragma unroll
             for (int r = 0; r < R; r++)
                 if (live[r] && lane == 0) { outs[(t + r) * slot + A] = value[r]; outs[(t + r) * slot + A + 1] = reward[r]; }
@@ -444,7 +447,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
         SMZ_STAMP(t_mlp)
     }
 #undef SMZ_STAMP
-    if (prof && lane == 0) {
+    if (INSTR && prof && lane == 0) {
         atomicAdd(&P.stats[4], t_stage); atomicAdd(&P.stats[5], t_expand);
         atomicAdd(&P.stats[6], t_select); atomicAdd(&P.stats[7], t_mlp);
     }
@@ -461,7 +464,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, co
         P.rng_pos[tree] = packed;
         P.hdr[tree] = h;
     }
-    wave_add_stats(P.stats, n_dec, n_chance, n_desc, n_children);
+    if (INSTR) wave_add_stats(P.stats, n_dec, n_chance, n_desc, n_children);
 }
 
 __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits, double *priors, float *root_value,
@@ -1080,20 +1083,23 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave) * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_INVALID, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
-#define SMZ_LAUNCH_SEARCH(UU)                                                                                          \
+#define SMZ_LAUNCH_SEARCH(UU, INSTR)                                                                                   \
     SMZ_DISPATCH2(h->maxa, h->K, {                                                                                     \
         static size_t granted_dev[64] = {}; /* per instantiation and device: the opt-in is a host-side call */           \
         size_t &granted = granted_dev[h->cfg.device & 63];                                                             \
         if (lds > granted) {                                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU>),                          \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU, INSTR>),                   \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)               \
                 return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                            \
             granted = lds;                                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_search_mlp<MA, KS, UU>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream, P, \
-                           *desc, weights_dev, obs_dev, train);                                                        \
+        hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR>), dim3(blocks), dim3(kWaves * kWave), lds,                 \
+                           (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train);                                \
     })
-    SMZ_LAUNCH_SEARCH(1);     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane)
+    // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
+    // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
+    if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true); }
+    else { SMZ_LAUNCH_SEARCH(1, false); }
 #undef SMZ_LAUNCH_SEARCH
     h->root_ready = true;
     h->selected = false;
