@@ -341,9 +341,14 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
 
 // INSTR: instrumented build (level statistics, s_memtime phase stamps, SMZ_DEBUG_SKIP ablations); the production
 // instantiation carries none of it -- the accumulators alone cost a dozen scalar registers in a kernel that spills them.
-template <int MAXA, int KS, int U, bool INSTR>
-__global__ void __launch_bounds__(512) k_search_mlp(Params P, smz_mlp_desc d, const float *weights, const float *obs,
+// AEX: the action count equals the MAXA bucket (2, 4, 8, ...): A (and K when KS > 0) become compile-time constants for
+// everything inlined below -- the run-time `j < A` predicates otherwise live in hoisted 64-bit scalar masks.
+template <int MAXA, int KS, int U, bool INSTR, bool AEX>
+__global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train) {
+    Params P = Pin;
+    if (AEX) P.A = MAXA;
+    if (KS > 0) P.K = KS;
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
     const smz_mlp_desc dl = smz_mlp::lds_desc_without_rep(d);      // LDS copy: everything but the representation matrices
     smz_mlp::stage_weights_without_rep(lds, weights, d);
@@ -1083,23 +1088,24 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave) * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_INVALID, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
-#define SMZ_LAUNCH_SEARCH(UU, INSTR)                                                                                   \
+#define SMZ_LAUNCH_SEARCH(UU, INSTR, AEX)                                                                              \
     SMZ_DISPATCH2(h->maxa, h->K, {                                                                                     \
         static size_t granted_dev[64] = {}; /* per instantiation and device: the opt-in is a host-side call */           \
         size_t &granted = granted_dev[h->cfg.device & 63];                                                             \
         if (lds > granted) {                                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU, INSTR>),                   \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU, INSTR, AEX>),              \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)               \
                 return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                            \
             granted = lds;                                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR>), dim3(blocks), dim3(kWaves * kWave), lds,                 \
+        hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR, AEX>), dim3(blocks), dim3(kWaves * kWave), lds,            \
                            (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train);                                \
     })
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
-    if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true); }
-    else { SMZ_LAUNCH_SEARCH(1, false); }
+    if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false); }
+    else if (P.A == h->maxa) { SMZ_LAUNCH_SEARCH(1, false, true); }
+    else { SMZ_LAUNCH_SEARCH(1, false, false); }
 #undef SMZ_LAUNCH_SEARCH
     h->root_ready = true;
     h->selected = false;
