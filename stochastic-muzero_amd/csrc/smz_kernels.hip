@@ -345,11 +345,12 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
 // 4096 trees on 256 CUs): A, tpw (and K when KS > 0) become compile-time constants for everything inlined below -- the
 // run-time `j < A` / `t < tpw` predicates otherwise live in hoisted 64-bit scalar masks, in a kernel that spills SGPRs.
 constexpr int kFastTpw = 2;
+constexpr int kFastH = 64;      // ... and the networks are the reference's default shape: 64 hidden units, no extra hidden layer
 template <int MAXA, int KS, int U, bool INSTR, bool AEX>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train) {
     Params P = Pin;
-    if (AEX) { P.A = MAXA; P.tpw = kFastTpw; }
+    if (AEX) { P.A = MAXA; P.tpw = kFastTpw; d.A = MAXA; d.H = kFastH; d.L = 0; d.OP = smz_mlp::kWave; }
     if (KS > 0) P.K = KS;
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
     const smz_mlp_desc dl = smz_mlp::lds_desc_without_rep(d);      // LDS copy: everything but the representation matrices
@@ -1106,7 +1107,7 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
     if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false); }
-    else if (P.A == h->maxa && tpw == kFastTpw) { SMZ_LAUNCH_SEARCH(1, false, true); }
+    else if (P.A == h->maxa && tpw == kFastTpw && desc->H == kFastH && desc->L == 0) { SMZ_LAUNCH_SEARCH(1, false, true); }
     else { SMZ_LAUNCH_SEARCH(1, false, false); }
 #undef SMZ_LAUNCH_SEARCH
     h->root_ready = true;
