@@ -341,16 +341,19 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
 
 // INSTR: instrumented build (level statistics, s_memtime phase stamps, SMZ_DEBUG_SKIP ablations); the production
 // instantiation carries none of it -- the accumulators alone cost a dozen scalar registers in a kernel that spills them.
-// AEX: the action count equals the MAXA bucket (2, 4, 8, ...) and a wavefront owns exactly two trees (the geometry of
-// 4096 trees on 256 CUs): A, tpw (and K when KS > 0) become compile-time constants for everything inlined below -- the
-// run-time `j < A` / `t < tpw` predicates otherwise live in hoisted 64-bit scalar masks, in a kernel that spills SGPRs.
-constexpr int kFastTpw = 2;
-constexpr int kFastH = 64;      // ... and the networks are the reference's default shape: 64 hidden units, no extra hidden layer
+// AEX ("exact"): the specialised instantiation for the common case -- the action count equals the MAXA bucket
+// (2, 4, 8, ...), a wavefront owns exactly two trees (the geometry of 4096 trees on 256 CUs) and the networks have the
+// shape the reference ships (state_space_dimensions 31, hidden_layer_dimensions 64, number_of_hidden_layer 0: 11 of
+// the 16 experiment configs under config/, and checkpoint 421).  A, tpw, K, S, H, L then are compile-time constants for
+// everything inlined below: layer loops unroll, and the run-time `j < A` / `t < tpw` / `k < K4` predicates no longer
+// live in hoisted 64-bit scalar masks (the generic instantiation spills ~90 SGPRs into VGPR lanes).  Any other
+// geometry or shape takes the generic instantiation; both produce identical results (tests/test_gpu_end_to_end.py).
+constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
 template <int MAXA, int KS, int U, bool INSTR, bool AEX>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train) {
     Params P = Pin;
-    if (AEX) { P.A = MAXA; P.tpw = kFastTpw; d.A = MAXA; d.H = kFastH; d.L = 0; d.OP = smz_mlp::kWave; }
+    if (AEX) { P.A = MAXA; P.tpw = kFastTpw; d.A = MAXA; d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = smz_mlp::kWave; P.S = kFastS; }
     if (KS > 0) P.K = KS;
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
     const smz_mlp_desc dl = smz_mlp::lds_desc_without_rep(d);      // LDS copy: everything but the representation matrices
@@ -1107,7 +1110,7 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
     if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false); }
-    else if (P.A == h->maxa && tpw == kFastTpw && desc->H == kFastH && desc->L == 0) { SMZ_LAUNCH_SEARCH(1, false, true); }
+    else if (P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL) { SMZ_LAUNCH_SEARCH(1, false, true); }
     else { SMZ_LAUNCH_SEARCH(1, false, false); }
 #undef SMZ_LAUNCH_SEARCH
     h->root_ready = true;
