@@ -254,9 +254,14 @@ __device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &
     wave_add_stats(P.stats, n_dec, n_chance, valid ? 1u : 0u, n_children);
 }
 
-template <int MAXA, int KS>
-__global__ void __launch_bounds__(kWave, 4) k_select(Params P, float *parent_hidden, int32_t *last_action,
+// AEX (instantiated for the MAXA 2 and 4 buckets): the action count equals the bucket, so A (and K when KS > 0) are
+// compile-time constants in everything inlined below (see k_search_mlp).
+template <int MAXA, int KS, bool AEX>
+__global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_hidden, int32_t *last_action,
                                                   uint8_t *branch, float *mlp_input) {
+    Params P = Pin;
+    if (AEX) P.A = MAXA;
+    if (KS > 0) P.K = KS;
     uint32_t *rng_tile = rng_tile_ptr(P);
     const int n_staged = rng_tile ? kRngStage : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
@@ -276,11 +281,14 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params P, float *parent_hid
     }
 }
 
-template <int MAXA, int KS, bool FUSE_SELECT>
-__global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params P, const float *hidden, const float *reward,
+template <int MAXA, int KS, bool FUSE_SELECT, bool AEX>
+__global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const float *hidden, const float *reward,
                                                          const float *policy, const float *value,
                                                          float *parent_hidden, int32_t *last_action, uint8_t *branch,
                                                          float *mlp_input) {
+    Params P = Pin;
+    if (AEX) P.A = MAXA;
+    if (KS > 0) P.K = KS;
     uint32_t *rng_tile = rng_tile_ptr(P);
     const int n_staged = rng_tile ? kRngStage : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
@@ -797,6 +805,20 @@ int launch_check() {
         case 16: { constexpr int MA = 16; __VA_ARGS__; } break; \
         default: { constexpr int MA = 32; __VA_ARGS__; } break; \
     }
+// same, plus the exact-action-count specialisation for the two small buckets (aex: A == bucket)
+#define SMZ_DISPATCH_AEX(maxa, aex, ...)                                                             \
+    switch (maxa) {                                                                                  \
+        case 2: if (aex) { constexpr int MA = 2; constexpr bool AEX = true; __VA_ARGS__; }            \
+                else { constexpr int MA = 2; constexpr bool AEX = false; __VA_ARGS__; } break;        \
+        case 4: if (aex) { constexpr int MA = 4; constexpr bool AEX = true; __VA_ARGS__; }            \
+                else { constexpr int MA = 4; constexpr bool AEX = false; __VA_ARGS__; } break;        \
+        case 8: { constexpr int MA = 8; constexpr bool AEX = false; __VA_ARGS__; } break;             \
+        case 16: { constexpr int MA = 16; constexpr bool AEX = false; __VA_ARGS__; } break;           \
+        default: { constexpr int MA = 32; constexpr bool AEX = false; __VA_ARGS__; } break;           \
+    }
+#define SMZ_DISPATCH2_AEX(maxa, k, aex, ...)                                          \
+    if ((k) == 2) { constexpr int KS = 2; SMZ_DISPATCH_AEX(maxa, aex, __VA_ARGS__); }  \
+    else { constexpr int KS = 0; SMZ_DISPATCH_AEX(maxa, aex, __VA_ARGS__); }
 // ... and on the children-per-expansion specialisation (KS = 2: the static two-child code, 0: run-time count)
 #define SMZ_DISPATCH2(maxa, k, ...)                                          \
     if ((k) == 2) { constexpr int KS = 2; SMZ_DISPATCH(maxa, __VA_ARGS__); }  \
@@ -1042,7 +1064,7 @@ int smz_select(smz_handle *h, float *parent_hidden_dev, int32_t *last_action_dev
     if (!h) return fail(SMZ_ERR_INVALID, "smz_select: null handle%s");
     if (!h->root_ready) return fail(SMZ_ERR_STATE, "smz_select before smz_root_init%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH2(h->maxa, h->K, hipLaunchKernelGGL((k_select<MA, KS>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P), (hipStream_t)stream, h->P,
+    SMZ_DISPATCH2_AEX(h->maxa, h->K, h->P.A == h->maxa, hipLaunchKernelGGL((k_select<MA, KS, AEX>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P), (hipStream_t)stream, h->P,
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
     h->selected = true;
     return launch_check();
@@ -1053,7 +1075,7 @@ int smz_expand_backup(smz_handle *h, const float *hidden_dev, const float *rewar
     if (!h || !policy_dev || !value_dev) return fail(SMZ_ERR_INVALID, "smz_expand_backup: null argument%s");
     if (!h->selected) return fail(SMZ_ERR_STATE, "smz_expand_backup without a preceding smz_select%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH2(h->maxa, h->K, hipLaunchKernelGGL((k_expand_backup<MA, KS, false>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
+    SMZ_DISPATCH2_AEX(h->maxa, h->K, h->P.A == h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, KS, false, AEX>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
                                              (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev,
                                              (float *)nullptr, (int32_t *)nullptr, (uint8_t *)nullptr, (float *)nullptr));
     h->selected = false;
@@ -1066,7 +1088,7 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
     if (!h || !policy_dev || !value_dev) return fail(SMZ_ERR_INVALID, "smz_expand_backup_select: null argument%s");
     if (!h->selected) return fail(SMZ_ERR_STATE, "smz_expand_backup_select without a preceding smz_select%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH2(h->maxa, h->K, hipLaunchKernelGGL((k_expand_backup<MA, KS, true>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
+    SMZ_DISPATCH2_AEX(h->maxa, h->K, h->P.A == h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, KS, true, AEX>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
                                              (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev,
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
     return launch_check();
