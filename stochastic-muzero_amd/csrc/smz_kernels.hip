@@ -1108,9 +1108,12 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     int kWaves = 8;
     if (const char *e = getenv("SMZ_SEARCH_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) kWaves = v; }
     Params P = h->P;
-    // trees per wave: the smallest power of two that covers B with 256 workgroups of 8 waves
+    // trees per wave: the smallest power of two that covers B with 256 workgroups of 8 waves, capped at 2 -- beyond
+    // 4096 trees the grid simply has more workgroups than CUs and they run one after another (each re-stages the
+    // weights, ~1 % of its run time): per-wave LDS buffers stay small and the specialised instantiation applies.
     int tpw = 1;
-    while (tpw < kWave && (size_t)256 * kWaves * tpw < (size_t)P.B) tpw <<= 1;
+    while (tpw < kFastTpw && (size_t)256 * kWaves * tpw < (size_t)P.B) tpw <<= 1;
+    if (const char *e = getenv("SMZ_SEARCH_TPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) tpw = v; }
     P.tpw = tpw;
     const MegaLds ml = mega_lds(*desc, P, tpw);
     const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave) * sizeof(float);

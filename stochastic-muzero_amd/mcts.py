@@ -88,6 +88,7 @@ class BatchedMCTS(_Hyper):
         self._graph = None
         self._graph_key = None
         self._single = None
+        self.single_launch_max_trees = 32768
 
     def _ensure_engine(self, num_actions, hidden_size):
         if self.engine is None or (self.engine.A, self.engine.S) != (num_actions, hidden_size):
@@ -154,7 +155,9 @@ class BatchedMCTS(_Hyper):
         enqueued on the current stream (read results with engine.root_stats() / engine.act()).
         With HipMlpHeads the whole search is ONE kernel launch (smz_search_mlp) when it fits in LDS; otherwise the
         step-wise kernels run, captured in a HIP graph unless use_graph is off."""
-        if self.single_launch and getattr(heads, "desc", None) is not None and self._single is not False:
+        # beyond ~32k trees the step-wise kernels (64 trees per wavefront, every lane busy) overtake the single launch
+        if (self.single_launch and getattr(heads, "desc", None) is not None and self._single is not False
+                and self.num_trees <= self.single_launch_max_trees):
             eng = self._ensure_engine(heads.A, heads.S)
             if getattr(self, "_pending_seed", None) is not None:
                 eng.seed(self._pending_seed)
