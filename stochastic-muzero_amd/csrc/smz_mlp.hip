@@ -20,12 +20,16 @@ namespace {
 extern __shared__ float4 smz_mlp_lds4[];
 
 // LDS map: [0, total_floats) the packed weights at their buffer offsets; then per-wave scratch
-template <int U>
+// FASTD: the reference's shipped network shape (S 31, H 64, L 0) with the dimensions as compile-time constants
+// (layer loops unroll; see k_search_mlp in smz_kernels.hip); A stays a run-time value here.
+constexpr int kFastS = 31, kFastH = 64, kFastL = 0;
+template <int U, bool FASTD>
 __global__ void __launch_bounds__(512) k_mlp_recurrent(smz_mlp_desc d, const float *weights, const float *x,
                                                        const uint8_t *branch, float *hidden_out, float *reward_out,
                                                        float *policy_out, float *value_out, int B, int rows_per_wave) {
     float *lds = reinterpret_cast<float *>(smz_mlp_lds4);
     stage_recurrent_weights(lds, weights, d);
+    if (FASTD) { d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = kWave; }
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, waves = blockDim.x / kWave;
     float *scratch = lds + d.total_floats + wave * scratch_floats(d);
     const int row0 = (blockIdx.x * waves + wave) * rows_per_wave;
@@ -154,10 +158,17 @@ int smz_mlp_recurrent(const smz_mlp_desc *d, const float *weights_dev, const flo
     int blocks, rpw;
     mlp_geometry(B, blocks, rpw);
     const size_t lds = ((size_t)d->total_floats + (size_t)kWavesPerWg * scratch_floats(*d)) * sizeof(float);
-    if (allow_lds(k_mlp_recurrent<1>, lds) != SMZ_OK) return SMZ_ERR_HIP;
-    hipLaunchKernelGGL((k_mlp_recurrent<1>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
-                       weights_dev, mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev,
-                       value_out_dev, B, rpw);
+    if (d->S == kFastS && d->H == kFastH && d->L == kFastL) {
+        if (allow_lds(k_mlp_recurrent<1, true>, lds) != SMZ_OK) return SMZ_ERR_HIP;
+        hipLaunchKernelGGL((k_mlp_recurrent<1, true>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
+                           weights_dev, mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev,
+                           value_out_dev, B, rpw);
+    } else {
+        if (allow_lds(k_mlp_recurrent<1, false>, lds) != SMZ_OK) return SMZ_ERR_HIP;
+        hipLaunchKernelGGL((k_mlp_recurrent<1, false>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
+                           weights_dev, mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev,
+                           value_out_dev, B, rpw);
+    }
     return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
 }
 
