@@ -254,6 +254,12 @@ __device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &
     wave_add_stats(P.stats, n_dec, n_chance, valid ? 1u : 0u, n_children);
 }
 
+// Block geometry as a function of A and K (the formulas of smz_create): with compile-time A / K these fold to constants.
+__device__ inline void fix_layout(Params &P, bool a_const, bool k_const) {
+    if (a_const) { P.rp_off = (5 * P.A + 1) & ~1; P.rb_words = ((P.rp_off + 2 * P.A) + 15) & ~15; }
+    if (k_const) P.eb_words = ((6 * P.K) + 15) & ~15;
+}
+
 // AEX (instantiated for the MAXA 2 and 4 buckets): the action count equals the bucket, so A (and K when KS > 0) are
 // compile-time constants in everything inlined below (see k_search_mlp).
 template <int MAXA, int KS, bool AEX>
@@ -262,6 +268,7 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
     Params P = Pin;
     if (AEX) P.A = MAXA;
     if (KS > 0) P.K = KS;
+    fix_layout(P, AEX, KS > 0);
     uint32_t *rng_tile = rng_tile_ptr(P);
     const int n_staged = rng_tile ? kRngStage : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
@@ -289,6 +296,7 @@ __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const fl
     Params P = Pin;
     if (AEX) P.A = MAXA;
     if (KS > 0) P.K = KS;
+    fix_layout(P, AEX, KS > 0);
     uint32_t *rng_tile = rng_tile_ptr(P);
     const int n_staged = rng_tile ? kRngStage : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
@@ -363,6 +371,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
     Params P = Pin;
     if (AEX) { P.A = MAXA; P.tpw = kFastTpw; d.A = MAXA; d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = smz_mlp::kWave; P.S = kFastS; }
     if (KS > 0) P.K = KS;
+    fix_layout(P, AEX, KS > 0);
+    if (AEX) P.hs = (kFastS + 15) & ~15;
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
     const smz_mlp_desc dl = smz_mlp::lds_desc_without_rep(d);      // LDS copy: everything but the representation matrices
     smz_mlp::stage_weights_without_rep(lds, weights, d);
