@@ -118,11 +118,31 @@ struct Rng {
         idx = (i + 1 == kMtN) ? 0 : i + 1;
         return mt_temper(y);
     }
+    // N consecutive words with ONE staged-words check and one bookkeeping update (a pUCT level needs 2 per child)
+    template <int N>
+    __device__ void take(uint32_t (&out)[N]) {
+        if (__builtin_expect(used + N <= staged, 1)) {
+#pragma unroll
+            for (int i = 0; i < N; i++) out[i] = stage[used + i];
+            used += N;
+            ready -= N;
+            idx += N;
+            if (idx >= kMtN) idx -= kMtN;
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; i++) out[i] = next32();
+        }
+    }
     // RandomState.random_sample(): (a * 2^26 + b) / 2^53 with a = 27 bits, b = 26 bits
-    __device__ double random_sample() {
-        const int32_t a = (int32_t)(next32() >> 5);
-        const int32_t b = (int32_t)(next32() >> 6);
+    __device__ static double to_double(uint32_t w0, uint32_t w1) {
+        const int32_t a = (int32_t)(w0 >> 5);
+        const int32_t b = (int32_t)(w1 >> 6);
         return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    __device__ double random_sample() {
+        uint32_t w[2];
+        take<2>(w);
+        return to_double(w[0], w[1]);
     }
 };
 
@@ -411,6 +431,12 @@ __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool n
                                     Rng &rng) {
     double best = 0.0;
     int pick = 0;
+    // the jitter words of all children at once when the child count is the (small) compile-time N: one staged-words
+    // check per level instead of one per draw; draw order is unchanged (child 0's pair first)
+    constexpr bool kBatch = N <= 4;
+    uint32_t jw[kBatch ? 2 * N : 2];
+    const bool batched = kBatch && cnt == N;
+    if (batched) rng.template take<kBatch ? 2 * N : 2>(jw);
 #pragma unroll
     for (int j = 0; j < N; j++) {
         if (j < cnt) {
@@ -424,7 +450,8 @@ __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool n
                 if (norm) { const float num = x - mn; x = num / span; }
                 value_score = (double)x;
             }
-            const double jitter = 1e-7 + (2e-7 - 1e-7) * rng.random_sample();
+            const double u = batched ? Rng::to_double(jw[kBatch ? 2 * j : 0], jw[kBatch ? 2 * j + 1 : 1]) : rng.random_sample();
+            const double jitter = 1e-7 + (2e-7 - 1e-7) * u;
             const double score = (prior_score + value_score) + jitter;
             if (j == 0 || score >= best) { best = score; pick = j; }  // exact tie -> larger action
         }

@@ -1144,8 +1144,14 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     })
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
-    if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false); }
-    else if (P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL) { SMZ_LAUNCH_SEARCH(1, false, true); }
+    const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL;
+    if ((P.stats || P.dbg) && fast && (P.dbg & 32) && h->maxa == 2 && h->K == 2) {
+        // phase stamps of the specialised instantiation itself (SMZ_DEBUG_SKIP=48), for the headline geometry only
+        constexpr int MA = 2, KS = 2;
+        hipLaunchKernelGGL((k_search_mlp<MA, KS, 1, true, true>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream,
+                           P, *desc, weights_dev, obs_dev, train);
+    } else if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false); }
+    else if (fast) { SMZ_LAUNCH_SEARCH(1, false, true); }
     else { SMZ_LAUNCH_SEARCH(1, false, false); }
 #undef SMZ_LAUNCH_SEARCH
     h->root_ready = true;
