@@ -203,8 +203,15 @@ __device__ inline void choice_noreplace(Rng &rng, double (&p)[MAXA], int n, int 
     int n_uniq = 0;
     while (n_uniq < size) {
         const int m = size - n_uniq;
+        if (MAXA <= 4 && m == MAXA) {            // a full round of draws: one staged-words check for all of them
+            uint32_t w[MAXA <= 4 ? 2 * MAXA : 2];
+            rng.template take<MAXA <= 4 ? 2 * MAXA : 2>(w);
 #pragma unroll
-        for (int i = 0; i < MAXA; i++) if (i < m) x[i] = rng.random_sample();
+            for (int i = 0; i < MAXA; i++) x[i] = Rng::to_double(w[MAXA <= 4 ? 2 * i : 0], w[MAXA <= 4 ? 2 * i + 1 : 1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MAXA; i++) if (i < m) x[i] = rng.random_sample();
+        }
         if (REG) {
 #pragma unroll
             for (int j = 0; j < MAXA; j++) {          // p[out[i]] = 0 for every pick so far
