@@ -173,9 +173,11 @@ __device__ inline int sample_cdf(const double *p, int n, double u) {
 #pragma unroll
     for (int i = 0; i < MAXA; i++) if (i < n) { acc += p[i]; cdf[i] = acc; }
     const double last = acc;
+    // the last entry is last / last: 1.0 (or NaN when the sum is 0 / inf), never <= u for u in [0, 1): neither the
+    // division nor the comparison can change the count
     int k = 0;
 #pragma unroll
-    for (int i = 0; i < MAXA; i++) if (i < n) k += ((cdf[i] / last) <= u) ? 1 : 0;
+    for (int i = 0; i < MAXA; i++) if (i < n - 1) k += ((cdf[i] / last) <= u) ? 1 : 0;
     return k;
 }
 
@@ -228,13 +230,13 @@ __device__ inline void choice_noreplace(Rng &rng, double (&p)[MAXA], int n, int 
         for (int i = 0; i < MAXA; i++) if (i < n) { acc += p[i]; cdf[i] = acc; }
         const double last = acc;
 #pragma unroll
-        for (int i = 0; i < MAXA; i++) if (i < n) cdf[i] = cdf[i] / last;
+        for (int i = 0; i < MAXA; i++) if (i < n - 1) cdf[i] = cdf[i] / last;     // entry n-1 would be 1.0 / NaN: see sample_cdf
 #pragma unroll
         for (int i = 0; i < MAXA; i++) {
             if (i < m) {
                 int k = 0;
 #pragma unroll
-                for (int j = 0; j < MAXA; j++) if (j < n) k += (cdf[j] <= x[i]) ? 1 : 0;
+                for (int j = 0; j < MAXA; j++) if (j < n - 1) k += (cdf[j] <= x[i]) ? 1 : 0;
                 cand[i] = k;
             }
         }
