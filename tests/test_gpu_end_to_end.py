@@ -544,3 +544,39 @@ def test_vectorised_value_targets_equal_the_per_game_make_target(td):
     # ignore_termination: every game spans the chunk
     length2, _, _ = sp.chunk_targets(dev, obs, A, disc, td, ignore_termination=True)
     assert (length2.cpu().numpy() == T).all()
+
+
+def test_specialised_generic_and_instrumented_search_kernels_agree():
+    """The three instantiations of the single-launch kernel on the same trees: the specialised one (A = bucket, two
+    trees per wave, shipped network shape -- the default at 4096 trees), the generic one (forced through another
+    trees-per-wave geometry) and the instrumented one (level statistics on).  Bit-identical outputs and streams."""
+    mcts_mod, model_mod, _, _ = _mods()
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_ckpt421.npz"))
+    heads = model.heads("cuda:0", backend="hip")
+    B, sims = 4096, 30
+    obs = torch.randn(B, 4, generator=torch.Generator().manual_seed(3)).mul(0.05).cuda()
+    res = []
+    for mode in ("specialised", "generic", "instrumented"):
+        if mode == "generic":
+            os.environ["SMZ_SEARCH_TPW"] = "4"
+        try:
+            m = mcts_mod.BatchedMCTS(B, num_simulations=sims, discount=0.999, root_exploration_fraction=0.1, use_graph=False)
+            m.seed(np.arange(B, dtype=np.uint64) + 11)
+            if mode == "instrumented":
+                m._ensure_engine(heads.A, heads.S).enable_stats(True)
+            e = m.run(obs, heads, train=True)
+            assert m._single is True
+            visits, priors, rv, cr = e.root_stats()
+            torch.cuda.synchronize()
+            if mode == "instrumented":
+                st = e.read_stats(reset=True)
+                assert st["descents"] == B * sims and st["decision_levels"] >= st["descents"]
+            res.append(([t.cpu().numpy().copy() for t in (visits, priors, rv, cr)], e.dump_tree(B - 1), e.get_rng_state(17)))
+        finally:
+            os.environ.pop("SMZ_SEARCH_TPW", None)
+    for other in res[1:]:
+        for a, b in zip(res[0][0], other[0]):
+            assert np.array_equal(a, b)
+        for k in res[0][1]:
+            assert np.array_equal(np.asarray(res[0][1][k]), np.asarray(other[1][k])), k
+        assert np.array_equal(res[0][2][0], other[2][0]) and res[0][2][1] == other[2][1]
