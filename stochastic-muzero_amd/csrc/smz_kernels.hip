@@ -108,6 +108,58 @@ __device__ inline int wave_stage_rng(const Params &P, int tree, bool valid, uint
     return wave_stage_rng_from<8>(P, tree, valid, lds_tile, valid ? P.rng_pos[tree] : 0);
 }
 
+// The same staging split in two for waves that own at most U trees: stage_issue requests the source words (the loads
+// stay in flight while the caller does unrelated work -- the network evaluation in k_search_mlp), stage_finish twists,
+// stores and fills the LDS tile.  Nothing may draw random words of these trees in between.
+template <int U>
+struct StagePre {
+    uint32_t w[U], b[U], c[U];
+};
+template <int U>
+__device__ inline void stage_issue(const Params &P, int tree, bool valid, int packed, StagePre<U> &pre) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tree0 = tree - lane;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int pk = __shfl(packed, u);
+        const bool vt = u < P.tpw && __shfl((int)valid, u) != 0;          // wave-uniform
+        const int idx = pk & 0xffff, ready = pk >> 16;
+        const uint32_t *mt = P.mt + (size_t)(tree0 + u) * kMtN;
+        int p = idx + lane;
+        if (p >= kMtN) p -= kMtN;
+        pre.w[u] = pre.b[u] = pre.c[u] = 0u;
+        if (vt) pre.w[u] = mt[p];
+        if (vt && lane >= ready) {
+            const int p1 = (p + 1 == kMtN) ? 0 : p + 1;
+            int pm = p + kMtM;
+            if (pm >= kMtN) pm -= kMtN;
+            pre.b[u] = mt[p1];
+            pre.c[u] = mt[pm];
+        }
+    }
+}
+template <int U>
+__device__ inline int stage_finish(const Params &P, int tree, bool valid, uint32_t *lds_tile, int packed, const StagePre<U> &pre) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tree0 = tree - lane;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int pk = __shfl(packed, u);
+        const bool vt = u < P.tpw && __shfl((int)valid, u) != 0;
+        const int idx = pk & 0xffff, ready = pk >> 16;
+        int p = idx + lane;
+        if (p >= kMtN) p -= kMtN;
+        uint32_t w = pre.w[u];
+        if (vt && lane >= ready) {
+            w = mt_twist(w, pre.b[u], pre.c[u]);
+            (P.mt + (size_t)(tree0 + u) * kMtN)[p] = w;
+        }
+        if (vt) lds_tile[u * kRngStride + lane] = mt_temper(w);
+    }
+    const int idx = packed & 0xffff, ready = packed >> 16;
+    return ((ready > kRngStage ? ready : kRngStage) << 16) | idx;
+}
+
 // Row moves.  `lpr` consecutive lanes move one row of `width` floats; the rows of the wave's 64 trees are handed
 // around with ds_bpermute.  Loads of kRowBatch rows are issued before the first store so that the (independent)
 // row reads overlap instead of each waiting behind the previous row's may-alias store.
@@ -417,10 +469,13 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
     unsigned long long t_stage = 0, t_expand = 0, t_select = 0, t_mlp = 0, t0 = 0, t1 = 0;
 #define SMZ_STAMP(acc) if (INSTR && prof) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
     // ---- simulations -------------------------------------------------------------------------------------------------
+    // Random words are staged once per round, for the NEXT round: the source words are requested right after the
+    // selection (the stream position is final then) and the loads fly during the network evaluation.
+    constexpr int SU = 2;
+    const bool split = P.tpw <= SU;
+    if (P.sims > 0 && !(dbg & 8)) packed = wave_stage_rng_from<4>(P, tree, valid, rng_tile, packed);
     for (int s = 0; s < P.sims; s++) {
         if (INSTR && prof) t0 = __builtin_amdgcn_s_memtime();
-        if (!(dbg & 8)) packed = wave_stage_rng_from<4>(P, tree, valid, rng_tile, packed);
-        SMZ_STAMP(t_stage)
         Leaf L = {0, 0, 0, 0};
         if (valid) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
@@ -439,6 +494,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         SMZ_STAMP(t_select)
         // hidden rows written in earlier rounds (by any lane of this wave) may be this round's parent rows
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        StagePre<SU> pre;       // (after the fence: it drains the vector-memory counter)
+        if (split && !(dbg & 8)) stage_issue<SU>(P, tree, valid, packed, pre);
         // all rows' network inputs first (independent global loads, one latency), then the rows one after another
         for (int t = 0; t < tpw; t++) {
             const int row = tree0 + t;
@@ -474,13 +531,15 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         }
         smz_mlp::lds_sync();
         SMZ_STAMP(t_mlp)
+        if (!(dbg & 8)) packed = split ? stage_finish<SU>(P, tree, valid, rng_tile, packed, pre)
+                                       : wave_stage_rng_from<4>(P, tree, valid, rng_tile, packed);
+        SMZ_STAMP(t_stage)
     }
 #undef SMZ_STAMP
     if (INSTR && prof && lane == 0) {
         atomicAdd(&P.stats[4], t_stage); atomicAdd(&P.stats[5], t_expand);
         atomicAdd(&P.stats[6], t_select); atomicAdd(&P.stats[7], t_mlp);
     }
-    if (P.sims > 0) packed = wave_stage_rng_from<4>(P, tree, valid, rng_tile, packed);   // words for the last expansion
     if (valid) {
         if (P.sims > 0) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
