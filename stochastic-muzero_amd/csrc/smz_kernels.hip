@@ -399,7 +399,7 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
     MegaLds m;
     m.pbc_off = r4(d.total_floats - smz_mlp::rep_floats(d));
     m.wave_off = m.pbc_off + r4(2 * (P.sims + 2));
-    m.x_off = r4(smz_mlp::scratch_floats(d));
+    m.x_off = r4(2 * smz_mlp::row_scratch_floats(d));     // two rows' scratch: a same-branch pair is evaluated together
     m.pv_off = m.x_off + tpw * smz_mlp::up4(P.S + P.A);
     m.rng_off = m.pv_off + tpw * P.P * 4;
     m.out_off = m.rng_off + r4(tpw * kRngStride);
@@ -506,7 +506,27 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
                 xall[t * K4in + k] = (k < S) ? src[k] : ((k < S + A && (k - S) == act) ? 1.f : 0.f);
         }
         smz_mlp::lds_sync();
-        for (int t = 0; t < tpw; t += smz_mlp::kRows) {
+        bool paired = false;
+        if (AEX && !(dbg & 1)) {
+            // the wave's two leaves need the same pair of networks: one pass, weights read from LDS once for both rows
+            const int b0 = __builtin_amdgcn_readlane(L.branch, 0), b1 = __builtin_amdgcn_readlane(L.branch, 1);
+            if (b0 == b1 && tree0 + 1 < P.B) {
+                const float *xin[2] = {xall, xall + K4in};
+                const bool dyn[2] = {b0 != 0, b0 != 0}, live[2] = {true, true};
+                float *dh[2], *dp[2] = {outs, outs + slot};
+                float reward[2], value[2];
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                    dh[r] = P.hidden + ((size_t)(tree0 + r) * P.N + __builtin_amdgcn_readlane(L.leaf_id, r)) * P.hs;
+                smz_mlp::recurrent_rows<U, 2, true>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
+                if (lane == 0) {
+                    outs[A] = value[0]; outs[A + 1] = reward[0];
+                    outs[slot + A] = value[1]; outs[slot + A + 1] = reward[1];
+                }
+                paired = true;
+            }
+        }
+        for (int t = 0; t < tpw && !paired; t += smz_mlp::kRows) {
             if (tree0 + t >= P.B) break;                         // wave-uniform
             constexpr int R = smz_mlp::kRows;
             const float *xin[R];

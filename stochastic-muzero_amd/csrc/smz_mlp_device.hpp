@@ -29,7 +29,8 @@ __device__ inline v2f pk_fma(float wx, float wy, float ax, float ay, v2f c) {
     v2f w = {wx, wy}, a = {ax, ay};
     return __builtin_elementwise_fma(w, a, c);
 }
-template <int U, int R>
+// SAME: every row uses row 0's matrix -- the weights are read from LDS once and applied to all R activation vectors
+template <int U, int R, bool SAME = false>
 __device__ inline void dense(const float *const (&W)[R], const float *const (&bias)[R], const float *const (&act)[R], int K4,
                              int OP, int lane, float (&acc)[R][U]) {
     const float4 *a4[R], *w4[R];
@@ -51,7 +52,7 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
             for (int j = 0; j < 4; j++) {
                 a[r][j] = a4[r][q + j];
 #pragma unroll
-                for (int u = 0; u < U; u++) w[r][u][j] = w4[r][(size_t)(q + j) * OP + kWave * u];
+                for (int u = 0; u < U; u++) w[r][u][j] = (SAME && r > 0) ? w[0][u][j] : w4[r][(size_t)(q + j) * OP + kWave * u];
             }
         }
 #pragma unroll
@@ -74,7 +75,7 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
             const float4 av = a4[r][q];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const float4 wv = w4[r][(size_t)q * OP + kWave * u];
+                const float4 wv = w4[SAME ? 0 : r][(size_t)q * OP + kWave * u];
                 v2f t = acc2[r][u];
                 t = pk_fma(wv.x, wv.y, av.x, av.y, t);
                 t = pk_fma(wv.z, wv.w, av.z, av.w, t);
@@ -338,14 +339,14 @@ __device__ inline MatOff pick(const smz_mlp_desc &d, bool first, int ma, int mb)
 
 // hidden trunk for R rows: in-layer + L repeats of the shared mid layer, ELU after each; results in tA[r] (LDS, zero
 // padded to a multiple of 4).  o_in[r] / o_mid[r]: each row's matrices.
-template <int U, int R>
+template <int U, int R, bool SAME = false>
 __device__ inline void trunk(const float *lds, const smz_mlp_desc &d, const MatOff (&o_in)[R], const MatOff (&o_mid)[R],
                              const float *const (&act_in)[R], int K4in, float *const (&tA)[R], int lane) {
     float acc[R][U];
     const float *W[R], *Bv[R];
 #pragma unroll
     for (int r = 0; r < R; r++) { W[r] = lds + o_in[r].w; Bv[r] = lds + o_in[r].b; }
-    dense<U, R>(W, Bv, act_in, K4in, d.OP, lane, acc);
+    dense<U, R, SAME>(W, Bv, act_in, K4in, d.OP, lane, acc);
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
@@ -355,7 +356,7 @@ __device__ inline void trunk(const float *lds, const smz_mlp_desc &d, const MatO
         const float *Wm[R], *Bm[R], *Am[R];
 #pragma unroll
         for (int r = 0; r < R; r++) { Wm[r] = lds + o_mid[r].w; Bm[r] = lds + o_mid[r].b; Am[r] = tA[r]; }
-        dense<U, R>(Wm, Bm, Am, up4(d.H), d.OP, lane, acc);
+        dense<U, R, SAME>(Wm, Bm, Am, up4(d.H), d.OP, lane, acc);
         lds_sync();   // every lane has issued its reads of tA (LDS is in order per wave) before it is overwritten
 #pragma unroll
         for (int r = 0; r < R; r++)
@@ -401,7 +402,7 @@ __host__ __device__ inline int scratch_floats(const smz_mlp_desc &d) { return kR
 // [hidden | one-hot], K4in floats, zero padded, in LDS.  dyn[r]: the row's branch.  live[r] = false suppresses the
 // row's global stores (odd tail).  Writes hidden' to dst_hidden[r] (S floats), the policy to dst_policy[r]; reward and
 // value are returned in every lane.
-template <int U, int R>
+template <int U, int R, bool SAME = false>
 __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, float *scratch, const float *const (&xin)[R],
                                       const bool (&dyn)[R], const bool (&live)[R], float *const (&dst_hidden)[R],
                                       float *const (&dst_policy)[R], float (&reward)[R], float (&value)[R]) {
@@ -418,7 +419,7 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         m3[r] = pick(d, dyn[r], M_PRE_IN, M_APR_IN);   m3m[r] = pick(d, dyn[r], M_PRE_MID, M_APR_MID);
         for (int k = lane; k < K4s; k += kWave) hbuf[r][k] = 0.f;
     }
-    trunk<U, R>(lds, d, m1, m1m, xin, K4in, tA, lane);
+    trunk<U, R, SAME>(lds, d, m1, m1m, xin, K4in, tA, lane);
     float acc[R][U];
     {
         const float *W[R], *Bv[R], *Ac[R];
@@ -427,7 +428,7 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
             const MatOff m = pick(d, dyn[r], M_DYN_OUT, M_ADY_OUT);
             W[r] = lds + m.w; Bv[r] = lds + m.b; Ac[r] = tA[r];
         }
-        dense<U, R>(W, Bv, Ac, K4h, d.OP, lane, acc);
+        dense<U, R, SAME>(W, Bv, Ac, K4h, d.OP, lane, acc);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -443,14 +444,14 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         const float *Hc[R];
 #pragma unroll
         for (int r = 0; r < R; r++) Hc[r] = hbuf[r];
-        trunk<U, R>(lds, d, m3, m3m, Hc, K4s, tA, lane);
+        trunk<U, R, SAME>(lds, d, m3, m3m, Hc, K4s, tA, lane);
         const float *W[R], *Bv[R], *Ac[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const MatOff m = pick(d, dyn[r], M_PRE_OUT, M_APR_OUT);
             W[r] = lds + m.w; Bv[r] = lds + m.b; Ac[r] = tA[r];
         }
-        dense<U, R>(W, Bv, Ac, K4h, d.OP, lane, acc);
+        dense<U, R, SAME>(W, Bv, Ac, K4h, d.OP, lane, acc);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
