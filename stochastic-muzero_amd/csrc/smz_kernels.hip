@@ -510,15 +510,16 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         if (AEX && !(dbg & 1)) {
             // the wave's two leaves need the same pair of networks: one pass, weights read from LDS once for both rows
             const int b0 = __builtin_amdgcn_readlane(L.branch, 0), b1 = __builtin_amdgcn_readlane(L.branch, 1);
-            if (b0 == b1 && tree0 + 1 < P.B) {
+            if (tree0 + 1 < P.B) {
                 const float *xin[2] = {xall, xall + K4in};
-                const bool dyn[2] = {b0 != 0, b0 != 0}, live[2] = {true, true};
+                const bool dyn[2] = {b0 != 0, b1 != 0}, live[2] = {true, true};
                 float *dh[2], *dp[2] = {outs, outs + slot};
                 float reward[2], value[2];
 #pragma unroll
                 for (int r = 0; r < 2; r++)
                     dh[r] = P.hidden + ((size_t)(tree0 + r) * P.N + __builtin_amdgcn_readlane(L.leaf_id, r)) * P.hs;
-                smz_mlp::recurrent_rows<U, 2, true>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
+                if (b0 == b1) smz_mlp::recurrent_rows<U, 2, true>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
+                else smz_mlp::recurrent_rows<U, 2, false>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
                 if (lane == 0) {
                     outs[A] = value[0]; outs[A + 1] = reward[0];
                     outs[slot + A] = value[1]; outs[slot + A + 1] = reward[1];

@@ -389,7 +389,8 @@ __device__ inline void stage_weights(float *lds, const float *weights, const int
     __syncthreads();
 }
 
-constexpr int kRows = 1;   // rows a wavefront evaluates together (2 was measured slower: the SIMD is issue-bound, not latency-bound)
+constexpr int kRows = 1;   // rows per pass of the stand-alone heads kernel and of the generic search kernel (the specialised
+                           // search kernel evaluates its two leaves as one two-row pass: smz_kernels.hip)
 
 // per-row LDS scratch: input vector | trunk activations | hidden state; a wave owns kRows of them
 __host__ __device__ inline int row_scratch_floats(const smz_mlp_desc &d) {
