@@ -171,6 +171,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Python's cyclic collector pauses the host for 30-50 ms when a full collection falls into the loop (torch keeps
+    # ~10^6 objects alive); the GPU drains its queue in a few ms, so such a pause inside the timed region would be charged
+    # to the engine.  Freeze what exists and keep the collector off while measuring.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     chunks = sp.play_games_grouped(groups, args.temperature, args.warmup)                 # W untimed warm-up steps
     if world > 1:      # the first grouped send/recv builds the RCCL communicators: keep that out of the timed region
         gather_mod.gather_to_learner(torch.cat([c.data[:max(1, args.warmup)] for c in chunks], dim=1))
