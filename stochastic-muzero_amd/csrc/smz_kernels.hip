@@ -8,6 +8,12 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction: parity with the reference's
 // separately rounded multiplies and adds).
+// SMZ_PART: 0 / undefined = the whole library part in one translation unit; the Makefile compiles this file twice --
+// 1 = everything but the single-launch search kernel, 2 = only that kernel and smz_search_mlp -- because its
+// instantiations are half of the compile time.
+#ifndef SMZ_PART
+#define SMZ_PART 0
+#endif
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -45,6 +51,7 @@ __host__ __device__ inline RowGeom row_geom(int width) {
 }
 
 // numpy `seed(int)`: init_genrand (numpy/random/src/mt19937/mt19937.c mt19937_seed); pos = 624.
+#if SMZ_PART != 2
 __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
     if (tree >= P.B) return;
@@ -56,6 +63,7 @@ __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds)
     }
     P.rng_pos[tree] = 0;  // idx 0, nothing pre-twisted: the first draw twists word 0 (== numpy pos 624)
 }
+#endif
 
 // Random-word staging: for each of the wave's 64 trees, all 64 lanes cooperate on that tree's NEXT 64 words --
 // lane j owns word (idx + j) mod 624; words not yet twisted (j >= ready) are twisted in place (every lane reads
@@ -268,6 +276,7 @@ __device__ inline uint32_t *rng_tile_ptr(const Params &P) {
     return reinterpret_cast<uint32_t *>(smz_dyn_lds + n);
 }
 
+#if SMZ_PART != 2
 template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidden, const float *policy,
                                                      const double *noise_override, int train) {
@@ -288,6 +297,7 @@ __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidd
         wave_copy_rows(hidden + (size_t)t * P.S, P.hidden + (size_t)t * P.N * P.hs, valid, P.S, P.tpw);
     }
 }
+#endif
 
 template <int MAXA, int KS>
 __device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &rng, TreeHdr &h, const double *pbc_lds,
@@ -314,6 +324,7 @@ __device__ inline void fix_layout(Params &P, bool a_const, bool k_const) {
 
 // AEX (instantiated for the MAXA 2 and 4 buckets): the action count equals the bucket, so A (and K when KS > 0) are
 // compile-time constants in everything inlined below (see k_search_mlp).
+#if SMZ_PART != 2
 template <int MAXA, int KS, bool AEX>
 __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_hidden, int32_t *last_action,
                                                   uint8_t *branch, float *mlp_input) {
@@ -339,7 +350,9 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
         P.hdr[tree] = h;
     }
 }
+#endif
 
+#if SMZ_PART != 2
 template <int MAXA, int KS, bool FUSE_SELECT, bool AEX>
 __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const float *hidden, const float *reward,
                                                          const float *policy, const float *value,
@@ -378,6 +391,7 @@ __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const fl
         P.hdr[tree] = h;
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Whole search in ONE launch (mlp_model heads): Monte_carlo_tree_search.run (mcts:311-349) for every tree.
@@ -417,6 +431,7 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
 // live in hoisted 64-bit scalar masks (the generic instantiation spills ~90 SGPRs into VGPR lanes).  Any other
 // geometry or shape takes the generic instantiation; both produce identical results (tests/test_gpu_end_to_end.py).
 constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
+#if SMZ_PART != 1
 template <int MAXA, int KS, int U, bool INSTR, bool AEX>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train) {
@@ -575,7 +590,9 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
     }
     if (INSTR) wave_add_stats(P.stats, n_dec, n_chance, n_desc, n_children);
 }
+#endif
 
+#if SMZ_PART != 2
 __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits, double *priors, float *root_value,
                                                       float *child_reward) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
@@ -592,7 +609,9 @@ __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits,
         root_value[tree] = h.root_visit ? h.root_value_sum / (float)h.root_visit : 0.0f;
     }
 }
+#endif
 
+#if SMZ_PART != 2
 template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_act(Params P, double temperature, int32_t *action, double *policy,
                                                double *child_visits, float *root_value) {
@@ -603,6 +622,7 @@ __global__ void __launch_bounds__(kWave) k_act(Params P, double temperature, int
     act_tree<MAXA>(P, tree, rng, temperature, action, policy, child_visits, root_value);
     P.rng_pos[tree] = rng.pack();
 }
+#endif
 
 // ---- head epilogues: `lpr` lanes cooperate on one row (coalesced loads, shuffle reductions) ------------------------
 __device__ inline float grp_max(float v, int lpr) {
@@ -648,19 +668,24 @@ __device__ inline void softmax_group(const float *row, int A, float *out, int li
     for (int i = li; i < A; i += lpr) out[i] = expf(row[i] - m) / den;
 }
 
+#if SMZ_PART != 2
 __global__ void __launch_bounds__(256) k_support_decode(const float *logits, int S, float *out, int B, int lpr) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
     const int row = gid < B ? gid : B - 1;     // surplus groups recompute the last row (keeps shuffles convergent)
     const float v = support_decode_group(logits + (size_t)row * S, S, li, lpr);
     if (gid < B && li == 0) out[row] = v;
 }
+#endif
 
+#if SMZ_PART != 2
 __global__ void __launch_bounds__(256) k_policy_softmax(const float *logits, int A, float *out, int B, int lpr) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
     if (gid < B) softmax_group(logits + (size_t)gid * A, A, out + (size_t)gid * A, li, lpr);
     else { float dummy[1]; softmax_group(logits + (size_t)(B - 1) * A, 0, dummy, li, lpr); }
 }
+#endif
 
+#if SMZ_PART != 2
 __global__ void __launch_bounds__(256) k_dynamics_epilogue(const float *state_dyn, const float *state_after,
                                                            const float *reward_logits, int ld, const uint8_t *branch,
                                                            int S, float *hidden_out, float *reward_out, int B, int lpr) {
@@ -682,7 +707,9 @@ __global__ void __launch_bounds__(256) k_dynamics_epilogue(const float *state_dy
         if (live && li == 0) reward_out[row] = dyn ? r : 0.f;
     }
 }
+#endif
 
+#if SMZ_PART != 2
 __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pred, const float *val_pred,
                                                              const float *pol_after, const float *val_after,
                                                              int ld, const uint8_t *branch, int A, int S,
@@ -702,8 +729,10 @@ __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pr
     const float v = support_decode_group((dyn ? val_pred : val_after) + (size_t)row * ld, S, li, lpr);
     if (live && li == 0) value_out[row] = v;
 }
+#endif
 
 // ---- synthetic env + trajectory record ---------------------------------------------------------------------------
+#if SMZ_PART != 2
 __global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int32_t *action, float *obs_out,
                                                        float *reward_out, uint8_t *term_out, int B) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -725,11 +754,13 @@ __global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int3
     if (reward_out) reward_out[e] = 1.0f;
     if (term_out) term_out[e] = (fabs(nx) > 2.4 || fabs(nth) > 12.0 * 2.0 * 3.14159265358979323846 / 360.0) ? 1 : 0;
 }
+#endif
 
 // record layout per (step, env):
 //   [obs(obs_dim) | reward | terminated | policy(A) | action one-hot(A) | root_value | child_visits(A)]
 // One thread per float64 of the step's [B][F] slab: writes are contiguous across the whole slab and the observation
 // reads are contiguous per row, whatever obs_dim is (4 for CartPole, 28812 for a 98x98x3 frame).
+#if SMZ_PART != 2
 __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, int obs_dim, int A, const float *obs,
                                                    const float *reward, const uint8_t *terminated, const int32_t *action,
                                                    const double *policy, const double *child_visits,
@@ -753,9 +784,11 @@ __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, i
         slab[i] = v;
     }
 }
+#endif
 
 // Game length of every env of a chunk: steps up to and including the first terminated one (chunk_to_games'/play_game's
 // cut, self_play.py:79-94), or T.
+#if SMZ_PART != 2
 __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T, int obs_dim, int A, int B, int ignore_term,
                                                       int32_t *length) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -767,6 +800,7 @@ __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T,
             if (traj[((size_t)t * B + e) * F + obs_dim + 1] != 0.0) { n = t + 1; break; }
     length[e] = n;
 }
+#endif
 
 // n-step value target of every stored position (the value entry of Game.make_target and the target inside
 // Game.make_priority, game.py:291-337), with the reference's scalar types: root values are numpy float32, rewards and
@@ -774,6 +808,7 @@ __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T,
 // float32 -- f32(root_value) * f32(discount^td), then one f32 add per reward of the f64 product reward * discount^i
 // rounded to f32 -- and a chain past the end of the game starts from a Python 0 and stays float64.
 // abs_td = |float64(root_value[t]) - target| (make_priority before ** priority_scale).  Positions t >= length are 0.
+#if SMZ_PART != 2
 __global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T, int obs_dim, int A, int B, int td,
                                                       const double *disc_pow, const int32_t *length, double *target,
                                                       double *abs_td) {
@@ -799,6 +834,7 @@ __global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T,
     target[i] = out;
     if (abs_td) abs_td[i] = err;
 }
+#endif
 
 }  // namespace
 
@@ -824,9 +860,15 @@ struct smz_handle {
     std::vector<void *> allocs;
 };
 
-namespace {
+// the last-error text is shared by the translation units this file is compiled into (SMZ_PART)
+#if SMZ_PART != 2
+thread_local char smz_g_err[512] = "";
+#else
+extern thread_local char smz_g_err[512];
+#endif
+#define g_err smz_g_err
 
-thread_local char g_err[512] = "";
+namespace {
 
 int fail(int code, const char *fmt, const char *detail = "") {
     snprintf(g_err, sizeof(g_err), fmt, detail);
@@ -918,6 +960,7 @@ int launch_check() {
 
 extern "C" {
 
+#if SMZ_PART != 2
 const char *smz_last_error(void) { return g_err; }
 int smz_abi_version(void) { return SMZ_ABI_VERSION; }
 int smz_node_capacity(const smz_handle *h) { return h ? h->N : SMZ_ERR_INVALID; }
@@ -1184,6 +1227,9 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
     return launch_check();
 }
 
+#endif  // SMZ_PART != 2
+
+#if SMZ_PART != 1
 int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
                    smz_stream stream) {
     if (!h || !desc || !weights_dev || !obs_dev) return fail(SMZ_ERR_INVALID, "smz_search_mlp: null argument%s");
@@ -1239,6 +1285,9 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     return launch_check();
 }
 
+#endif  // SMZ_PART != 1
+
+#if SMZ_PART != 2
 int smz_root_stats(smz_handle *h, int32_t *visits_dev, double *priors_dev, float *root_value_dev,
                    float *child_reward_dev, smz_stream stream) {
     if (!h) return fail(SMZ_ERR_INVALID, "smz_root_stats: null handle%s");
@@ -1416,5 +1465,7 @@ int smz_read_stats(smz_handle *h, uint64_t levels_out[4], int reset) {
     if (reset) HIP_TRY(hipMemset(h->d_stats, 0, sizeof(v)));
     return SMZ_OK;
 }
+
+#endif  // SMZ_PART != 2
 
 }  // extern "C"
