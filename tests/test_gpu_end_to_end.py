@@ -202,6 +202,8 @@ def test_single_tree_drop_in_matches_reference_game():
 
 
 @pytest.mark.parametrize("wname,B,sims,K", [("weights_ckpt421", 4096, 50, 2), ("weights_ckpt421", 100, 11, 2),
+                                            ("weights_ckpt421", 2049, 8, 2), ("weights_ckpt421", 4097, 9, 2),
+                                            ("weights_lunar_L0", 4096, 12, 2),
                                             ("weights_lunar_L0", 700, 30, 4), ("weights_lunar_L2", 256, 24, 3),
                                             ("weights_wide_A11", 130, 20, 9), ("weights_ckpt421", 70, 0, 2), ("weights_lunar_L0", 65, 1, 1)])
 def test_single_launch_search_equals_stepwise_search(wname, B, sims, K):
