@@ -304,6 +304,11 @@ int smz_traj_targets(const double *traj_dev, int T, int obs_dim, int A, int B, i
  * Returns the number of allocated nodes (>= 0) or a negative status. */
 int smz_debug_dump_tree(smz_handle *h, int tree, smz_node_view *nodes, int cap, float *minmax_out, int32_t *path_out,
                         int cap_path, int32_t *path_len_out, double *root_priors_out);
+/* Element-wise out = x / n computed the way the single-launch search divides the pUCT prior term by a visit count
+ * (correctly rounded reciprocal table + one FMA correction: smz_device.hpp div_by_count), n in [1, table_size).
+ * For tests: the results must equal the IEEE quotients bit for bit. */
+int smz_debug_div_by_count(const double *x_dev, const int32_t *n_dev, int count, int table_size, double *out_dev,
+                           smz_stream stream);
 /* Per-level counters accumulated by smz_select since the last reset (device-side atomics, off by default):
  * levels_out[0] = decision levels, [1] = chance levels, [2] = descents, [3] = children scored.  [sync] */
 int smz_enable_stats(smz_handle *h, int on);

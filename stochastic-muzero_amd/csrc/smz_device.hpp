@@ -434,10 +434,24 @@ __device__ inline int pick_chance(const Kids<N> &k, int cnt, Rng &rng) {
     return sample_cdf<N>(q64, cnt, rng.random_sample());
 }
 
+// Correctly rounded x / n for a visit count n in [1, sims + 1] through a table of correctly rounded reciprocals:
+// q = RN(x r) is a faithful quotient, e = x - q n is exact in an FMA, RN(q + e r) = RN(x / n) (Markstein's theorem; its
+// one exception, a divisor whose significand is all ones, cannot be a small integer).  x = sqrt(N) pb_c prior is a
+// normal number of moderate magnitude or exactly 0, so the correction term cannot underflow.  Three dependent
+// operations instead of the ~14 of the IEEE sequence, on the longest dependent chain of a tree level.
+// (tests/test_gpu_tree_parity.py::test_small_integer_division_is_correctly_rounded pins it against the IEEE quotient.)
+__device__ inline double div_by_count(double x, int n, const double *r64) {
+    const double r = r64[n], dn = (double)n;
+    const double q = x * r;
+    const double e = fma(-q, dn, x);
+    return fma(e, r, q);
+}
+
 // decision-flagged node: pUCT argmax (mcts:235-243, 257-259)
+// r64: reciprocal table (1/n at r64[n], n <= sims + 1) or nullptr (compile-time at every call site) for the IEEE division
 template <int N>
 __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool norm, float mn, float span, float disc32,
-                                    Rng &rng) {
+                                    Rng &rng, const double *r64 = nullptr) {
     double best = 0.0;
     int pick = 0;
     // the jitter words of all children at once when the child count is the (small) compile-time N: one staged-words
@@ -450,7 +464,7 @@ __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool n
     for (int j = 0; j < N; j++) {
         if (j < cnt) {
             const int Nc = k.vis[j];
-            const double prior_score = (sp * k.pri64[j]) / (double)(Nc + 1);
+            const double prior_score = r64 ? div_by_count(sp * k.pri64[j], Nc + 1, r64) : (sp * k.pri64[j]) / (double)(Nc + 1);
             double value_score = 0.0;
             if (Nc > 0) {
                 const float qv = k.vsum[j] / (float)Nc;
@@ -468,7 +482,8 @@ __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool n
     return pick;
 }
 
-template <int MAXA, int KS, bool STATS = true>
+// LUT: the reciprocal table of div_by_count follows the pb_c table (pbc_sqrt[sims + 2 + n] = 1 / n)
+template <int MAXA, int KS, bool STATS = true, bool LUT = false>
 __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const TreeHdr &h, const double *pbc_sqrt,
                                    int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children,
                                    uint4 *rec) {
@@ -482,7 +497,7 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
     {   // ---- root level: decision-flagged, A children, float64 priors ----------------------------------------------
         Kids<MAXA> k;
         load_kids_dyn<MAXA>(tb, A, true, P.rp_off, k);
-        const int pick = pick_decision<MAXA>(k, A, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng);
+        const int pick = pick_decision<MAXA>(k, A, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
         float pv = 0.f, pr = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXA; j++) if (j == pick) { c = k.chd[j]; cur_visit = k.vis[j]; action = j; pv = k.vsum[j]; pr = k.rew[j]; }
@@ -501,7 +516,7 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
         if (depth_flag(depth)) {
             pick = pick_chance<NK>(k, cnt, rng);
         } else {
-            pick = pick_decision<NK>(k, cnt, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng);
+            pick = pick_decision<NK>(k, cnt, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
         }
         float pv = 0.f, pr = 0.f;
 #pragma unroll

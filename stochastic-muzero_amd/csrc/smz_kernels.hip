@@ -412,7 +412,7 @@ __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params &P, int tpw) {
     MegaLds m;
     m.pbc_off = r4(d.total_floats - smz_mlp::rep_floats(d));
-    m.wave_off = m.pbc_off + r4(2 * (P.sims + 2));
+    m.wave_off = m.pbc_off + r4(2 * 2 * (P.sims + 2));     // pb_c table + reciprocal table (div_by_count)
     m.x_off = r4(2 * smz_mlp::row_scratch_floats(d));     // two rows' scratch: a same-branch pair is evaluated together
     m.pv_off = m.x_off + tpw * smz_mlp::up4(P.S + P.A);
     m.rng_off = m.pv_off + tpw * P.P * 4;
@@ -448,7 +448,10 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
     const MegaLds ml = mega_lds(d, P, tpw);
     double *pbc_lds = reinterpret_cast<double *>(lds + ml.pbc_off);
     const int n_pbc = P.sims + 2;
-    for (int i = threadIdx.x; i < n_pbc; i += blockDim.x) pbc_lds[i] = P.pbc_sqrt[i];
+    for (int i = threadIdx.x; i < n_pbc; i += blockDim.x) {
+        pbc_lds[i] = P.pbc_sqrt[i];
+        pbc_lds[n_pbc + i] = i > 0 ? 1.0 / (double)i : 0.0;      // IEEE division: correctly rounded reciprocals
+    }
     const int slot = A + 2;
     const int K4in = smz_mlp::up4(S + A);
     float *scratch = lds + ml.wave_off + wave * ml.per_wave;
@@ -501,7 +504,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         if (valid) {
             int len = 0;
             if (dbg & 2) { L.leaf_id = 1; L.parent_id = 0; L.action = 0; L.branch = 0; len = 1; }
-            else L = select_tree<MAXA, KS, INSTR>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
+            else L = select_tree<MAXA, KS, INSTR, true>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
             h.path_len = len;
             if (INSTR) n_desc++;
             packed = rng.pack();
@@ -833,6 +836,16 @@ __global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T,
     }
     target[i] = out;
     if (abs_td) abs_td[i] = err;
+}
+#endif
+
+#if SMZ_PART != 2
+// div_by_count against the IEEE division, element-wise (inspection: tests pin the table-based quotients)
+__global__ void __launch_bounds__(256) k_debug_div_by_count(const double *x, const int32_t *n, int count, int N, double *out) {
+    for (int i = threadIdx.x; i < N; i += blockDim.x) smz_dyn_lds[i] = i > 0 ? 1.0 / (double)i : 0.0;
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+        out[i] = div_by_count(x[i], n[i], smz_dyn_lds);
 }
 #endif
 
@@ -1393,6 +1406,15 @@ int smz_traj_targets(const double *traj_dev, int T, int obs_dim, int A, int B, i
     const size_t cells = (size_t)T * B;
     hipLaunchKernelGGL(k_traj_targets, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, (hipStream_t)stream, traj_dev, T,
                        obs_dim, A, B, td_steps, discount_pow_dev, length_dev, value_target_dev, abs_td_error_dev);
+    return launch_check();
+}
+
+int smz_debug_div_by_count(const double *x_dev, const int32_t *n_dev, int count, int table_size, double *out_dev,
+                           smz_stream stream) {
+    if (!x_dev || !n_dev || !out_dev || count < 1 || table_size < 2 || table_size > kPbcLdsMax)
+        return fail(SMZ_ERR_INVALID, "smz_debug_div_by_count: bad argument%s");
+    hipLaunchKernelGGL(k_debug_div_by_count, dim3(256), dim3(256), (size_t)table_size * sizeof(double), (hipStream_t)stream,
+                       x_dev, n_dev, count, table_size, out_dev);
     return launch_check();
 }
 

@@ -319,3 +319,25 @@ def test_launch_geometries_give_identical_trees(name, env, monkeypatch):
     for fused in (False, True):
         eng, cfg, data = gh.drive_fixture(name, fused=fused)
         gh.check_fixture_outputs(eng, cfg, data, prior_exact=False)
+
+
+def test_small_integer_division_is_correctly_rounded():
+    """div_by_count (reciprocal table + one FMA correction: how the single-launch search divides sqrt(N) pb_c prior by
+    1 + visit count) against the IEEE quotient, bit for bit: numerators over 60 binades (and 0), every divisor of a
+    203-entry table (100 simulations)."""
+    import ctypes as C
+    from importlib import import_module
+    import stochastic_muzero_amd  # noqa: F401
+    lib = import_module("stochastic-muzero_amd._lib").load()
+    g = np.random.RandomState(0)
+    count, N = 1 << 21, 203
+    x = np.abs(g.standard_normal(count)) * np.exp2(g.randint(-45, 15, count))
+    x[:4] = [0.0, 1.0, 3.0, 1e-12]
+    n = g.randint(1, N, count).astype(np.int32)
+    n[:N - 1] = np.arange(1, N)
+    dx, dn = torch.from_numpy(x).cuda(), torch.from_numpy(n).cuda()
+    out = torch.empty(count, dtype=torch.float64, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.smz_debug_div_by_count(P(dx), P(dn), count, N, P(out), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), x / n.astype(np.float64))
