@@ -89,8 +89,12 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
         for (int u = 0; u < U; u++) acc[r][u] = acc2[r][u].x + acc2[r][u].y;
 }
 
+// exp for the heads: the hardware exponential (v_exp_f32 on x log2 e, ~1 ulp) -- the network outputs are held to the
+// 1e-5 class against the reference's torch-CPU numbers, not to bit parity, and the library expf costs a dozen more
+// instructions per call on the leaf-evaluation path (ELU of every hidden unit, three softmaxes per leaf)
+__device__ inline float smz_exp(float x) { return __expf(x); }
 // torch's ELU evaluates exp(x) - 1 (aten/src/ATen/native/cpu/Activation.cpp elu_kernel)
-__device__ inline float elu(float x) { return x > 0.f ? x : expf(x) - 1.0f; }
+__device__ inline float elu(float x) { return x > 0.f ? x : smz_exp(x) - 1.0f; }
 // Wave-wide reductions on the DPP crossbar (VALU latency, no LDS round trips), written as fused v_<op>_f32_dpp
 // instructions: row_shr 1/2/4/8 build the totals of each 16-lane row in lanes 15/31/47/63 (a lane whose source lies
 // outside its row keeps its value: bound_ctrl off), row_bcast:15 / row_bcast:31 carry them across rows, lane 63 holds
@@ -194,7 +198,7 @@ __device__ inline float decode_lanes(const float (&v)[U], int lo, int S, int lan
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int o = lane + kWave * u;
-        if (o >= lo && o < lo + S) { const float e = expf(v[u] - m); den += e; num += (float)(o - lo - half) * e; }
+        if (o >= lo && o < lo + S) { const float e = smz_exp(v[u] - m); den += e; num += (float)(o - lo - half) * e; }
     }
     wave_sum2(den, num);
     const float y = num / den;
@@ -233,7 +237,7 @@ __device__ inline void softmax_lanes(const float (&v)[U], int A, int lane, float
     m = wave_max(m);
     float e[U], den = 0.f;
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; e[u] = (o < A) ? expf(v[u] - m) : 0.f; den += e[u]; }
+    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; e[u] = (o < A) ? smz_exp(v[u] - m) : 0.f; den += e[u]; }
     den = wave_sum(den);
 #pragma unroll
     for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) dst[o] = e[u] / den; }
@@ -265,7 +269,7 @@ __device__ inline float softmax_decode_lanes(const float (&v)[U], int A, int S, 
     for (int u = 0; u < U; u++) {
         const int o = lane + kWave * u;
         const bool pol = o < A, val = !pol && o < A + S;
-        e[u] = (pol || val) ? expf(v[u] - (pol ? mp : mv)) : 0.f;
+        e[u] = (pol || val) ? smz_exp(v[u] - (pol ? mp : mv)) : 0.f;
         if (pol) dp += e[u];
         if (val) { dv += e[u]; nv += (float)(o - A - half) * e[u]; }
     }
@@ -293,7 +297,7 @@ __device__ inline float decode_scale_lanes(const float (&v)[U], int S, int lane,
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int o = lane + kWave * u;
-        if (o < S) { const float e = expf(v[u] - mr); den += e; num += (float)(o - half) * e; }
+        if (o < S) { const float e = smz_exp(v[u] - mr); den += e; num += (float)(o - half) * e; }
     }
     wave_sum2(den, num);
     float sc = mx - mn;
