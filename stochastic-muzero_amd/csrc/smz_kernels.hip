@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         }
         smz_mlp::lds_sync();
         bool paired = false;
-        if (AEX && !(dbg & 1)) {
+        if (tpw == 2 && !(dbg & 1)) {
             // the wave's two leaves need the same pair of networks: one pass, weights read from LDS once for both rows
             const int b0 = __builtin_amdgcn_readlane(L.branch, 0), b1 = __builtin_amdgcn_readlane(L.branch, 1);
             if (tree0 + 1 < P.B) {
