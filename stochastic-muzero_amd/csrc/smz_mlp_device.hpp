@@ -203,7 +203,7 @@ __device__ inline float decode_lanes(const float (&v)[U], int lo, int S, int lan
     wave_sum2(den, num);
     const float y = num / den;
     const float sg = (y > 0.f) ? 1.f : ((y < 0.f) ? -1.f : 0.f);
-    const float r = (sqrtf(1.f + 4.f * 0.001f * (fabsf(y) + 1.f + 0.001f)) - 1.f) / (2.f * 0.001f);
+    const float r = (sqrtf(1.f + 4.f * 0.001f * (fabsf(y) + 1.f + 0.001f)) - 1.f) * 500.0f;
     return sg * (r * r - 1.f);
 }
 
@@ -221,7 +221,7 @@ __device__ inline void scale_lanes(const float (&v)[U], int lo, int S, int lane,
     for (int u = 0; u < U; u++) {
         const int o = lane + kWave * u;
         if (o >= lo && o < lo + S) {
-            const float h = (v[u] - mn) / sc;
+            const float h = __fdividef(v[u] - mn, sc);
             act_out[o - lo] = h;
             if (dst) dst[o - lo] = h;
             if (dst2) dst2[o - lo] = h;
@@ -240,13 +240,13 @@ __device__ inline void softmax_lanes(const float (&v)[U], int A, int lane, float
     for (int u = 0; u < U; u++) { const int o = lane + kWave * u; e[u] = (o < A) ? smz_exp(v[u] - m) : 0.f; den += e[u]; }
     den = wave_sum(den);
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) dst[o] = e[u] / den; }
+    for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) dst[o] = __fdividef(e[u], den); }
 }
 
 __device__ inline float support_to_scalar(float num, float den) {
     const float y = num / den;
     const float sg = (y > 0.f) ? 1.f : ((y < 0.f) ? -1.f : 0.f);
-    const float r = (sqrtf(1.f + 4.f * 0.001f * (fabsf(y) + 1.f + 0.001f)) - 1.f) / (2.f * 0.001f);
+    const float r = (sqrtf(1.f + 4.f * 0.001f * (fabsf(y) + 1.f + 0.001f)) - 1.f) * 500.0f;
     return sg * (r * r - 1.f);
 }
 
@@ -276,7 +276,7 @@ __device__ inline float softmax_decode_lanes(const float (&v)[U], int A, int S, 
     wave_sum3(dp, dv, nv);
     if (dst) {
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) dst[o] = e[u] / dp; }
+        for (int u = 0; u < U; u++) { const int o = lane + kWave * u; if (o < A) dst[o] = __fdividef(e[u], dp); }
     }
     return support_to_scalar(nv, dv);
 }
@@ -306,7 +306,7 @@ __device__ inline float decode_scale_lanes(const float (&v)[U], int S, int lane,
     for (int u = 0; u < U; u++) {
         const int o = lane + kWave * u;
         if (o >= S && o < 2 * S) {
-            const float h = (v[u] - mn) / sc;
+            const float h = __fdividef(v[u] - mn, sc);
             act_out[o - S] = h;
             if (dst) dst[o - S] = h;
         }
