@@ -450,6 +450,22 @@ __device__ inline double div_by_count(double x, int n, const double *r64) {
 // decision-flagged node: pUCT argmax (mcts:235-243, 257-259)
 // r64: reciprocal table (1/n at r64[n], n <= sims + 1) or nullptr (compile-time at every call site) for the IEEE division
 template <int N>
+__device__ inline double puct_score(const Kids<N> &k, int j, double sp, bool norm, float mn, float span, float disc32,
+                                    double u, const double *r64) {
+    const int Nc = k.vis[j];
+    const double prior_score = r64 ? div_by_count(sp * k.pri64[j], Nc + 1, r64) : (sp * k.pri64[j]) / (double)(Nc + 1);
+    double value_score = 0.0;
+    if (Nc > 0) {
+        const float qv = k.vsum[j] / (float)Nc;
+        const float dv = disc32 * qv;
+        float x = k.rew[j] + dv;
+        if (norm) { const float num = x - mn; x = num / span; }
+        value_score = (double)x;
+    }
+    const double jitter = 1e-7 + (2e-7 - 1e-7) * u;
+    return (prior_score + value_score) + jitter;
+}
+template <int N>
 __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool norm, float mn, float span, float disc32,
                                     Rng &rng, const double *r64 = nullptr) {
     double best = 0.0;
@@ -463,30 +479,46 @@ __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool n
 #pragma unroll
     for (int j = 0; j < N; j++) {
         if (j < cnt) {
-            const int Nc = k.vis[j];
-            const double prior_score = r64 ? div_by_count(sp * k.pri64[j], Nc + 1, r64) : (sp * k.pri64[j]) / (double)(Nc + 1);
-            double value_score = 0.0;
-            if (Nc > 0) {
-                const float qv = k.vsum[j] / (float)Nc;
-                const float dv = disc32 * qv;
-                float x = k.rew[j] + dv;
-                if (norm) { const float num = x - mn; x = num / span; }
-                value_score = (double)x;
-            }
             const double u = batched ? Rng::to_double(jw[kBatch ? 2 * j : 0], jw[kBatch ? 2 * j + 1 : 1]) : rng.random_sample();
-            const double jitter = 1e-7 + (2e-7 - 1e-7) * u;
-            const double score = (prior_score + value_score) + jitter;
+            const double score = puct_score<N>(k, j, sp, norm, mn, span, disc32, u, r64);
             if (j == 0 || score >= best) { best = score; pick = j; }  // exact tie -> larger action
         }
     }
     return pick;
 }
 
+// The same decision for a two-child level when TWO lanes of a quad work on the tree: lane `me` (0 / 1 = the tree's
+// own lane / its helper, two lanes further in the quad) scores child `me`, the scores are exchanged with a quad-perm
+// DPP and both lanes take the same pick.  Every lane consumes the level's four random words (its copy of the
+// tree's stream stays in step) and uses the pair belonging to its child.
+__device__ inline double quad_partner(double v) {          // value held by lane ^ 2
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline int pick_decision_pair(const Kids<2> &k, int me, double sp, bool norm, float mn, float span,
+                                         float disc32, Rng &rng, const double *r64) {
+    uint32_t jw[4];
+    rng.template take<4>(jw);
+    Kids<2> mine;                 // slot 0 = this lane's child
+    mine.vis[0] = me ? k.vis[1] : k.vis[0];
+    mine.vsum[0] = me ? k.vsum[1] : k.vsum[0];
+    mine.rew[0] = me ? k.rew[1] : k.rew[0];
+    mine.pri64[0] = me ? k.pri64[1] : k.pri64[0];
+    const double u = Rng::to_double(me ? jw[2] : jw[0], me ? jw[3] : jw[1]);
+    const double s_me = puct_score<2>(mine, 0, sp, norm, mn, span, disc32, u, r64);
+    const double s_other = quad_partner(s_me);
+    const double s0 = me ? s_other : s_me, s1 = me ? s_me : s_other;
+    return s1 >= s0 ? 1 : 0;      // exact tie -> larger action
+}
+
 // LUT: the reciprocal table of div_by_count follows the pb_c table (pbc_sqrt[sims + 2 + n] = 1 / n)
-template <int MAXA, int KS, bool STATS = true, bool LUT = false>
+// PAIR (MAXA == 2, KS == 2, A == 2): two lanes per tree, see pick_decision_pair; `me` = 0 for the tree's lane (which
+// alone writes the path records), 1 for its helper.  Chance levels are evaluated redundantly by both lanes.
+template <int MAXA, int KS, bool STATS = true, bool LUT = false, bool PAIR = false>
 __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const TreeHdr &h, const double *pbc_sqrt,
                                    int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children,
-                                   uint4 *rec) {
+                                   uint4 *rec, int me = 0) {
     constexpr int NK = KS > 0 ? KS : MAXA;     // register arrays of the expansion levels
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
@@ -497,11 +529,13 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
     {   // ---- root level: decision-flagged, A children, float64 priors ----------------------------------------------
         Kids<MAXA> k;
         load_kids_dyn<MAXA>(tb, A, true, P.rp_off, k);
-        const int pick = pick_decision<MAXA>(k, A, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
+        int pick;
+        if constexpr (PAIR) pick = pick_decision_pair(k, me, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
+        else pick = pick_decision<MAXA>(k, A, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
         float pv = 0.f, pr = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXA; j++) if (j == pick) { c = k.chd[j]; cur_visit = k.vis[j]; action = j; pv = k.vsum[j]; pr = k.rew[j]; }
-        rec[0] = make_uint4((uint32_t)pick, (uint32_t)cur_visit, __float_as_uint(pv), __float_as_uint(pr));
+        if (!PAIR || me == 0) rec[0] = make_uint4((uint32_t)pick, (uint32_t)cur_visit, __float_as_uint(pv), __float_as_uint(pr));
         leaf_id = 1 + pick;
         depth = 1;
     }
@@ -516,12 +550,13 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
         if (depth_flag(depth)) {
             pick = pick_chance<NK>(k, cnt, rng);
         } else {
-            pick = pick_decision<NK>(k, cnt, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
+            if constexpr (PAIR) pick = pick_decision_pair(k, me, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
+            else pick = pick_decision<NK>(k, cnt, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
         }
         float pv = 0.f, pr = 0.f;
 #pragma unroll
         for (int j = 0; j < NK; j++) if (j == pick) { c = k.chd[j]; cur_visit = k.vis[j]; action = k.act[j]; pv = k.vsum[j]; pr = k.rew[j]; }
-        rec[depth] = make_uint4((uint32_t)((blk << 8) | pick), (uint32_t)cur_visit, __float_as_uint(pv), __float_as_uint(pr));
+        if (!PAIR || me == 0) rec[depth] = make_uint4((uint32_t)((blk << 8) | pick), (uint32_t)cur_visit, __float_as_uint(pv), __float_as_uint(pr));
         parent_id = leaf_id;
         leaf_id = 1 + A + (blk - 1) * K + pick;
         depth++;

@@ -501,7 +501,31 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
                                                 outs[lane * slot + A], pvals + lane * P.P);
         }
         SMZ_STAMP(t_expand)
-        if (valid) {
+        // Specialised two-action kernel: the descent runs on lanes 0..3 -- lane t and its helper t + 2 score one child
+        // each (pick_decision_pair).  The helper works on a copy of the tree lane's stream position and MinMax bounds.
+        constexpr bool PAIR = AEX && MAXA == 2 && KS == 2 && !INSTR;
+        if constexpr (PAIR) {
+            const int src = lane & 1;
+            const int pk = __shfl(valid ? rng.pack() : 0, src), us = __shfl(valid ? rng.used : 0, src);
+            const float hmn = __shfl(h.mn, src), hmx = __shfl(h.mx, src);
+            const int hrv = __shfl(h.root_visit, src);
+            if (lane < 4 && tree0 + src < P.B) {
+                TreeHdr hs = h;
+                if (lane >= 2) {
+                    rng.load(P.mt + (size_t)(tree0 + src) * kMtN, pk, rng_tile + src * kRngStride, kRngStage);
+                    rng.used = us;
+                    hs.mn = hmn; hs.mx = hmx; hs.root_visit = hrv;
+                }
+                int len = 0;
+                const Leaf Lp = select_tree<MAXA, KS, false, true, true>(P, tree0 + src, rng, hs, pbc_lds, len, n_dec, n_chance,
+                                                                        n_children, pvals + src * P.P, lane >> 1);
+                if (lane < 2) {
+                    L = Lp;
+                    h.path_len = len;
+                    packed = rng.pack();
+                }
+            }
+        } else if (valid) {
             int len = 0;
             if (dbg & 2) { L.leaf_id = 1; L.parent_id = 0; L.action = 0; L.branch = 0; len = 1; }
             else L = select_tree<MAXA, KS, INSTR, true>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
