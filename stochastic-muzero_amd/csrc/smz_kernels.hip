@@ -1046,7 +1046,7 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     P.dbg = getenv("SMZ_DEBUG_SKIP") ? atoi(getenv("SMZ_DEBUG_SKIP")) : 0;
     {   // trees per wavefront: spread small batches over the whole chip (>= 1 wave per SIMD before packing lanes)
         int tpw = kWave;
-        while (tpw > 4 && (B + tpw - 1) / tpw < 1024) tpw >>= 1;
+        while (tpw > 1 && (B + tpw - 1) / tpw < 1024) tpw >>= 1;
         if (const char *e = getenv("SMZ_TREES_PER_WAVE")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) tpw = v;
