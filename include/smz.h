@@ -269,6 +269,12 @@ int smz_vision_recurrent(const smz_vision_desc *desc, const float *weights_dev, 
 int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
                    smz_stream stream);
 
+/* smz_search_mlp followed by smz_act (same arguments, same results, same stream position afterwards) in ONE launch:
+ * the action selection runs in the tail of the search kernel, on the lanes that own the trees. */
+int smz_search_mlp_act(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
+                       double temperature, const double *pow_table_host, int32_t *action_dev, double *policy_dev,
+                       double *child_visits_dev, float *root_value_dev, smz_stream stream);
+
 /* ---- synthetic environment + trajectory record (self_play.py:63-98 loop body around the search) -------------- */
 /* CartPole-v1 shaped Euler step on device (float64 state, float32 observation), used for the synthetic
  * fixed-length episodes of the benchmark: state_dev [B,4] f64 in/out, action_dev [B] i32,

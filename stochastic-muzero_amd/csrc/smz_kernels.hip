@@ -430,11 +430,17 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
 // everything inlined below: layer loops unroll, and the run-time `j < A` / `t < tpw` / `k < K4` predicates no longer
 // live in hoisted 64-bit scalar masks (the generic instantiation spills ~90 SGPRs into VGPR lanes).  Any other
 // geometry or shape takes the generic instantiation; both produce identical results (tests/test_gpu_end_to_end.py).
+struct ActOut {              // smz_search_mlp_act: Game.policy_step folded into the tail of the launch (action == nullptr: off)
+    double temperature;
+    int32_t *action;
+    double *policy, *child_visits;
+    float *root_value;
+};
 constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
 #if SMZ_PART != 1
 template <int MAXA, int KS, int U, bool INSTR, bool AEX>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
-                                                    int train) {
+                                                    int train, ActOut act) {
     Params P = Pin;
     if (AEX) { P.A = MAXA; P.tpw = kFastTpw; d.A = MAXA; d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = smz_mlp::kWave; P.S = kFastS; }
     if (KS > 0) P.K = KS;
@@ -612,8 +618,14 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
             for (int i = 0; i < h.path_len; i++) P.path[(size_t)tree * P.P + i] = pvals[lane * P.P + i];
             packed = rng.pack();
         }
-        P.rng_pos[tree] = packed;
         P.hdr[tree] = h;
+        if (act.action) {
+            // the post-search policy / action of game.py:179-232 on the finished tree: the same draws from the same
+            // stream position as a separate smz_act launch (rng still holds this tree's position)
+            act_tree<MAXA>(P, tree, rng, act.temperature, act.action, act.policy, act.child_visits, act.root_value);
+            packed = rng.pack();
+        }
+        P.rng_pos[tree] = packed;
     }
     if (INSTR) wave_add_stats(P.stats, n_dec, n_chance, n_desc, n_children);
 }
@@ -1267,8 +1279,8 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
 #endif  // SMZ_PART != 2
 
 #if SMZ_PART != 1
-int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
-                   smz_stream stream) {
+static int search_launch(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
+                         ActOut act, const double *pow_table_host, smz_stream stream) {
     if (!h || !desc || !weights_dev || !obs_dev) return fail(SMZ_ERR_INVALID, "smz_search_mlp: null argument%s");
     smz_mlp_desc t = *desc;
     if (smz_mlp_layout(&t) != SMZ_OK || t.total_floats != desc->total_floats)
@@ -1281,6 +1293,16 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     int kWaves = 8;
     if (const char *e = getenv("SMZ_SEARCH_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) kWaves = v; }
     Params P = h->P;
+    if (act.action && pow_table_host && act.temperature >= 0.3) {       // as smz_act: the power table of this temperature
+        if (!h->pow_valid || h->pow_T != act.temperature) {
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            HIP_TRY(hipMemcpy(h->d_pow, pow_table_host, ((size_t)h->cfg.num_simulations + 1) * sizeof(double),
+                              hipMemcpyHostToDevice));
+            h->pow_T = act.temperature;
+            h->pow_valid = true;
+        }
+        P.pow_table = h->d_pow;
+    }
     // trees per wave: the smallest power of two that covers B with 256 workgroups of 8 waves, capped at 2 -- beyond
     // 4096 trees the grid simply has more workgroups than CUs and they run one after another (each re-stages the
     // weights, ~1 % of its run time): per-wave LDS buffers stay small and the specialised instantiation applies.
@@ -1303,7 +1325,7 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
             granted = lds;                                                                                             \
         }                                                                                                              \
         hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR, AEX>), dim3(blocks), dim3(kWaves * kWave), lds,            \
-                           (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train);                                \
+                           (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act);                           \
     })
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
@@ -1312,7 +1334,7 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
         // phase stamps of the specialised instantiation itself (SMZ_DEBUG_SKIP=48), for the headline geometry only
         constexpr int MA = 2, KS = 2;
         hipLaunchKernelGGL((k_search_mlp<MA, KS, 1, true, true>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream,
-                           P, *desc, weights_dev, obs_dev, train);
+                           P, *desc, weights_dev, obs_dev, train, act);
     } else if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false); }
     else if (fast) { SMZ_LAUNCH_SEARCH(1, false, true); }
     else { SMZ_LAUNCH_SEARCH(1, false, false); }
@@ -1320,6 +1342,19 @@ int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights
     h->root_ready = true;
     h->selected = false;
     return launch_check();
+}
+
+int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
+                   smz_stream stream) {
+    return search_launch(h, desc, weights_dev, obs_dev, train, ActOut{0.0, nullptr, nullptr, nullptr, nullptr}, nullptr, stream);
+}
+
+int smz_search_mlp_act(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
+                       double temperature, const double *pow_table_host, int32_t *action_dev, double *policy_dev,
+                       double *child_visits_dev, float *root_value_dev, smz_stream stream) {
+    if (!action_dev || !policy_dev || !child_visits_dev) return fail(SMZ_ERR_INVALID, "smz_search_mlp_act: null output%s");
+    return search_launch(h, desc, weights_dev, obs_dev, train,
+                         ActOut{temperature, action_dev, policy_dev, child_visits_dev, root_value_dev}, pow_table_host, stream);
 }
 
 #endif  // SMZ_PART != 1

@@ -116,6 +116,7 @@ class SearchEngine:
         return t
 
     def root_init(self, hidden, policy, train=True, noise_override=None):
+        self._act_done = None
         hidden = self._f32(hidden.reshape(self.B, -1), (self.B, self.S)) if self.S > 0 else None
         policy = self._f32(policy, (self.B, self.A))
         if noise_override is not None:
@@ -144,11 +145,31 @@ class SearchEngine:
             _ptr(self.branch), _ptr(self.mlp_input) if (want_mlp_input and self.S > 0) else None, self._stream()))
         return self.parent_hidden, self.last_action, self.branch, self.mlp_input
 
-    def search_mlp(self, mlp_desc, weights, obs, train=True):
-        """Whole search (root + num_simulations rounds) in one launch with LDS-resident mlp_model heads."""
+    def _pow_table(self, temperature):
+        if temperature < 0.3:
+            return None
+        tab = self._pow_tables.get(temperature)
+        if tab is None:
+            tab = self._pow_tables[temperature] = pow_table(temperature, self.sims + 1)
+        return tab
+
+    def search_mlp(self, mlp_desc, weights, obs, train=True, act_temperature=None):
+        """Whole search (root + num_simulations rounds) in one launch with LDS-resident mlp_model heads.  With
+        `act_temperature` the action selection of act() runs in the tail of the same launch; the next act() call with
+        that temperature returns its outputs without launching anything."""
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[0] == self.B
-        _lib.check(self.lib.smz_search_mlp(self.h, C.byref(mlp_desc), _ptr(weights), _ptr(obs), int(bool(train)),
-                                           self._stream()))
+        self._act_done = None
+        if act_temperature is None:
+            _lib.check(self.lib.smz_search_mlp(self.h, C.byref(mlp_desc), _ptr(weights), _ptr(obs), int(bool(train)),
+                                               self._stream()))
+            return
+        T = float(act_temperature)
+        tab = self._pow_table(T)
+        _lib.check(self.lib.smz_search_mlp_act(self.h, C.byref(mlp_desc), _ptr(weights), _ptr(obs), int(bool(train)), T,
+                                               None if tab is None else tab.ctypes.data_as(C.c_void_p), _ptr(self.action),
+                                               _ptr(self.policy), _ptr(self.child_visits), _ptr(self.root_value),
+                                               self._stream()))
+        self._act_done = T
 
     def root_stats(self):
         _lib.check(self.lib.smz_root_stats(self.h, _ptr(self.visits), _ptr(self.priors), _ptr(self.root_value),
@@ -158,11 +179,11 @@ class SearchEngine:
     def act(self, temperature):
         """Game.policy_step's policy/action + store_search_statistics (game.py:179-235) for every tree."""
         temperature = float(temperature)
-        tab = None
-        if temperature >= 0.3:
-            tab = self._pow_tables.get(temperature)
-            if tab is None:
-                tab = self._pow_tables[temperature] = pow_table(temperature, self.sims + 1)
+        if getattr(self, "_act_done", None) == temperature:      # already computed in the tail of the search launch
+            self._act_done = None
+            return self.action, self.policy, self.child_visits, self.root_value
+        self._act_done = None
+        tab = self._pow_table(temperature)
         _lib.check(self.lib.smz_act(self.h, temperature, None if tab is None else tab.ctypes.data_as(C.c_void_p),
                                     _ptr(self.action), _ptr(self.policy), _ptr(self.child_visits), _ptr(self.root_value),
                                     self._stream()))

@@ -150,7 +150,7 @@ class BatchedMCTS(_Hyper):
             self._search(self._static_obs, heads, train)
         self._graph, self._graph_key = g, key
 
-    def run(self, observations, heads, train=True):
+    def run(self, observations, heads, train=True, act_temperature=None):
         """observations: [B, ...] float32 tensor on the engine's device.  Returns the engine; the search has been
         enqueued on the current stream (read results with engine.root_stats() / engine.act()).
         With HipMlpHeads the whole search is ONE kernel launch (smz_search_mlp) when it fits in LDS; otherwise the
@@ -163,7 +163,7 @@ class BatchedMCTS(_Hyper):
                 eng.seed(self._pending_seed)
                 self._pending_seed = None
             try:
-                eng.search_mlp(heads.desc, heads.weights, observations, train=train)
+                eng.search_mlp(heads.desc, heads.weights, observations, train=train, act_temperature=act_temperature)
                 self._single = True
                 return eng
             except Exception:

@@ -171,7 +171,7 @@ def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
     obs = env.obs
     P = lambda t: C.c_void_p(t.data_ptr())
     for t in range(steps):
-        eng = mcts.run(obs, heads, train=train)
+        eng = mcts.run(obs, heads, train=train, act_temperature=temperature)
         action, policy, child_visits, root_value = eng.act(temperature)
         obs, reward, terminated = env.step(action)
         _lib.check(lib.smz_traj_pack(P(chunk.data), chunk.T, t, env.obs_dim, A, P(obs), P(reward), P(terminated),
@@ -206,7 +206,7 @@ def play_games_grouped(groups, temperature, steps, train=True):
         for g in groups:
             with torch.cuda.stream(g.stream):
                 env = g.env
-                eng = g.mcts.run(env.obs, g.heads, train=train)
+                eng = g.mcts.run(env.obs, g.heads, train=train, act_temperature=temperature)
                 action, policy, child_visits, root_value = eng.act(temperature)
                 obs, reward, terminated = env.step(action)
                 _lib.check(lib.smz_traj_pack(P(g.chunk.data), g.chunk.T, t, env.obs_dim, env.num_actions, P(obs),

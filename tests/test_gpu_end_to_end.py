@@ -582,3 +582,28 @@ def test_specialised_generic_and_instrumented_search_kernels_agree():
         for k in res[0][1]:
             assert np.array_equal(np.asarray(res[0][1][k]), np.asarray(other[1][k])), k
         assert np.array_equal(res[0][2][0], other[2][0]) and res[0][2][1] == other[2][1]
+
+
+@pytest.mark.parametrize("T", [1.0, 0.5, 0.2, 0.0])
+def test_action_selection_in_the_tail_of_the_search_launch(T):
+    """smz_search_mlp_act == smz_search_mlp followed by smz_act: same actions, policies, child_visits, root values and
+    the same stream position afterwards, for every temperature regime of game.py:206-216."""
+    mcts_mod, model_mod, _, _ = _mods()
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_ckpt421.npz"))
+    heads = model.heads("cuda:0", backend="hip")
+    B = 4097
+    obs = torch.randn(B, 4, generator=torch.Generator().manual_seed(5)).mul(0.05).cuda()
+    res = []
+    for fused in (False, True):
+        m = mcts_mod.BatchedMCTS(B, num_simulations=17, discount=0.999, root_exploration_fraction=0.1, use_graph=False)
+        m.seed(np.arange(B, dtype=np.uint64) + 3)
+        e = m.run(obs, heads, train=True, act_temperature=T if fused else None)
+        assert (e._act_done == T) if fused else (e._act_done is None)
+        out = [t.clone() for t in e.act(T)]
+        assert e._act_done is None
+        torch.cuda.synchronize()
+        res.append(([t.cpu().numpy() for t in out], e.get_rng_state(0), e.get_rng_state(B - 1)))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for i in (1, 2):
+        assert np.array_equal(res[0][i][0], res[1][i][0]) and res[0][i][1] == res[1][i][1]
