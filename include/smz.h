@@ -281,6 +281,10 @@ int smz_search_mlp_act(smz_handle *h, const smz_mlp_desc *desc, const float *wei
  * obs_out_dev [B,4] f32, reward_out_dev [B] f32, terminated_out_dev [B] u8 (any output may be NULL). */
 int smz_cartpole_step(double *state_dev, const int32_t *action_dev, float *obs_out_dev, float *reward_out_dev,
                       uint8_t *terminated_out_dev, int B, smz_stream stream);
+/* smz_cartpole_step followed by smz_traj_pack (obs_dim 4, A 2) in one launch: same record, one launch less per env step. */
+int smz_cartpole_step_pack(double *state_dev, const int32_t *action_dev, float *obs_out_dev, float *reward_out_dev,
+                           uint8_t *terminated_out_dev, double *traj_dev, int T, int t, const double *policy_dev,
+                           const double *child_visits_dev, const float *root_value_dev, int B, smz_stream stream);
 /* Appends one env step of every tree to a fixed-length trajectory buffer laid out [T][B][F] (step-major, so one
  * step is one contiguous, coalesced slab and a finished chunk is one message for the trajectory gather):
  * what Game.policy_step / store_search_statistics append to their lists (game.py:193-195, 263-267).  Record of F =

@@ -78,6 +78,7 @@ SIGNATURES = {
     "smz_search_mlp_act": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
     "smz_search_mlp": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, _P]),
     "smz_cartpole_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
+    "smz_cartpole_step_pack": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
     "smz_traj_floats": (C.c_int, [C.c_int, C.c_int]),
     "smz_traj_pack": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_traj_targets": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P]),

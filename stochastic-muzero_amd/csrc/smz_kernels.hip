@@ -772,8 +772,11 @@ __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pr
 
 // ---- synthetic env + trajectory record ---------------------------------------------------------------------------
 #if SMZ_PART != 2
+// traj != nullptr: also appends the step's record (the layout of k_traj_pack, A = 2) -- one launch less per env step
 __global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int32_t *action, float *obs_out,
-                                                       float *reward_out, uint8_t *term_out, int B) {
+                                                       float *reward_out, uint8_t *term_out, int B, double *traj, int t,
+                                                       const double *policy, const double *child_visits,
+                                                       const float *root_value) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B) return;
     const double g = 9.8, mc = 1.0, mp = 0.1, tm = mc + mp, len = 0.5, pml = mp * len, fm = 10.0, tau = 0.02;
@@ -791,7 +794,19 @@ __global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int3
         o[0] = (float)nx; o[1] = (float)nxd; o[2] = (float)nth; o[3] = (float)nthd;
     }
     if (reward_out) reward_out[e] = 1.0f;
-    if (term_out) term_out[e] = (fabs(nx) > 2.4 || fabs(nth) > 12.0 * 2.0 * 3.14159265358979323846 / 360.0) ? 1 : 0;
+    const bool term = fabs(nx) > 2.4 || fabs(nth) > 12.0 * 2.0 * 3.14159265358979323846 / 360.0;
+    if (term_out) term_out[e] = term ? 1 : 0;
+    if (traj) {
+        constexpr int A = 2, F = 4 + 3 * A + 3;
+        double *r = traj + ((size_t)t * B + e) * F;
+        r[0] = (double)(float)nx; r[1] = (double)(float)nxd; r[2] = (double)(float)nth; r[3] = (double)(float)nthd;
+        r[4] = 1.0;
+        r[5] = term ? 1.0 : 0.0;
+        r[6] = policy[(size_t)e * A]; r[7] = policy[(size_t)e * A + 1];
+        r[8] = action[e] == 0 ? 1.0 : 0.0; r[9] = action[e] == 1 ? 1.0 : 0.0;
+        r[10] = (double)root_value[e];
+        r[11] = child_visits[(size_t)e * A]; r[12] = child_visits[(size_t)e * A + 1];
+    }
 }
 #endif
 
@@ -1435,7 +1450,18 @@ int smz_cartpole_step(double *state_dev, const int32_t *action_dev, float *obs_o
                       uint8_t *terminated_out_dev, int B, smz_stream stream) {
     if (!state_dev || !action_dev || B < 1) return fail(SMZ_ERR_INVALID, "smz_cartpole_step: bad argument%s");
     hipLaunchKernelGGL(k_cartpole_step, row_grid(B), dim3(256), 0, (hipStream_t)stream, state_dev, action_dev, obs_out_dev,
-                       reward_out_dev, terminated_out_dev, B);
+                       reward_out_dev, terminated_out_dev, B, (double *)nullptr, 0, (const double *)nullptr,
+                       (const double *)nullptr, (const float *)nullptr);
+    return launch_check();
+}
+
+int smz_cartpole_step_pack(double *state_dev, const int32_t *action_dev, float *obs_out_dev, float *reward_out_dev,
+                           uint8_t *terminated_out_dev, double *traj_dev, int T, int t, const double *policy_dev,
+                           const double *child_visits_dev, const float *root_value_dev, int B, smz_stream stream) {
+    if (!state_dev || !action_dev || !traj_dev || !policy_dev || !child_visits_dev || !root_value_dev || t < 0 || t >= T || B < 1)
+        return fail(SMZ_ERR_INVALID, "smz_cartpole_step_pack: bad argument%s");
+    hipLaunchKernelGGL(k_cartpole_step, row_grid(B), dim3(256), 0, (hipStream_t)stream, state_dev, action_dev, obs_out_dev,
+                       reward_out_dev, terminated_out_dev, B, traj_dev, t, policy_dev, child_visits_dev, root_value_dev);
     return launch_check();
 }
 

@@ -42,6 +42,15 @@ class CartPoleVec:
                                               C.c_void_p(self.terminated.data_ptr()), self.B, s))
         return self.obs, self.reward, self.terminated
 
+    def step_and_record(self, action, chunk_data, t, policy, child_visits, root_value):
+        """step(action) + the trajectory record of this step (smz_traj_pack's layout) in one launch."""
+        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        P = lambda x: C.c_void_p(x.data_ptr())
+        _lib.check(self.lib.smz_cartpole_step_pack(P(self.state), P(action), P(self.obs), P(self.reward), P(self.terminated),
+                                                   P(chunk_data), chunk_data.shape[0], int(t), P(policy), P(child_visits),
+                                                   P(root_value), self.B, s))
+        return self.obs, self.reward, self.terminated
+
 
 class SyntheticVec:
     """Observation-only stand-in (e.g. LunarLander-shaped: obs 8 ~ N(0,1), 4 actions; Box2D is absent here)."""

@@ -173,10 +173,13 @@ def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
     for t in range(steps):
         eng = mcts.run(obs, heads, train=train, act_temperature=temperature)
         action, policy, child_visits, root_value = eng.act(temperature)
-        obs, reward, terminated = env.step(action)
-        _lib.check(lib.smz_traj_pack(P(chunk.data), chunk.T, t, env.obs_dim, A, P(obs), P(reward), P(terminated),
-                                     P(action), P(policy), P(child_visits), P(root_value), env.B,
-                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if hasattr(env, "step_and_record"):          # built-in env: step + record in one launch
+            obs, reward, terminated = env.step_and_record(action, chunk.data, t, policy, child_visits, root_value)
+        else:
+            obs, reward, terminated = env.step(action)
+            _lib.check(lib.smz_traj_pack(P(chunk.data), chunk.T, t, env.obs_dim, A, P(obs), P(reward), P(terminated),
+                                         P(action), P(policy), P(child_visits), P(root_value), env.B,
+                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return chunk
 
 
@@ -208,10 +211,13 @@ def play_games_grouped(groups, temperature, steps, train=True):
                 env = g.env
                 eng = g.mcts.run(env.obs, g.heads, train=train, act_temperature=temperature)
                 action, policy, child_visits, root_value = eng.act(temperature)
-                obs, reward, terminated = env.step(action)
-                _lib.check(lib.smz_traj_pack(P(g.chunk.data), g.chunk.T, t, env.obs_dim, env.num_actions, P(obs),
-                                             P(reward), P(terminated), P(action), P(policy), P(child_visits),
-                                             P(root_value), env.B, C.c_void_p(g.stream.cuda_stream)))
+                if hasattr(env, "step_and_record"):      # built-in env: step + record in one launch
+                    env.step_and_record(action, g.chunk.data, t, policy, child_visits, root_value)
+                else:
+                    obs, reward, terminated = env.step(action)
+                    _lib.check(lib.smz_traj_pack(P(g.chunk.data), g.chunk.T, t, env.obs_dim, env.num_actions, P(obs),
+                                                 P(reward), P(terminated), P(action), P(policy), P(child_visits),
+                                                 P(root_value), env.B, C.c_void_p(g.stream.cuda_stream)))
     for g in groups:
         cur.wait_stream(g.stream)
     return [g.chunk for g in groups]

@@ -607,3 +607,32 @@ def test_action_selection_in_the_tail_of_the_search_launch(T):
         assert np.array_equal(a, b)
     for i in (1, 2):
         assert np.array_equal(res[0][i][0], res[1][i][0]) and res[0][i][1] == res[1][i][1]
+
+
+def test_env_step_with_record_equals_step_then_pack():
+    """smz_cartpole_step_pack == smz_cartpole_step + smz_traj_pack (state, observation, flags and the f64 record)."""
+    import ctypes as C
+    _, _, envs_mod, sp = _mods()
+    lib = import_module("stochastic-muzero_amd._lib").load()
+    B, T = 300, 3
+    g = torch.Generator().manual_seed(0)
+    action = torch.randint(0, 2, (B,), generator=g).int().cuda()
+    pol = torch.rand(B, 2, generator=g, dtype=torch.float64); pol = (pol / pol.sum(1, keepdim=True)).cuda()
+    cv = torch.rand(B, 2, generator=g, dtype=torch.float64).cuda()
+    rv = torch.randn(B, generator=g).cuda()
+    P = lambda x: C.c_void_p(x.data_ptr())
+    out = []
+    for fused in (False, True):
+        env = envs_mod.CartPoleVec(B, "cuda:0", seed=4); env.reset()
+        env.state[:5, 0] = 2.45                      # these envs terminate on this step
+        chunk = sp.TrajectoryChunk(T, B, 4, 2, "cuda:0")
+        if fused:
+            env.step_and_record(action, chunk.data, 1, pol, cv, rv)
+        else:
+            obs, rew, term = env.step(action)
+            assert lib.smz_traj_pack(P(chunk.data), T, 1, 4, 2, P(obs), P(rew), P(term), P(action), P(pol), P(cv), P(rv), B, None) == 0
+        torch.cuda.synchronize()
+        out.append([t.cpu().numpy().copy() for t in (env.state, env.obs, env.reward, env.terminated, chunk.data)])
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert out[0][4][1].any() and not out[0][4][0].any() and out[0][3].any()
