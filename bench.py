@@ -4,8 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
 
 A "step" is ONE env step of every environment of this rank: root inference, num_simulations x (select -> six-head
-evaluation -> expand + backup), action selection (smz_act), env step and trajectory record -- the loop body of
-self_play.py:79-94 for 4096 envs at once.  Workload at N=1 = BASELINE.json configs[1]: CartPole-v1 shaped synthetic
+evaluation -> expand + backup), action selection, env step and trajectory record -- the loop body of
+self_play.py:79-94 for 4096 envs at once (two launches: smz_search_mlp_act, smz_cartpole_step_pack).  Workload at N=1 = BASELINE.json configs[1]: CartPole-v1 shaped synthetic
 episodes, checkpoint-421 MLP heads (S31/H64/L0), 4096 envs x 50 simulations, per-tree numpy-legacy MT19937 streams
 (parity mode, the mode the parity tests pin).  Inputs (weights, env state, trees) are resident in HBM before the
 timed region.  N > 1: each rank owns 4096 envs (weak scaling), and the finished K-step trajectory chunk is gathered
@@ -278,7 +278,7 @@ def main():
         achieved = bytes_launch / (mean_us * 1e-6) / 1e9
         # HBM bytes per launch from the TCC counters, when a PMC pass of this workload/kernel has been committed
         traffic, traffic_note = None, None
-        tfile = os.path.join(ROOT, "profiles", "r01_m_traffic_k_search_mlp.json")
+        tfile = os.path.join(ROOT, "profiles", "r01_n_traffic_k_search_mlp.json")
         if single and Bg == 4096 and args.workload == "cartpole_mlp_4096x50" and os.path.exists(tfile):
             tj = json.load(open(tfile))
             traffic = tj["hbm_bytes_per_launch_raw"]
