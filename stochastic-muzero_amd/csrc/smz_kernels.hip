@@ -9,8 +9,10 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction: parity with the reference's
 // separately rounded multiplies and adds).
 // SMZ_PART: 0 / undefined = the whole library part in one translation unit; the Makefile compiles this file twice --
-// 1 = everything but the single-launch search kernel, 2 = only that kernel and smz_search_mlp -- because its
-// instantiations are half of the compile time.
+// 1 = everything but the single-launch search kernel and the fused expand+backup+select entry point, 2 = the search
+// kernel for the action buckets 2 and 4 with smz_search_mlp(_act), 4 = the search kernel for the buckets 8-32,
+// 3 = only smz_expand_backup_select -- the template instantiations behind those are most of the compile time, and the
+// parts build in parallel.
 #ifndef SMZ_PART
 #define SMZ_PART 0
 #endif
@@ -58,7 +60,7 @@ __host__ __device__ inline RowGeom row_geom(int width) {
 }
 
 // numpy `seed(int)`: init_genrand (numpy/random/src/mt19937/mt19937.c mt19937_seed); pos = 624.
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
     if (tree >= P.B) return;
@@ -283,7 +285,7 @@ __device__ inline uint32_t *rng_tile_ptr(const Params &P) {
     return reinterpret_cast<uint32_t *>(smz_dyn_lds + n);
 }
 
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidden, const float *policy,
                                                      const double *noise_override, int train) {
@@ -331,7 +333,7 @@ __device__ inline void fix_layout(Params &P, bool a_const, bool k_const) {
 
 // AEX (instantiated for the MAXA 2 and 4 buckets): the action count equals the bucket, so A (and K when KS > 0) are
 // compile-time constants in everything inlined below (see k_search_mlp).
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 template <int MAXA, int KS, bool AEX>
 __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_hidden, int32_t *last_action,
                                                   uint8_t *branch, float *mlp_input) {
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
 }
 #endif
 
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 template <int MAXA, int KS, bool FUSE_SELECT, bool AEX>
 __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const float *hidden, const float *reward,
                                                          const float *policy, const float *value,
@@ -444,7 +446,7 @@ struct ActOut {              // smz_search_mlp_act: Game.policy_step folded into
     float *root_value;
 };
 constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
-#if SMZ_PART != 1
+#if SMZ_PART == 0 || SMZ_PART == 2 || SMZ_PART == 4
 template <int MAXA, int KS, int U, bool INSTR, bool AEX>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train, ActOut act) {
@@ -640,7 +642,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
 }
 #endif
 
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits, double *priors, float *root_value,
                                                       float *child_reward) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
@@ -659,7 +661,7 @@ __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits,
 }
 #endif
 
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_act(Params P, double temperature, int32_t *action, double *policy,
                                                double *child_visits, float *root_value) {
@@ -716,7 +718,7 @@ __device__ inline void softmax_group(const float *row, int A, float *out, int li
     for (int i = li; i < A; i += lpr) out[i] = expf(row[i] - m) / den;
 }
 
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 __global__ void __launch_bounds__(256) k_support_decode(const float *logits, int S, float *out, int B, int lpr) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
     const int row = gid < B ? gid : B - 1;     // surplus groups recompute the last row (keeps shuffles convergent)
@@ -725,7 +727,7 @@ __global__ void __launch_bounds__(256) k_support_decode(const float *logits, int
 }
 #endif
 
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 __global__ void __launch_bounds__(256) k_policy_softmax(const float *logits, int A, float *out, int B, int lpr) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
     if (gid < B) softmax_group(logits + (size_t)gid * A, A, out + (size_t)gid * A, li, lpr);
@@ -733,7 +735,7 @@ __global__ void __launch_bounds__(256) k_policy_softmax(const float *logits, int
 }
 #endif
 
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 __global__ void __launch_bounds__(256) k_dynamics_epilogue(const float *state_dyn, const float *state_after,
                                                            const float *reward_logits, int ld, const uint8_t *branch,
                                                            int S, float *hidden_out, float *reward_out, int B, int lpr) {
@@ -757,7 +759,7 @@ __global__ void __launch_bounds__(256) k_dynamics_epilogue(const float *state_dy
 }
 #endif
 
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pred, const float *val_pred,
                                                              const float *pol_after, const float *val_after,
                                                              int ld, const uint8_t *branch, int A, int S,
@@ -780,7 +782,7 @@ __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pr
 #endif
 
 // ---- synthetic env + trajectory record ---------------------------------------------------------------------------
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 // traj != nullptr: also appends the step's record (the layout of k_traj_pack, A = 2) -- one launch less per env step
 __global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int32_t *action, float *obs_out,
                                                        float *reward_out, uint8_t *term_out, int B, double *traj, int t,
@@ -823,7 +825,7 @@ __global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int3
 //   [obs(obs_dim) | reward | terminated | policy(A) | action one-hot(A) | root_value | child_visits(A)]
 // One thread per float64 of the step's [B][F] slab: writes are contiguous across the whole slab and the observation
 // reads are contiguous per row, whatever obs_dim is (4 for CartPole, 28812 for a 98x98x3 frame).
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, int obs_dim, int A, const float *obs,
                                                    const float *reward, const uint8_t *terminated, const int32_t *action,
                                                    const double *policy, const double *child_visits,
@@ -851,7 +853,7 @@ __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, i
 
 // Game length of every env of a chunk: steps up to and including the first terminated one (chunk_to_games'/play_game's
 // cut, self_play.py:79-94), or T.
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T, int obs_dim, int A, int B, int ignore_term,
                                                       int32_t *length) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -871,7 +873,7 @@ __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T,
 // float32 -- f32(root_value) * f32(discount^td), then one f32 add per reward of the f64 product reward * discount^i
 // rounded to f32 -- and a chain past the end of the game starts from a Python 0 and stays float64.
 // abs_td = |float64(root_value[t]) - target| (make_priority before ** priority_scale).  Positions t >= length are 0.
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 __global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T, int obs_dim, int A, int B, int td,
                                                       const double *disc_pow, const int32_t *length, double *target,
                                                       double *abs_td) {
@@ -899,7 +901,7 @@ __global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T,
 }
 #endif
 
-#if SMZ_PART != 2
+#if SMZ_PART != 2 && SMZ_PART != 4
 // div_by_count against the IEEE division, element-wise (inspection: tests pin the table-based quotients)
 __global__ void __launch_bounds__(256) k_debug_div_by_count(const double *x, const int32_t *n, int count, int N, double *out) {
     for (int i = threadIdx.x; i < N; i += blockDim.x) smz_dyn_lds[i] = i > 0 ? 1.0 / (double)i : 0.0;
@@ -934,7 +936,7 @@ struct smz_handle {
 };
 
 // the last-error text is shared by the translation units this file is compiled into (SMZ_PART)
-#if SMZ_PART != 2
+#if SMZ_PART == 0 || SMZ_PART == 1
 thread_local char smz_g_err[512] = "";
 #else
 extern thread_local char smz_g_err[512];
@@ -1033,7 +1035,7 @@ int launch_check() {
 
 extern "C" {
 
-#if SMZ_PART != 2
+#if SMZ_PART == 0 || SMZ_PART == 1
 const char *smz_last_error(void) { return g_err; }
 int smz_abi_version(void) { return SMZ_ABI_VERSION; }
 int smz_node_capacity(const smz_handle *h) { return h ? h->N : SMZ_ERR_INVALID; }
@@ -1288,6 +1290,9 @@ int smz_expand_backup(smz_handle *h, const float *hidden_dev, const float *rewar
     return launch_check();
 }
 
+#endif
+
+#if SMZ_PART == 0 || SMZ_PART == 3
 int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float *reward_dev, const float *policy_dev,
                              const float *value_dev, float *parent_hidden_dev, int32_t *last_action_dev,
                              uint8_t *branch_dev, float *mlp_input_dev, smz_stream stream) {
@@ -1299,12 +1304,54 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
     return launch_check();
 }
+#endif
+
+#if SMZ_PART == 0 || SMZ_PART == 1
 
 #endif  // SMZ_PART != 2
 
-#if SMZ_PART != 1
-static int search_launch(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
-                         ActOut act, const double *pow_table_host, smz_stream stream) {
+#if SMZ_PART == 0 || SMZ_PART == 2 || SMZ_PART == 4
+// The instantiations are split over two translation units by action bucket (compile time): SMZ_PART 2 holds the
+// buckets 2 and 4 and the ABI entry points, SMZ_PART 4 the buckets 8, 16 and 32.
+#if SMZ_PART == 4
+#define SMZ_SEARCH_LAUNCH smz_internal_search_launch_wide
+#define SMZ_SEARCH_DISPATCH(maxa, ...)                                        \
+    switch (maxa) {                                                           \
+        case 8: { constexpr int MA = 8; __VA_ARGS__; } break;                 \
+        case 16: { constexpr int MA = 16; __VA_ARGS__; } break;               \
+        default: { constexpr int MA = 32; __VA_ARGS__; } break;               \
+    }
+#elif SMZ_PART == 2
+#define SMZ_SEARCH_LAUNCH smz_internal_search_launch_narrow
+#define SMZ_SEARCH_DISPATCH(maxa, ...)                                        \
+    switch (maxa) {                                                           \
+        case 2: { constexpr int MA = 2; __VA_ARGS__; } break;                 \
+        default: { constexpr int MA = 4; __VA_ARGS__; } break;                \
+    }
+#else
+#define SMZ_SEARCH_LAUNCH smz_internal_search_launch_narrow
+#define SMZ_SEARCH_DISPATCH(maxa, ...) SMZ_DISPATCH(maxa, __VA_ARGS__)
+#endif
+#define SMZ_SEARCH_DISPATCH2(maxa, k, ...)                                          \
+    if ((k) == 2) { constexpr int KS = 2; SMZ_SEARCH_DISPATCH(maxa, __VA_ARGS__); }  \
+    else { constexpr int KS = 0; SMZ_SEARCH_DISPATCH(maxa, __VA_ARGS__); }
+struct SearchActArgs {       // ActOut across the translation-unit boundary (plain data)
+    double temperature;
+    int32_t *action;
+    double *policy, *child_visits;
+    float *root_value;
+};
+}  // extern "C" (internal C++ linkage for the two launchers)
+int smz_internal_search_launch_narrow(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
+                                      int train, SearchActArgs a, const double *pow_table_host, smz_stream stream);
+int smz_internal_search_launch_wide(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
+                                    int train, SearchActArgs a, const double *pow_table_host, smz_stream stream);
+int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
+                      SearchActArgs a, const double *pow_table_host, smz_stream stream) {
+    const ActOut act = {a.temperature, a.action, a.policy, a.child_visits, a.root_value};
+#if SMZ_PART == 2
+    if (h && h->maxa > 4) return smz_internal_search_launch_wide(h, desc, weights_dev, obs_dev, train, a, pow_table_host, stream);
+#endif
     if (!h || !desc || !weights_dev || !obs_dev) return fail(SMZ_ERR_INVALID, "smz_search_mlp: null argument%s");
     smz_mlp_desc t = *desc;
     if (smz_mlp_layout(&t) != SMZ_OK || t.total_floats != desc->total_floats)
@@ -1339,7 +1386,7 @@ static int search_launch(smz_handle *h, const smz_mlp_desc *desc, const float *w
     if (lds > 160 * 1024) return fail(SMZ_ERR_INVALID, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
 #define SMZ_LAUNCH_SEARCH(UU, INSTR, AEX)                                                                              \
-    SMZ_DISPATCH2(h->maxa, h->K, {                                                                                     \
+    SMZ_SEARCH_DISPATCH2(h->maxa, h->K, {                                                                              \
         static size_t granted_dev[64] = {}; /* per instantiation and device: the opt-in is a host-side call */           \
         size_t &granted = granted_dev[h->cfg.device & 63];                                                             \
         if (lds > granted) {                                                                                           \
@@ -1354,12 +1401,15 @@ static int search_launch(smz_handle *h, const smz_mlp_desc *desc, const float *w
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
     const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL;
+#if SMZ_PART != 4
     if ((P.stats || P.dbg) && fast && (P.dbg & 32) && h->maxa == 2 && h->K == 2) {
         // phase stamps of the specialised instantiation itself (SMZ_DEBUG_SKIP=48), for the headline geometry only
         constexpr int MA = 2, KS = 2;
         hipLaunchKernelGGL((k_search_mlp<MA, KS, 1, true, true>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream,
                            P, *desc, weights_dev, obs_dev, train, act);
-    } else if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false); }
+    } else
+#endif
+    if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false); }
     else if (fast) { SMZ_LAUNCH_SEARCH(1, false, true); }
     else { SMZ_LAUNCH_SEARCH(1, false, false); }
 #undef SMZ_LAUNCH_SEARCH
@@ -1368,22 +1418,27 @@ static int search_launch(smz_handle *h, const smz_mlp_desc *desc, const float *w
     return launch_check();
 }
 
+extern "C" {
+#if SMZ_PART != 4
 int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
                    smz_stream stream) {
-    return search_launch(h, desc, weights_dev, obs_dev, train, ActOut{0.0, nullptr, nullptr, nullptr, nullptr}, nullptr, stream);
+    return smz_internal_search_launch_narrow(h, desc, weights_dev, obs_dev, train,
+                                             SearchActArgs{0.0, nullptr, nullptr, nullptr, nullptr}, nullptr, stream);
 }
 
 int smz_search_mlp_act(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
                        double temperature, const double *pow_table_host, int32_t *action_dev, double *policy_dev,
                        double *child_visits_dev, float *root_value_dev, smz_stream stream) {
     if (!action_dev || !policy_dev || !child_visits_dev) return fail(SMZ_ERR_INVALID, "smz_search_mlp_act: null output%s");
-    return search_launch(h, desc, weights_dev, obs_dev, train,
-                         ActOut{temperature, action_dev, policy_dev, child_visits_dev, root_value_dev}, pow_table_host, stream);
+    return smz_internal_search_launch_narrow(h, desc, weights_dev, obs_dev, train,
+                                             SearchActArgs{temperature, action_dev, policy_dev, child_visits_dev, root_value_dev},
+                                             pow_table_host, stream);
 }
+#endif  // SMZ_PART != 4
 
 #endif  // SMZ_PART != 1
 
-#if SMZ_PART != 2
+#if SMZ_PART == 0 || SMZ_PART == 1
 int smz_root_stats(smz_handle *h, int32_t *visits_dev, double *priors_dev, float *root_value_dev,
                    float *child_reward_dev, smz_stream stream) {
     if (!h) return fail(SMZ_ERR_INVALID, "smz_root_stats: null handle%s");
