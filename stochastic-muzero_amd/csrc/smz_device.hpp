@@ -582,9 +582,11 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
 // The path records of the preceding select carry every visited node's (visit, value_sum, reward): the backup only
 // STORES into the tree.  Returns the leaf's node id.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAXA, int KS>
+// EXPAND_ONLY: stop after the expansion and return the leaf reward through *leaf_reward_out -- the caller runs the
+// backup with backup_levels_lanes (several lanes per tree).
+template <int MAXA, int KS, bool EXPAND_ONLY = false>
 __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, TreeHdr &h, const float *policy_row,
-                                         float reward, float value, const uint4 *rec) {
+                                         float reward, float value, const uint4 *rec, float *leaf_reward_out = nullptr) {
     constexpr int CH = 8;   // path records fetched per round trip
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
@@ -633,6 +635,10 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, Tr
         lp[4 * lc + ls] = (uint32_t)(e + 1);             // leaf.children now live in expansion e
         lp[2 * lc + ls] = __float_as_uint(leaf_reward);
     }
+    if constexpr (EXPAND_ONLY) {
+        *leaf_reward_out = leaf_reward;
+        return loc_node_id(P, leaf_loc);
+    }
     // ---- backup, leaf -> root: stores only -----------------------------------------------------------------------
     float v = value;
     float mn = h.mn, mx = h.mx;
@@ -672,6 +678,53 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, Tr
     h.mn = mn;
     h.mx = mx;
     return loc_node_id(P, leaf_loc);
+}
+
+// The backup of expand_backup_tree with one lane per path level: lane (t + TPW * j) of the wave handles level
+// (base - j) of tree slot t, eight levels per pass.  The value recursion v <- r + disc v is a two-operation chain that
+// every lane repeats; the per-level work (visit / value_sum stores, the MinMax quotient) is the same arithmetic as in
+// the one-lane loop, so the tree and the bounds come out bit-identical; min / max are order-free.  Called by lanes
+// [0, 8 TPW); returns the tree's new MinMax bounds and the value arriving at the root in the lanes j == 0.
+template <int TPW>
+__device__ inline void backup_levels_lanes(const Params &P, int tree, int j, int len, float value, float leaf_reward,
+                                           const uint4 *rec, float &mn, float &mx, float &v_root) {
+    const int A = P.A, K = P.K;
+    uint32_t *tb = tree_base(P, tree);
+    float v = value;
+    for (int base = len - 1; base >= 0; base -= 8) {
+        float vin = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = base - q;
+            if (i >= 0) {                                   // uniform over the lanes of a tree
+                if (q == j) vin = v;
+                const float r = (i == len - 1) ? leaf_reward : __uint_as_float(rec[i].w);
+                const float dv = P.disc32 * v;
+                v = r + dv;
+            }
+        }
+        const int i = base - j;
+        if (i >= 0) {
+            const uint4 e4 = rec[i];
+            const int b = (int)e4.x >> 8, sl = (int)e4.x & 0xff;
+            const int cnt = (b == 0) ? A : K;
+            uint32_t *np = block_ptr(P, tb, b) + sl;
+            const float nvs = __uint_as_float(e4.z) + vin;
+            const int nvc = (int)e4.y + 1;
+            np[0] = (uint32_t)nvc;
+            np[cnt] = __float_as_uint(nvs);
+            const float qv = nvs / (float)nvc;
+            if (qv > mx) mx = qv;
+            if (qv < mn) mn = qv;
+        }
+    }
+    v_root = v;
+    // min / max over the tree's eight lanes (stride TPW inside one 16-lane row): shift-left reductions bring them to j == 0
+#pragma unroll
+    for (int sh = TPW; sh < 8 * TPW; sh <<= 1) {
+        mn = fminf(mn, __shfl_down(mn, sh));
+        mx = fmaxf(mx, __shfl_down(mx, sh));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -511,10 +511,38 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         if (INSTR && prof) t0 = __builtin_amdgcn_s_memtime();
         Leaf L = {0, 0, 0, 0};
         __builtin_amdgcn_s_setprio(SMZ_PRIO_TREE);
+        // Specialised kernel: the expansion runs in the tree's lane, the backup with one lane per path level
+        // (backup_levels_lanes: lanes t, t + 2, ..., t + 14 take eight levels of tree slot t per pass).
+        constexpr bool LBKP = AEX && !INSTR;
+        float leaf_rw = 0.f;
         if (valid) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            if (s > 0 && !(dbg & 4)) expand_backup_tree<MAXA, KS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
-                                                outs[lane * slot + A], pvals + lane * P.P);
+            if (s > 0 && !(dbg & 4)) expand_backup_tree<MAXA, KS, LBKP>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
+                                                      outs[lane * slot + A], pvals + lane * P.P, &leaf_rw);
+        }
+        if constexpr (LBKP) {
+            if (s > 0) {
+                const int src = lane & (kFastTpw - 1);
+                const int len = __shfl(h.path_len, src);
+                const float lrw = __shfl(leaf_rw, src);
+                if (lane < 8 * kFastTpw && tree0 + src < P.B) {
+                    const bool own = lane < kFastTpw;
+                    float mn = own ? h.mn : __builtin_inff(), mx = own ? h.mx : -__builtin_inff(), v_root = 0.f;
+                    backup_levels_lanes<kFastTpw>(P, tree0 + src, lane / kFastTpw, len, outs[src * slot + A], lrw,
+                                                  pvals + src * P.P, mn, mx, v_root);
+                    if (own) {   // the root itself (reward 0)
+                        const float nvs = h.root_value_sum + v_root;
+                        const int nvc = h.root_visit + 1;
+                        h.root_value_sum = nvs;
+                        h.root_visit = nvc;
+                        const float qv = nvs / (float)nvc;
+                        if (qv > mx) mx = qv;
+                        if (qv < mn) mn = qv;
+                        h.mn = mn;
+                        h.mx = mx;
+                    }
+                }
+            }
         }
         SMZ_STAMP(t_expand)
         // Specialised two-action kernel: the descent runs on lanes 0..3 -- lane t and its helper t + 2 score one child
