@@ -278,7 +278,7 @@ def main():
         achieved = bytes_launch / (mean_us * 1e-6) / 1e9
         # HBM bytes per launch from the TCC counters, when a PMC pass of this workload/kernel has been committed
         traffic, traffic_note = None, None
-        tfile = os.path.join(ROOT, "profiles", "r01_o_traffic_k_search_mlp.json")
+        tfile = os.path.join(ROOT, "profiles", "r01_p_traffic_k_search_mlp.json")
         if single and Bg == 4096 and args.workload == "cartpole_mlp_4096x50" and os.path.exists(tfile):
             tj = json.load(open(tfile))
             traffic = tj["hbm_bytes_per_launch_raw"]
