@@ -171,6 +171,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # one priming step outside everything: code-object upload, LDS opt-in and allocator warm-up are initialisation, not
+    # part of a step (a run with --warmup 0 would otherwise time them)
+    sp.play_games_grouped(groups, args.temperature, 1)
+    torch.cuda.synchronize(dev)
     # Python's cyclic collector pauses the host for 30-50 ms when a full collection falls into the loop (torch keeps
     # ~10^6 objects alive); the GPU drains its queue in a few ms, so such a pause inside the timed region would be charged
     # to the engine.  Freeze what exists and keep the collector off while measuring.
