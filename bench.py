@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- MCTS simulations/sec of the batched self-play engine (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+N > 1 is served either way the driver may start it: under `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...` (RANK / WORLD_SIZE in the environment), or as plain `python bench.py --gpus N`, in which case this process
+touches no GPU at all: it starts the N rank processes through torch.distributed.run as a child and exits with its status.
+A WORLD_SIZE that disagrees with --gpus is an error, not a silent single-GPU run.
 
 A "step" is ONE env step of every environment of this rank: root inference, num_simulations x (select -> six-head
 evaluation -> expand + backup), action selection, env step and trajectory record -- the loop body of
-self_play.py:79-94 for 4096 envs at once (two launches: smz_search_mlp_act, smz_cartpole_step_pack).  Workload at N=1 = BASELINE.json configs[1]: CartPole-v1 shaped synthetic
-episodes, checkpoint-421 MLP heads (S31/H64/L0), 4096 envs x 50 simulations, per-tree numpy-legacy MT19937 streams
-(parity mode, the mode the parity tests pin).  Inputs (weights, env state, trees) are resident in HBM before the
-timed region.  N > 1: each rank owns 4096 envs (weak scaling), and the finished K-step trajectory chunk is gathered
-to rank 0 over RCCL inside the timed region.
+self_play.py:79-94 for 4096 envs at once (two launches for the MLP workloads: smz_search_mlp_act and the env step +
+record).  Workload at N = 1 = BASELINE.json configs[1]: CartPole-v1 shaped synthetic episodes, checkpoint-421 MLP heads
+(S31/H64/L0), 4096 envs x 50 simulations, per-tree numpy-legacy MT19937 streams (parity mode, the mode the parity tests
+pin).  Inputs (weights, env state, trees) are resident in HBM before the timed region.  N > 1: each rank owns 4096 envs
+(weak scaling) and the finished K-step trajectory chunk is gathered to rank 0 over RCCL inside the timed region.
 
-The JSON line also carries
-  roofline     -- the dominant tree kernel's algorithmic bytes (SURVEY.md 8d formula evaluated on this run's own
-                  level histogram) / its mean launch duration measured with events on the launching stream;
-  cpu_baseline -- the CPU oracle (oracle/smz_oracle.c, plain-C heads, one game per thread) timed on this box's host
-                  cores on a bounded sample of the same workload.
+Timing: after W warm-up steps, R blocks of EXACTLY K steps are timed, each bracketed by barrier + torch.cuda.synchronize
+on both sides, the block time being the MAX over ranks; R is chosen so that the timed region is about 0.5 s or more
+(one 10 ms block is at the mercy of a host hiccup).  `value` and `ms_per_step` come from the MEDIAN block; the spread
+is in `timing`.
+
+The JSON line also carries, for every workload,
+  roofline     -- the dominant kernel's algorithmic bytes (SURVEY.md 8d formula evaluated on this run's own level
+                  histogram) / its mean launch duration measured with events on the launching stream;
+  cpu_baseline -- the CPU oracle (oracle/smz_oracle.c with plain-C heads, one game per thread; for the vision family the
+                  oracle tree driven by torch-CPU batch-1 heads, the reference's own shape) timed on this box's host cores
+                  on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,9 +40,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -43,6 +53,7 @@ WORKLOADS = {
     # (--heads torch: the same modules through torch-ROCm, for comparison)
     "vision_resnet_1024x50": dict(weights="visionnet_L1_seed0.npz", env="image", obs=3 * 98 * 98, A=2, K=2, sims=50, envs=1024),
 }
+TRAFFIC_FILES = {"cartpole_mlp_4096x50": "r02_traffic_k_search_mlp.json"}
 
 
 def algorithmic_bytes(stats, A, K, S, launches):
@@ -57,40 +68,99 @@ def algorithmic_bytes(stats, A, K, S, launches):
     return k2, k5, depth
 
 
-def cpu_baseline(wl, weights_path, seconds_target=15.0):
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))               # cores this process may actually run on
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline_mlp(wl, weights_path, seconds_target=15.0):
     """The CPU oracle on all host cores, on a bounded sample of the same workload (about 10-30 s of CPU work)."""
+    import numpy as np
     import orc
     w = orc.MlpWeights.from_npz(weights_path)
-    try:
-        cores = len(os.sched_getaffinity(0))               # cores this process may actually run on
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     cfg = orc.make_cfg(wl["A"], wl["K"], w.dims["S"], wl["sims"], discount=0.999, alpha=0.25, frac=0.1)
     rs = np.random.RandomState(0)
-    obs1 = rs.uniform(-0.05, 0.05, (4, 4))
-    t1 = time.perf_counter()
-    one = orc.selfplay_cartpole(cfg, w, obs1, np.arange(4, dtype=np.uint32), 64, temperature=1.0, train=True, threads=1,
-                                record=False)
-    single = one["simulations"] / (time.perf_counter() - t1)
-
-    def run(n_env, steps):
-        obs0 = rs.uniform(-0.05, 0.05, (n_env, 4))
-        t0 = time.perf_counter()
-        out = orc.selfplay_cartpole(cfg, w, obs0, np.arange(n_env, dtype=np.uint32), steps, temperature=1.0,
-                                    train=True, threads=cores, record=False)
-        return out["simulations"], time.perf_counter() - t0
     steps = 64                                                 # the synthetic episode length of the workload
-    n_env = 2 * cores
-    sims, dt = run(n_env, steps)                               # calibration pass (also warms the thread pool)
+    cart = wl["env"] == "cartpole"
+
+    def run(n_env, n_steps, threads):
+        seeds = np.arange(n_env, dtype=np.uint32)
+        t0 = time.perf_counter()
+        if cart:
+            out = orc.selfplay_cartpole(cfg, w, rs.uniform(-0.05, 0.05, (n_env, 4)), seeds, n_steps, temperature=1.0,
+                                        train=True, threads=threads, record=False)
+        else:
+            out = orc.selfplay_observations(cfg, w, rs.standard_normal((n_env, n_steps, wl["obs"])).astype(np.float32), seeds,
+                                            temperature=1.0, train=True, threads=threads, record=False)
+        return out["simulations"], time.perf_counter() - t0
+    sims, dt = run(4, steps, 1)
+    single = sims / dt
+    sims, dt = run(2 * cores, steps, cores)                    # calibration pass (also warms the thread pool)
     rate = sims / dt
     n_env = int(max(cores, min(64 * cores, rate * seconds_target / (steps * wl["sims"]))))
     n_env -= n_env % cores
-    sims, dt = run(n_env, steps)
+    sims, dt = run(n_env, steps, cores)
+    what = "CartPole" if cart else f"N(0,1)-observation (obs {wl['obs']}, {wl['A']} actions)"
     return dict(value=sims / dt, unit="simulations/s", cores=cores, kind="port",
-                sample=f"{n_env} envs x {steps} steps x {wl['sims']} sims of the same CartPole workload, C oracle "
+                sample=f"{n_env} envs x {steps} steps x {wl['sims']} sims of the same {what} workload, C oracle "
                        f"(oracle/smz_oracle.c) with plain-C MLP heads, {cores} threads (one game per thread), "
                        f"{dt:.1f} s wall = {dt * cores:.0f} core-seconds; one thread alone: {single:.0f} simulations/s "
                        f"(os.cpu_count() = {os.cpu_count()})")
+
+
+def cpu_baseline_vision(wl, model, seconds_target=12.0):
+    """Vision family: the oracle's tree arithmetic (C) driven by the model's batch-1 torch-CPU inference functions -- the
+    call shape of the reference's own search (muzero_model.py:802-909), one process, one torch thread."""
+    import numpy as np
+    import torch
+    import orc
+    torch.set_num_threads(1)
+    A, K, sims = wl["A"], wl["K"], wl["sims"]
+    cfg = orc.make_cfg(A, K, 147, sims, discount=0.999, alpha=0.25, frac=0.1)
+    rs = np.random.RandomState(0)
+
+    def search(tree, frame):
+        h = model.representation_function_inference(frame)
+        pol, _ = model.prediction_function_inference(h)
+        tree.root_init(np.asarray(pol, np.float32).reshape(-1), hidden=h.numpy().reshape(-1), train=True)
+        for _ in range(sims):
+            leaf, parent, act, flag, ph = tree.select(want_hidden=True)
+            ph = torch.from_numpy(ph[:147].reshape(1, 3, 7, 7))
+            if flag:
+                reward, h2 = model.dynamics_function_inference(ph, act)
+                pol, val = model.prediction_function_inference(h2)
+            else:
+                reward, h2 = 0.0, model.afterstate_dynamics_function_inference(ph, act)
+                pol, val = model.afterstate_prediction_function_inference(h2)
+            tree.expand_backup(np.asarray(pol, np.float32).reshape(-1), float(val), reward=float(reward), hidden=h2.numpy().reshape(-1))
+    t0 = time.perf_counter()
+    done = 0
+    tree = orc.Tree(cfg)
+    tree.seed(0)
+    while time.perf_counter() - t0 < seconds_target:
+        search(tree, torch.from_numpy(rs.rand(1, 3, 98, 98).astype(np.float32)))
+        done += sims
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="simulations/s", cores=1, kind="port",
+                sample=f"{done // sims} searches x {sims} sims on 98x98x3 frames, oracle tree (oracle/smz_oracle.c) driven by "
+                       f"batch-1 torch-CPU heads of the same ResNet-v2 weights, 1 process / 1 torch thread, {dt:.1f} s")
+
+
+def self_launch(args, argv):
+    """--gpus N without a launcher: start the N ranks as a CHILD (torch.distributed.run) before anything here has
+    touched a GPU; this process only waits and passes the status on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -109,20 +179,38 @@ def main():
     ap.add_argument("--stepwise", action="store_true", help="never use the single-launch search kernel")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SMZ_STREAM_GROUPS", "1")),
                     help="independent env groups per GPU, each on its own HIP stream")
+    ap.add_argument("--min-timed-seconds", type=float, default=0.5, help="repeat the K-step block until this much is timed")
+    ap.add_argument("--max-blocks", type=int, default=200)
+    ap.add_argument("--host-env", action="store_true",
+                    help="cartpole workloads: step the envs on the HOST (envs.HostVecEnv over numpy CartPoles): the "
+                         "PCIe-inclusive rate of the boundary's host-buffer variant")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}.  Run `python bench.py --gpus N` on its own "
+                         f"(it starts the N ranks itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`.")
+
+    import numpy as np
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the search engine has no CPU fallback")
-    local_rank = local_rank % torch.cuda.device_count()      # (functional tests may oversubscribe one GPU)
+    n_dev = torch.cuda.device_count()
+    shared_gpu = world > n_dev                                  # functional runs: several ranks on one GPU
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SMZ_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm; it cannot place two ranks on one device, so a run with more ranks than GPUs (the
+        # 1-GPU functional test of the N > 1 path) exchanges through gloo and says so in its JSON line
+        backend = os.environ.get("SMZ_DIST_BACKEND", "gloo" if shared_gpu else "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -152,7 +240,10 @@ def main():
     groups = []
     for gi in range(G):
         glo = lo + gi * Bg
-        if wl["env"] == "cartpole":
+        if wl["env"] == "cartpole" and args.host_env:
+            env = envs_mod.HostVecEnv([envs_mod.HostCartPole() for _ in range(Bg)], 4, 2, dev, env_seed=0, limit=0,
+                                      on_end="reset", first_env=glo)
+        elif wl["env"] == "cartpole":
             env = envs_mod.CartPoleVec(Bg, dev, seed=0, first_env=glo, total_envs=total)
         elif wl["env"] == "image":
             env = envs_mod.ImageVec(Bg, wl["A"], dev, seed=0, first_env=glo, total_envs=total)
@@ -171,6 +262,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_block():
+        """EXACTLY K steps (+ the trajectory gather when N > 1) between two barrier + synchronize pairs; max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        chunks = sp.play_games_grouped(groups, args.temperature, args.steps)
+        if world > 1:
+            gather_mod.gather_to_learner(torch.cat([c.data[:args.steps] for c in chunks], dim=1))   # -> learner rank
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
     # one priming step outside everything: code-object upload, LDS opt-in and allocator warm-up are initialisation, not
     # part of a step (a run with --warmup 0 would otherwise time them)
     sp.play_games_grouped(groups, args.temperature, 1)
@@ -185,40 +293,58 @@ def main():
     chunks = sp.play_games_grouped(groups, args.temperature, args.warmup)                 # W untimed warm-up steps
     if world > 1:      # the first grouped send/recv builds the RCCL communicators: keep that out of the timed region
         gather_mod.gather_to_learner(torch.cat([c.data[:max(1, args.warmup)] for c in chunks], dim=1))
-    barrier()
-    t0 = time.perf_counter()
-    chunks = sp.play_games_grouped(groups, args.temperature, args.steps)                  # EXACTLY K timed steps
-    if world > 1:
-        slab = torch.cat([c.data[:args.steps] for c in chunks], dim=1)
-        gather_mod.gather_to_learner(slab)                                               # trajectories -> learner rank
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    first = timed_block()                                      # block 1 (timed like the others; also sizes R)
+    R = int(min(args.max_blocks, max(1, np.ceil(args.min_timed_seconds / max(first, 1e-6)))))
+    blocks = [first] + [timed_block() for _ in range(R - 1)]
+    dt = float(np.median(blocks))
+    per_rank_rate = None
+    if world > 1:                                              # every rank's own rate of its last block, for the record
+        barrier()
+        t0 = time.perf_counter()
+        sp.play_games_grouped(groups, args.temperature, args.steps)
+        torch.cuda.synchronize(dev)
+        mine = B * wl["sims"] * args.steps / (time.perf_counter() - t0)
+        rates = [None] * world
+        dist.all_gather_object(rates, mine)
+        per_rank_rate = [float(r) for r in rates]
     sims_total = total * wl["sims"] * args.steps
-    headline = args.workload == "cartpole_mlp_4096x50" and B == 4096
+    headline = args.workload == "cartpole_mlp_4096x50" and B == 4096 and not args.host_env
+    single = getattr(mcts, "_single", None) is True
     data_note = {"cartpole": "synthetic (CartPole-shaped Euler env, fixed-length episodes; checkpoint-421 weights)",
-                 "synthetic": "synthetic (N(0,1) observations of LunarLander width; random-init weights, reference init rule)",
+                 "synthetic": "synthetic (N(0,1) observations of LunarLander width generated on the device; random-init weights, reference init rule)",
                  "image": "synthetic (uniform 98x98x3 frames scrolled per step; random-init ResNet-v2 weights)"}[wl["env"]]
+    config = {"workload": args.workload, "envs_per_gpu": B, "num_simulations": wl["sims"],
+              "actions": wl["A"], "children_per_expansion": wl["K"],
+              "hidden_floats": int(groups[0].heads.S) if hasattr(groups[0].heads, "S") else model.state_dimension,
+              "rng": "per-tree MT19937 (numpy-legacy, parity mode)",
+              "search": "one launch per env step (smz_search_mlp_act)" if single else
+                        ("step-wise kernels" + ("" if args.no_graph else ", one HIP graph per env step")),
+              "stream_groups": G, "heads": type(groups[0].heads).__name__,
+              "env": "host (envs.HostVecEnv, pinned-memory action download + observation upload per step)" if args.host_env else "device",
+              "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}
+    if world > 1:
+        config["collective_backend"] = "nccl (RCCL)" if backend == "nccl" else f"{backend} ({world} ranks share {n_dev} GPU(s))"
+        config["ranks"] = world
+        config["gpus_visible"] = n_dev
     out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs x 50 sims" if headline else
-                     f"MCTS simulations/sec (whole node), {args.workload} at {B} envs/GPU",
+                     f"MCTS simulations/sec (whole node), {args.workload} at {B} envs/GPU" + (" (host-resident envs)" if args.host_env else ""),
            "value": sims_total / dt, "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32 (tree values, heads) + f64 (pUCT scores, root priors) + i32 (counts)",
-           "data": data_note,
-           "config": {"workload": args.workload, "envs_per_gpu": B, "num_simulations": wl["sims"],
-                      "actions": wl["A"], "children_per_expansion": wl["K"], "hidden_floats": int(groups[0].heads.S) if hasattr(groups[0].heads, "S") else model.state_dimension,
-                      "rng": "per-tree MT19937 (numpy-legacy, parity mode)", "hip_graph": not args.no_graph,
-                      "stream_groups": G, "heads": type(groups[0].heads).__name__,
-                      "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}}
+           "data": data_note, "config": config,
+           "timing": {"blocks": R, "steps_per_block": args.steps, "block_ms_median": 1e3 * dt,
+                      "block_ms_min": 1e3 * float(np.min(blocks)), "block_ms_max": 1e3 * float(np.max(blocks)),
+                      "block_ms_p10_p90": [1e3 * float(np.percentile(blocks, 10)), 1e3 * float(np.percentile(blocks, 90))],
+                      "timed_region_s": float(np.sum(blocks)),
+                      "rule": "value and ms_per_step from the median block; every block is K steps between barrier + "
+                              "synchronize pairs, max over ranks"}}
+    if per_rank_rate is not None:
+        out["per_rank_simulations_per_s"] = per_rank_rate
 
     # ---- roofline (rank 0) --------------------------------------------------------------------------------------
     if rank == 0 and not args.no_roofline:
         eng = mcts.engine
         S, A, K = eng.S, eng.A, eng.K
-        single = mcts._single is True
         # (1) level histogram of this workload (stats atomics on; not timed)
         eng.enable_stats(True)
         eng.read_stats(reset=True)
@@ -233,7 +359,7 @@ def main():
         stats = eng.read_stats(reset=True)
         eng.enable_stats(False)
         k2, k5, depth = algorithmic_bytes(stats, A, K, S, wl["sims"])
-        reps = max(1, min(args.steps, 4))
+        reps = max(1, min(args.steps, 8))
         if single:
             # dominant kernel = k_search_mlp (the whole search, one launch per env step): event pairs around each launch
             durs = []
@@ -246,24 +372,26 @@ def main():
             ms = np.array([a.elapsed_time(b) for a, b in durs[1:]])
             mean_us = float(ms.mean() * 1e3)
             bytes_launch = (k2 + k5) * Bg * wl["sims"]
-            kernel = "k_search_mlp<MAXA,U> (root + num_simulations x [select, heads, expand, backup] in one launch)"
+            kernel = "k_search_mlp<MAXA,KS,U,INSTR,AEX> (root + num_simulations x [select, heads, expand, backup] in one launch)"
         else:
-            kernel = "k_expand_backup<MAXA,true> (expand + backup + next select)"
+            kernel = "k_expand_backup<MAXA,KS,true,AEX> (expand + backup + next select)"
             durs = []
         # the tree kernel on its own (step-wise path): events around each fused expand+backup+select launch.  A spin
         # kernel in front of every repetition lets the host enqueue the whole search before the GPU starts on it, so an
         # event pair brackets the kernel alone (an idle queue would stamp e0 early and add the host's launch latency).
         hidden, policy = heads.initial(env.obs)
         tdurs = []
-        for _ in range(reps):
+        for _ in range(min(reps, 4)):
             eng.root_init(hidden, policy, train=True)
-            eng.select(want_parent_hidden=False)
+            eng.select(want_mlp_input=getattr(heads, "wants_mlp_input", True),
+                       want_parent_hidden=getattr(heads, "wants_parent_hidden", False))
             torch.cuda._sleep(2_000_000)
             for s in range(wl["sims"] - 1):
                 o = heads.recurrent(eng)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                eng.expand_backup_select(*o, want_parent_hidden=False)
+                eng.expand_backup_select(*o, want_mlp_input=getattr(heads, "wants_mlp_input", True),
+                                         want_parent_hidden=getattr(heads, "wants_parent_hidden", False))
                 e1.record()
                 tdurs.append((e0, e1))
             eng.expand_backup(*heads.recurrent(eng))
@@ -282,8 +410,8 @@ def main():
         achieved = bytes_launch / (mean_us * 1e-6) / 1e9
         # HBM bytes per launch from the TCC counters, when a PMC pass of this workload/kernel has been committed
         traffic, traffic_note = None, None
-        tfile = os.path.join(ROOT, "profiles", "r01_p_traffic_k_search_mlp.json")
-        if single and Bg == 4096 and args.workload == "cartpole_mlp_4096x50" and os.path.exists(tfile):
+        tfile = os.path.join(ROOT, "profiles", TRAFFIC_FILES.get(args.workload, "-"))
+        if single and Bg == wl["envs"] and os.path.exists(tfile):
             tj = json.load(open(tfile))
             traffic = tj["hbm_bytes_per_launch_raw"]
             traffic_note = ("(FETCH_SIZE + WRITE_SIZE) x 1024 per launch from " + os.path.basename(tfile) +
@@ -294,14 +422,14 @@ def main():
                            "mean_launch_us": mean_us, "median_launch_us": float(np.median(ms) * 1e3),
                            "launches_timed": int(ms.size), "bytes_per_tree_select": k2,
                            "bytes_per_tree_expand_backup": k5, "mean_depth": depth,
-                           "tree_kernel_alone": {"kernel": "k_expand_backup<MAXA,true>", "mean_launch_us": tree_us,
+                           "tree_kernel_alone": {"kernel": "k_expand_backup<MAXA,KS,true,AEX>", "mean_launch_us": tree_us,
                                                  "bytes_per_launch": tree_bytes,
                                                  "achieved": tree_bytes / (tree_us * 1e-6) / 1e9,
                                                  "frac": tree_bytes / (tree_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
                            "method": "HIP event pairs on the launching (torch current) stream around each launch, "
                                      "after the timed region; bytes = SURVEY 8d formula on this run's level histogram"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl["env"] == "cartpole":    # N=1 only (contract)
-        out["cpu_baseline"] = cpu_baseline(wl, wpath)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:                                # N=1 only (contract)
+        out["cpu_baseline"] = cpu_baseline_vision(wl, model) if wl["env"] == "image" else cpu_baseline_mlp(wl, wpath)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

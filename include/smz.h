@@ -39,7 +39,9 @@ typedef enum {
     SMZ_ERR_INVALID = -1,   /* bad argument / hyper-parameter (the reference raises AssertionError, mcts:148-173) */
     SMZ_ERR_HIP = -2,       /* a HIP runtime call failed */
     SMZ_ERR_NOMEM = -3,     /* device allocation failed */
-    SMZ_ERR_STATE = -4      /* call order violated (e.g. select before root_init) */
+    SMZ_ERR_STATE = -4,     /* call order violated (e.g. select before root_init) */
+    SMZ_ERR_TOO_LARGE = -5  /* the working set of a single-launch kernel exceeds a CU's LDS for this batch geometry:
+                               nothing was launched, use the step-wise entry points */
 } smz_status;
 
 typedef enum {
@@ -106,6 +108,13 @@ int smz_get_rng_state(smz_handle *h, int tree, uint32_t *host_key, int *pos);
  * run throw-away warm-up searches (e.g. before capturing a HIP graph) without disturbing the per-tree streams. */
 int smz_rng_snapshot(smz_handle *h, smz_stream stream);
 int smz_rng_restore(smz_handle *h, smz_stream stream);
+
+/* Per-tree on/off switch: active_dev [B] u8 (caller-owned device memory that must outlive its use; NULL = all on).
+ * Every search phase, smz_search_mlp(_act) and smz_act skip the trees whose byte is 0: their nodes, outputs and random
+ * streams stay untouched.  This is the batched form of the reference loop's `while not environment.terminal`
+ * (self_play.py:79): a finished game stops consuming simulations.  The array is read when the kernels run, so the
+ * env-step kernel may clear entries on the same stream (smz_cartpole_step_ctl). */
+int smz_set_active(smz_handle *h, const uint8_t *active_dev);
 
 /* ---- the search (one call per phase of Monte_carlo_tree_search.run, mcts:311-349) ----------------------------- */
 /* Root: resets the trees and MinMaxStats, stores the root hidden state, normalises the root policy, creates all A
@@ -265,7 +274,7 @@ int smz_vision_recurrent(const smz_vision_desc *desc, const float *weights_dev, 
  * in LDS: representation + root prediction, root expansion and noise, then num_simulations x (select, the pair of
  * networks the leaf needs, expansion, backup).  Network weights are staged once per workgroup; leaf hand-off and
  * network outputs never leave LDS.  Results are read as after the step-wise calls (smz_root_stats / smz_act /
- * smz_debug_dump_tree).  obs_dev [B,obs] f32.  SMZ_ERR_INVALID when the working set exceeds a CU's LDS. */
+ * smz_debug_dump_tree).  obs_dev [B,obs] f32.  SMZ_ERR_TOO_LARGE when the working set exceeds a CU's LDS. */
 int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
                    smz_stream stream);
 
@@ -285,6 +294,43 @@ int smz_cartpole_step(double *state_dev, const int32_t *action_dev, float *obs_o
 int smz_cartpole_step_pack(double *state_dev, const int32_t *action_dev, float *obs_out_dev, float *reward_out_dev,
                            uint8_t *terminated_out_dev, double *traj_dev, int T, int t, const double *policy_dev,
                            const double *child_visits_dev, const float *root_value_dev, int B, smz_stream stream);
+/* The same step with the per-env game bookkeeping of the reference's loop (`while not environment.terminal and counter <
+ * environment.limit_of_game_play`, self_play.py:79; Game.done, game.py:270-271) kept on the device, so that a batched
+ * loop needs no host round trip to learn which games have ended.  The flag written to flag_out_dev [B] u8 and to the
+ * record's `terminated` slot is
+ *     0 running | 1 terminated (Game.done True) | 2 stopped by limit_of_game_play (game over, Game.done stays False,
+ *     game.py:270-271) | 3 no step taken (the env is switched off: active_dev[e] == 0).
+ * smz_episode_ctl (host struct, read before return; the arrays are caller-owned device memory):
+ *   step_count_dev [B] i32 in/out  steps taken in the current game (the reference's `counter`)
+ *   episode_dev    [B] i32 in/out  games finished by this env so far (needed for on_end 2)
+ *   active_dev     [B] u8  in/out  envs still playing (needed for on_end 1; may be NULL otherwise).  Hand the same array
+ *                                  to smz_set_active and finished envs stop consuming simulations.
+ *   limit          limit_of_game_play (<= 0: none)
+ *   on_end         0: keep stepping past the end (fixed-length synthetic episodes of the benchmark)
+ *                  1: switch the env off (active_dev[e] = 0)
+ *                  2: start the env's next game at once: state ~ U(-0.05, 0.05)^4 (CartPole-v1's reset distribution)
+ *                     drawn from a counter-based generator keyed by (reset_seed, first_env + e, episode) -- independent
+ *                     of the shard and of the launch geometry; smz_cartpole_reset_state gives the same values on the host.
+ * traj_dev may be NULL (no record). */
+typedef struct {
+    int32_t *step_count_dev;
+    int32_t *episode_dev;
+    uint8_t *active_dev;
+    int32_t limit;
+    int32_t on_end;
+    uint64_t reset_seed;
+    int64_t first_env;
+} smz_episode_ctl;
+int smz_cartpole_step_ctl(double *state_dev, const int32_t *action_dev, float *obs_out_dev, float *reward_out_dev,
+                          uint8_t *flag_out_dev, const smz_episode_ctl *ctl, double *traj_dev, int T, int t,
+                          const double *policy_dev, const double *child_visits_dev, const float *root_value_dev, int B,
+                          smz_stream stream);
+/* Host evaluation of the reset state smz_cartpole_step_ctl gives env `env` for its game number `episode` (>= 1). */
+int smz_cartpole_reset_state(uint64_t reset_seed, int64_t env, int64_t episode, double state_out[4]);
+/* Observation-only stand-in env (LunarLander-shaped benchmark workload; Box2D / gymnasium are not part of this build):
+ * obs_dev [B][obs_dim] f32 ~ N(0,1), element (env, k) of step t a pure function of (seed, first_env + env, t, k). */
+int smz_synthetic_obs(float *obs_dev, int B, int obs_dim, uint64_t seed, int64_t first_env, int64_t t, smz_stream stream);
+
 /* Appends one env step of every tree to a fixed-length trajectory buffer laid out [T][B][F] (step-major, so one
  * step is one contiguous, coalesced slab and a finished chunk is one message for the trajectory gather):
  * what Game.policy_step / store_search_statistics append to their lists (game.py:193-195, 263-267).  Record of F =

@@ -68,6 +68,10 @@ def lib():
         L.orc_selfplay_cartpole.restype = C.c_int64
         L.orc_selfplay_cartpole.argtypes = [C.POINTER(Cfg), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_selfplay_observations.restype = C.c_int64
+        L.orc_selfplay_observations.argtypes = [C.POINTER(Cfg), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]
         for name in ("orc_mlp_representation",):
             getattr(L, name).argtypes = [C.POINTER(Mlp), C.c_void_p, C.c_void_p]
         L.orc_mlp_prediction.argtypes = [C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_void_p]
@@ -217,4 +221,24 @@ def selfplay_cartpole(cfg, weights, obs0, seeds, steps, temperature=0.0, train=T
     rv = np.zeros((n_env, steps), np.float32) if record else None
     n = L.orc_selfplay_cartpole(C.byref(cfg), C.byref(weights.struct), _p(pbc), _p(pow_lut), _p(obs0), _p(seeds),
                                 n_env, steps, float(temperature), int(bool(train)), int(threads), _p(acts), _p(vis), _p(rv))
+    return dict(simulations=int(n), actions=acts, visits=vis, root_values=rv)
+
+
+def selfplay_observations(cfg, weights, obs_seq, seeds, temperature=0.0, train=True, threads=1, pbc=None, record=True):
+    """As selfplay_cartpole for observation-only stand-in envs: obs_seq [n_env][steps][obs_dim] float32 is what the env
+    shows the agent at each step (the actions do not influence it)."""
+    L = lib()
+    obs_seq = np.ascontiguousarray(obs_seq, dtype=np.float32)
+    n_env, steps, obs_dim = obs_seq.shape
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    if pbc is None:
+        pbc = pbc_table(cfg.pb_c_base, cfg.pb_c_init, cfg.sims + 2)
+    pbc = np.ascontiguousarray(pbc, dtype=np.float64)
+    pow_lut = pow_table(temperature, cfg.sims + 1) if temperature >= 0.3 else None
+    acts = np.zeros((n_env, steps), np.int32) if record else None
+    vis = np.zeros((n_env, steps, cfg.A), np.int32) if record else None
+    rv = np.zeros((n_env, steps), np.float32) if record else None
+    n = L.orc_selfplay_observations(C.byref(cfg), C.byref(weights.struct), _p(pbc), _p(pow_lut), _p(obs_seq), obs_dim,
+                                    _p(seeds), n_env, steps, float(temperature), int(bool(train)), int(threads), _p(acts),
+                                    _p(vis), _p(rv))
     return dict(simulations=int(n), actions=acts, visits=vis, root_values=rv)

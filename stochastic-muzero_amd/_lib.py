@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsmz.so")
 
-SMZ_OK, SMZ_ERR_INVALID, SMZ_ERR_HIP, SMZ_ERR_NOMEM, SMZ_ERR_STATE = 0, -1, -2, -3, -4
+SMZ_OK, SMZ_ERR_INVALID, SMZ_ERR_HIP, SMZ_ERR_NOMEM, SMZ_ERR_STATE, SMZ_ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5
 RNG_MT19937_NUMPY, RNG_PHILOX = 0, 1
 MAX_ACTIONS = 32
 
@@ -38,6 +38,12 @@ class VisionDesc(C.Structure):
     """smz_vision_desc (include/smz.h): dimensions + float offsets of the packed vision_model weight buffer."""
     _fields_ = [("A", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("OP", C.c_int32),
                 ("total_floats", C.c_int32), ("small_floats", C.c_int32), ("off", C.c_int32 * 80)]
+
+
+class EpisodeCtl(C.Structure):
+    """smz_episode_ctl (include/smz.h): per-env game bookkeeping of smz_cartpole_step_ctl."""
+    _fields_ = [("step_count_dev", C.c_void_p), ("episode_dev", C.c_void_p), ("active_dev", C.c_void_p),
+                ("limit", C.c_int32), ("on_end", C.c_int32), ("reset_seed", C.c_uint64), ("first_env", C.c_int64)]
 
 
 class NodeView(C.Structure):
@@ -79,6 +85,10 @@ SIGNATURES = {
     "smz_search_mlp": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, _P]),
     "smz_cartpole_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_cartpole_step_pack": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "smz_cartpole_step_ctl": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(EpisodeCtl), _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "smz_cartpole_reset_state": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.POINTER(C.c_double * 4)]),
+    "smz_synthetic_obs": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int64, _P]),
+    "smz_set_active": (C.c_int, [_P, _P]),
     "smz_traj_floats": (C.c_int, [C.c_int, C.c_int]),
     "smz_traj_pack": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_traj_targets": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P]),

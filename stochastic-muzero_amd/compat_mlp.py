@@ -28,6 +28,14 @@ def _trunk(n_in, width, depth):
     return [first, act] + [mid, act] * depth
 
 
+def _unused_draws(width, n_out):
+    """The reference's Representation_function and Encoder_function construct one Linear(H, S) that never enters a
+    Sequential (neural_network_mlp_model.py:17, 222) before the output layer they do use; its default initialisation
+    consumes torch's global generator, so an equal torch seed only reproduces the reference's fresh weights if the same
+    draws are made here (tests/test_abi_and_host.py pins this against weights the reference itself initialised)."""
+    nn.Linear(width, n_out)
+
+
 class _TwoHeadTrunk(nn.Module):
     def _build(self, n_in, width, depth, names_and_outs):
         layers = _trunk(n_in, width, depth)
@@ -41,9 +49,9 @@ class Representation_function(nn.Module):
         super().__init__()
         self.action_space = action_dimension
         self.scale = nn.Tanh()
-        self.state_norm = nn.Sequential(*_trunk(observation_space_dimensions, hidden_layer_dimensions,
-                                                number_of_hidden_layer),
-                                        nn.Linear(hidden_layer_dimensions, state_dimension))
+        layers = _trunk(observation_space_dimensions, hidden_layer_dimensions, number_of_hidden_layer)
+        _unused_draws(hidden_layer_dimensions, state_dimension)
+        self.state_norm = nn.Sequential(*layers, nn.Linear(hidden_layer_dimensions, state_dimension))
 
     def forward(self, state):
         return scale_to_bound_action(self.state_norm(state))
@@ -106,9 +114,9 @@ class Encoder_function(nn.Module):
         super().__init__()
         self.action_space = action_dimension
         self.scale = nn.Tanh()
-        self.encoder = nn.Sequential(*_trunk(observation_space_dimensions, hidden_layer_dimensions,
-                                             number_of_hidden_layer),
-                                     nn.Linear(hidden_layer_dimensions, action_dimension))
+        layers = _trunk(observation_space_dimensions, hidden_layer_dimensions, number_of_hidden_layer)
+        _unused_draws(hidden_layer_dimensions, state_dimension)
+        self.encoder = nn.Sequential(*layers, nn.Linear(hidden_layer_dimensions, action_dimension))
         self.onehot_argmax = StraightThroughEstimator()
 
     def forward(self, o_i):

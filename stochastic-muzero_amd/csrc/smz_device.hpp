@@ -57,7 +57,9 @@ struct Params {
     const double *pbc_sqrt; // [sims+2]  sqrt(n) * pb_c(n)
     const double *pow_table;  // [sims+1] or nullptr
     unsigned long long *stats;  // [4] or nullptr
+    const uint8_t *active;      // [B] or nullptr: trees with active[i] == 0 are skipped by every entry point (smz_set_active)
 };
+__device__ inline bool tree_active(const Params &P, int tree) { return !P.active || P.active[tree] != 0; }
 
 __device__ inline uint32_t *tree_base(const Params &P, int tree) { return P.nodes + (size_t)tree * P.tree_words; }
 __device__ inline uint32_t *block_ptr(const Params &P, uint32_t *tb, int blk) {

@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidd
     uint32_t *rng_tile = rng_tile_ptr(P);
     const int n_staged = rng_tile ? kRngStage : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
-    const bool valid = (int)threadIdx.x < P.tpw && tree < P.B;
+    const bool valid = (int)threadIdx.x < P.tpw && tree < P.B && tree_active(P, tree);
     const int packed = wave_stage_rng(P, tree, valid, rng_tile);
     if (valid) {
         Rng rng;
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
     uint32_t *rng_tile = rng_tile_ptr(P);
     const int n_staged = rng_tile ? kRngStage : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
-    const bool valid = (int)threadIdx.x < P.tpw && tree < P.B;
+    const bool valid = (int)threadIdx.x < P.tpw && tree < P.B && tree_active(P, tree);
     const double *pbc_lds = stage_pbc(P);
     const int packed = wave_stage_rng(P, tree, valid, rng_tile);
     Rng rng;
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const fl
     uint32_t *rng_tile = rng_tile_ptr(P);
     const int n_staged = rng_tile ? kRngStage : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
-    const bool valid = (int)threadIdx.x < P.tpw && tree < P.B;
+    const bool valid = (int)threadIdx.x < P.tpw && tree < P.B && tree_active(P, tree);
     const double *pbc_lds = stage_pbc(P);
     const int packed = wave_stage_rng(P, tree, valid, rng_tile);
     Rng rng;
@@ -478,12 +478,16 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
 
     const int tree0 = (blockIdx.x * waves + wave) * tpw;
     const int tree = tree0 + lane;
-    const bool valid = lane < tpw && tree < P.B;
+    const bool valid = lane < tpw && tree < P.B && tree_active(P, tree);
+    // a wave none of whose trees is searched (beyond B, or switched off with smz_set_active) is done: there is no
+    // workgroup barrier after the weight staging above
+    if (__ballot(valid) == 0ull) return;
 
     // ---- root: representation + prediction per row, then root expansion per lane ---------------------------------
     for (int t = 0; t < tpw; t++) {
         const int row = tree0 + t;
         if (row >= P.B) break;                                   // wave-uniform
+        if (!__shfl((int)valid, t)) continue;                    // wave-uniform: the tree is switched off
         smz_mlp::initial_row<U>(lds, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * P.hs,
                                 nullptr, outs + t * slot);
     }
@@ -525,7 +529,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
                 const int src = lane & (kFastTpw - 1);
                 const int len = __shfl(h.path_len, src);
                 const float lrw = __shfl(leaf_rw, src);
-                if (lane < 8 * kFastTpw && tree0 + src < P.B) {
+                if (lane < 8 * kFastTpw && tree0 + src < P.B && __shfl((int)valid, src)) {
                     const bool own = lane < kFastTpw;
                     float mn = own ? h.mn : __builtin_inff(), mx = own ? h.mx : -__builtin_inff(), v_root = 0.f;
                     backup_levels_lanes<kFastTpw>(P, tree0 + src, lane / kFastTpw, len, outs[src * slot + A], lrw,
@@ -553,7 +557,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
             const int pk = __shfl(valid ? rng.pack() : 0, src), us = __shfl(valid ? rng.used : 0, src);
             const float hmn = __shfl(h.mn, src), hmx = __shfl(h.mx, src);
             const int hrv = __shfl(h.root_visit, src);
-            if (lane < 4 && tree0 + src < P.B) {
+            const bool src_valid = __shfl((int)valid, src) != 0;
+            if (lane < 4 && tree0 + src < P.B && src_valid) {
                 TreeHdr hs = h;
                 if (lane >= 2) {
                     rng.load(P.mt + (size_t)(tree0 + src) * kMtN, pk, rng_tile + src * kRngStride, kRngStage);
@@ -599,7 +604,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
             const int b0 = __builtin_amdgcn_readlane(L.branch, 0), b1 = __builtin_amdgcn_readlane(L.branch, 1);
             if (tree0 + 1 < P.B) {
                 const float *xin[2] = {xall, xall + K4in};
-                const bool dyn[2] = {b0 != 0, b1 != 0}, live[2] = {true, true};
+                const bool dyn[2] = {b0 != 0, b1 != 0};
+                const bool live[2] = {__builtin_amdgcn_readlane((int)valid, 0) != 0, __builtin_amdgcn_readlane((int)valid, 1) != 0};
                 float *dh[2], *dp[2] = {outs, outs + slot};
                 float reward[2], value[2];
 #pragma unroll
@@ -625,6 +631,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
             for (int r = 0; r < R; r++) {
                 live[r] = (t + r < tpw) && (tree0 + t + r < P.B);
                 const int tt = live[r] ? t + r : t;
+                live[r] = live[r] && __shfl((int)valid, tt) != 0;
                 const int row = tree0 + tt;
                 const int leaf = __builtin_amdgcn_readlane(L.leaf_id, tt);
                 dyn[r] = __builtin_amdgcn_readlane(L.branch, tt) != 0;
@@ -694,7 +701,7 @@ template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_act(Params P, double temperature, int32_t *action, double *policy,
                                                double *child_visits, float *root_value) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
-    if (tree >= P.B) return;
+    if (tree >= P.B || !tree_active(P, tree)) return;
     Rng rng;
     rng.load(P.mt + (size_t)tree * kMtN, P.rng_pos[tree], nullptr, 0);
     act_tree<MAXA>(P, tree, rng, temperature, action, policy, child_visits, root_value);
@@ -846,6 +853,95 @@ __global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int3
         r[10] = (double)root_value[e];
         r[11] = child_visits[(size_t)e * A]; r[12] = child_visits[(size_t)e * A + 1];
     }
+}
+#endif
+
+// Counter-based generator of the built-in environments (reset states of later episodes, stand-in observations):
+// splitmix64 of (seed, env, episode / step, component) -- the same value whatever the shard or launch geometry.
+__host__ __device__ inline uint64_t smz_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline double smz_unit(uint64_t seed, uint64_t env, uint64_t epoch, uint64_t comp) {   // [0, 1)
+    const uint64_t z = smz_mix64(smz_mix64(smz_mix64(seed ^ (env * 0xD1342543DE82EF95ull)) + epoch) + comp);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+#if SMZ_PART != 2 && SMZ_PART != 4
+// k_cartpole_step with the game bookkeeping of self_play.py:79 / game.py:270-271 per env: the flag written to
+// flag_out / the record's `terminated` slot is 0 running, 1 terminated (Game.done True), 2 stopped by
+// limit_of_game_play (the game is over but Game.done stays False, game.py:270-271), 3 no step taken (env switched off).
+// on_end: 1 = a finished env is switched off (active[e] = 0: the searches skip it from now on), 2 = it starts its next
+// episode at once (state ~ U(-0.05, 0.05)^4 from the counter-based generator, episode[e] + 1).
+__global__ void __launch_bounds__(256) k_cartpole_step_ctl(double *state, const int32_t *action, float *obs_out,
+                                                           float *reward_out, uint8_t *flag_out, int32_t *step_count,
+                                                           int32_t *episode, uint8_t *active, int limit, int on_end,
+                                                           uint64_t reset_seed, long long first_env, int B, double *traj,
+                                                           int t, const double *policy, const double *child_visits,
+                                                           const float *root_value) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    constexpr int A = 2, F = 4 + 3 * A + 3;
+    double *r = traj ? traj + ((size_t)t * B + e) * F : nullptr;
+    if (active && !active[e]) {
+        if (flag_out) flag_out[e] = 3;
+        if (reward_out) reward_out[e] = 0.f;
+        if (r) { for (int k = 0; k < F; k++) r[k] = 0.0; r[5] = 3.0; }
+        return;
+    }
+    const double g = 9.8, mc = 1.0, mp = 0.1, tm = mc + mp, len = 0.5, pml = mp * len, fm = 10.0, tau = 0.02;
+    double *st = state + (size_t)e * 4;
+    const double x = st[0], xd = st[1], th = st[2], thd = st[3];
+    const double force = action[e] == 1 ? fm : -fm;
+    const double ct = cos(th), sn = sin(th);
+    const double temp = (force + pml * thd * thd * sn) / tm;
+    const double tha = (g * sn - ct * temp) / (len * (4.0 / 3.0 - mp * ct * ct / tm));
+    const double xa = temp - pml * tha * ct / tm;
+    double nx = x + tau * xd, nxd = xd + tau * xa, nth = th + tau * thd, nthd = thd + tau * tha;
+    const bool term = fabs(nx) > 2.4 || fabs(nth) > 12.0 * 2.0 * 3.14159265358979323846 / 360.0;
+    const int count = step_count[e] + 1;
+    const int flag = (limit > 0 && count == limit) ? 2 : (term ? 1 : 0);
+    if (r) {
+        r[0] = (double)(float)nx; r[1] = (double)(float)nxd; r[2] = (double)(float)nth; r[3] = (double)(float)nthd;
+        r[4] = 1.0;
+        r[5] = (double)flag;
+        r[6] = policy[(size_t)e * A]; r[7] = policy[(size_t)e * A + 1];
+        r[8] = action[e] == 0 ? 1.0 : 0.0; r[9] = action[e] == 1 ? 1.0 : 0.0;
+        r[10] = (double)root_value[e];
+        r[11] = child_visits[(size_t)e * A]; r[12] = child_visits[(size_t)e * A + 1];
+    }
+    if (reward_out) reward_out[e] = 1.0f;
+    if (flag_out) flag_out[e] = (uint8_t)flag;
+    int next_count = count;
+    if (flag != 0 && on_end == 2) {
+        const int ep = episode[e] + 1;
+        episode[e] = ep;
+        nx = -0.05 + 0.1 * smz_unit(reset_seed, (uint64_t)(first_env + e), (uint64_t)ep, 0);
+        nxd = -0.05 + 0.1 * smz_unit(reset_seed, (uint64_t)(first_env + e), (uint64_t)ep, 1);
+        nth = -0.05 + 0.1 * smz_unit(reset_seed, (uint64_t)(first_env + e), (uint64_t)ep, 2);
+        nthd = -0.05 + 0.1 * smz_unit(reset_seed, (uint64_t)(first_env + e), (uint64_t)ep, 3);
+        next_count = 0;
+    } else if (flag != 0 && on_end == 1 && active) {
+        active[e] = 0;
+    }
+    step_count[e] = next_count;
+    st[0] = nx; st[1] = nxd; st[2] = nth; st[3] = nthd;
+    if (obs_out) {
+        float *o = obs_out + (size_t)e * 4;
+        o[0] = (float)nx; o[1] = (float)nxd; o[2] = (float)nth; o[3] = (float)nthd;
+    }
+}
+
+// N(0,1) float32 observations of a stand-in env (Box-Muller on two counter-based uniforms), env-major [B][obs_dim]
+__global__ void __launch_bounds__(256) k_synthetic_obs(float *obs, int B, int obs_dim, uint64_t seed, long long first_env,
+                                                       long long t) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * obs_dim) return;
+    const uint64_t e = (uint64_t)(first_env + (long long)(i / obs_dim)), k = (uint64_t)(i % obs_dim);
+    const double u1 = 1.0 - smz_unit(seed, e, (uint64_t)t, 2 * k), u2 = smz_unit(seed, e, (uint64_t)t, 2 * k + 1);
+    obs[i] = (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2));
 }
 #endif
 
@@ -1411,7 +1507,7 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     P.tpw = tpw;
     const MegaLds ml = mega_lds(*desc, P, tpw);
     const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave) * sizeof(float);
-    if (lds > 160 * 1024) return fail(SMZ_ERR_INVALID, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
+    if (lds > 160 * 1024) return fail(SMZ_ERR_TOO_LARGE, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
 #define SMZ_LAUNCH_SEARCH(UU, INSTR, AEX)                                                                              \
     SMZ_SEARCH_DISPATCH2(h->maxa, h->K, {                                                                              \
@@ -1555,6 +1651,43 @@ int smz_cartpole_step_pack(double *state_dev, const int32_t *action_dev, float *
     hipLaunchKernelGGL(k_cartpole_step, row_grid(B), dim3(256), 0, (hipStream_t)stream, state_dev, action_dev, obs_out_dev,
                        reward_out_dev, terminated_out_dev, B, traj_dev, t, policy_dev, child_visits_dev, root_value_dev);
     return launch_check();
+}
+
+int smz_cartpole_step_ctl(double *state_dev, const int32_t *action_dev, float *obs_out_dev, float *reward_out_dev,
+                          uint8_t *flag_out_dev, const smz_episode_ctl *ctl, double *traj_dev, int T, int t,
+                          const double *policy_dev, const double *child_visits_dev, const float *root_value_dev, int B,
+                          smz_stream stream) {
+    if (!state_dev || !action_dev || !ctl || !ctl->step_count_dev || B < 1)
+        return fail(SMZ_ERR_INVALID, "smz_cartpole_step_ctl: bad argument%s");
+    if (ctl->on_end < 0 || ctl->on_end > 2 || (ctl->on_end == 2 && !ctl->episode_dev) || (ctl->on_end == 1 && !ctl->active_dev))
+        return fail(SMZ_ERR_INVALID, "smz_cartpole_step_ctl: on_end 1 needs active_dev, on_end 2 needs episode_dev%s");
+    if (traj_dev && (!policy_dev || !child_visits_dev || !root_value_dev || t < 0 || t >= T))
+        return fail(SMZ_ERR_INVALID, "smz_cartpole_step_ctl: bad trajectory argument%s");
+    hipLaunchKernelGGL(k_cartpole_step_ctl, row_grid(B), dim3(256), 0, (hipStream_t)stream, state_dev, action_dev, obs_out_dev,
+                       reward_out_dev, flag_out_dev, ctl->step_count_dev, ctl->episode_dev, ctl->active_dev, ctl->limit,
+                       ctl->on_end, (uint64_t)ctl->reset_seed, (long long)ctl->first_env, B, traj_dev, t, policy_dev,
+                       child_visits_dev, root_value_dev);
+    return launch_check();
+}
+
+int smz_cartpole_reset_state(uint64_t reset_seed, int64_t env, int64_t episode, double state_out[4]) {
+    if (!state_out || episode < 1) return fail(SMZ_ERR_INVALID, "smz_cartpole_reset_state: bad argument%s");
+    for (int c = 0; c < 4; c++) state_out[c] = -0.05 + 0.1 * smz_unit(reset_seed, (uint64_t)env, (uint64_t)episode, (uint64_t)c);
+    return SMZ_OK;
+}
+
+int smz_synthetic_obs(float *obs_dev, int B, int obs_dim, uint64_t seed, int64_t first_env, int64_t t, smz_stream stream) {
+    if (!obs_dev || B < 1 || obs_dim < 1) return fail(SMZ_ERR_INVALID, "smz_synthetic_obs: bad argument%s");
+    const size_t n = (size_t)B * obs_dim;
+    hipLaunchKernelGGL(k_synthetic_obs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs_dev, B,
+                       obs_dim, seed, (long long)first_env, (long long)t);
+    return launch_check();
+}
+
+int smz_set_active(smz_handle *h, const uint8_t *active_dev) {
+    if (!h) return fail(SMZ_ERR_INVALID, "smz_set_active: null handle%s");
+    h->P.active = active_dev;
+    return SMZ_OK;
 }
 
 int smz_traj_floats(int obs_dim, int A) { return obs_dim + 3 * A + 3; }

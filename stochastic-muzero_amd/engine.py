@@ -83,6 +83,16 @@ class SearchEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_active(self, active):
+        """Per-tree on/off switch (smz_set_active): `active` is a uint8 [B] device tensor (kept alive here) or None.
+        Trees whose byte is 0 are skipped by every search phase and by act(): the batched `while not
+        environment.terminal` of self_play.py:79."""
+        if active is not None:
+            assert active.dtype == torch.uint8 and active.is_contiguous() and active.device == self.device and \
+                tuple(active.shape) == (self.B,)
+        self._active = active
+        _lib.check(self.lib.smz_set_active(self.h, _ptr(active)))
+
     # ---- random streams ------------------------------------------------------------------------------------------
     def seed(self, seeds):
         """numpy `seed(int)` per tree; a scalar s seeds tree i with s + i."""

@@ -13,18 +13,37 @@ import torch
 from . import _lib
 
 
+ON_END = {"continue": 0, "mask": 1, "reset": 2}
+
+
 class CartPoleVec:
+    """B CartPole-v1 shaped games stepped on the device.
+
+    on_end says what happens to an env whose game is over (terminated, or `limit` steps played -- the two exits of the
+    reference's loop, self_play.py:79):
+      "continue"  keep stepping (the fixed-length synthetic episodes of the benchmark; flags are recorded, nothing else);
+      "mask"      switch the env off: `active[e]` drops to 0 on the device, the search skips it from then on
+                  (SearchEngine.set_active) and its later records carry flag 3;
+      "reset"     start its next game at once (counter-based reset state, smz_cartpole_step_ctl), so that every
+                  simulation of a chunk belongs to some game.
+    """
     obs_dim, num_actions = 4, 2
 
-    def __init__(self, num_envs, device, seed=0, first_env=0, total_envs=None):
+    def __init__(self, num_envs, device, seed=0, first_env=0, total_envs=None, on_end="continue", limit=0):
         self.lib = _lib.load()
         self.B, self.device = int(num_envs), torch.device(device)
         self.seed, self.first_env = int(seed), int(first_env)
         self.total = int(total_envs) if total_envs is not None else self.first_env + self.B
+        assert on_end in ON_END
+        self.on_end, self.limit = on_end, int(limit)
         self.state = torch.empty(self.B, 4, dtype=torch.float64, device=self.device)
         self.obs = torch.empty(self.B, 4, dtype=torch.float32, device=self.device)
         self.reward = torch.empty(self.B, dtype=torch.float32, device=self.device)
-        self.terminated = torch.empty(self.B, dtype=torch.uint8, device=self.device)
+        self.terminated = torch.empty(self.B, dtype=torch.uint8, device=self.device)     # the flag of the last step
+        self.step_count = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.episode = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.active = torch.ones(self.B, dtype=torch.uint8, device=self.device) if on_end == "mask" else None
+        self._ctl = None
 
     def reset(self):
         all_states = np.random.RandomState(self.seed).uniform(-0.05, 0.05, size=(self.total, 4))
@@ -32,30 +51,59 @@ class CartPoleVec:
         self.state.copy_(torch.from_numpy(np.ascontiguousarray(st)))
         self.obs.copy_(self.state.to(torch.float32))
         self.terminated.zero_()
+        self.step_count.zero_()
+        self.episode.zero_()
+        if self.active is not None:
+            self.active.fill_(1)
         return self.obs
+
+    def reset_state_of(self, env, episode):
+        """Host copy of the state env `env` (global index) starts its game number `episode` >= 1 from (on_end="reset")."""
+        out = (C.c_double * 4)()
+        _lib.check(self.lib.smz_cartpole_reset_state(self.seed, int(env), int(episode), C.byref(out)))
+        return np.array(list(out))
+
+    def _controlled(self):
+        return self.on_end != "continue" or self.limit > 0
+
+    def _ctl_struct(self):
+        if self._ctl is None:
+            P = lambda x: None if x is None else x.data_ptr()
+            self._ctl = _lib.EpisodeCtl(P(self.step_count), P(self.episode), P(self.active), self.limit, ON_END[self.on_end],
+                                        self.seed, self.first_env)
+        return self._ctl
 
     def step(self, action):
         """action: int32 [B] device tensor (index into action_map).  Asynchronous on the current stream."""
-        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(self.lib.smz_cartpole_step(C.c_void_p(self.state.data_ptr()), C.c_void_p(action.data_ptr()),
-                                              C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
-                                              C.c_void_p(self.terminated.data_ptr()), self.B, s))
-        return self.obs, self.reward, self.terminated
+        return self.step_and_record(action, None, 0, None, None, None)
 
     def step_and_record(self, action, chunk_data, t, policy, child_visits, root_value):
         """step(action) + the trajectory record of this step (smz_traj_pack's layout) in one launch."""
         s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        P = lambda x: C.c_void_p(x.data_ptr())
-        _lib.check(self.lib.smz_cartpole_step_pack(P(self.state), P(action), P(self.obs), P(self.reward), P(self.terminated),
-                                                   P(chunk_data), chunk_data.shape[0], int(t), P(policy), P(child_visits),
-                                                   P(root_value), self.B, s))
+        P = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        T = 0 if chunk_data is None else chunk_data.shape[0]
+        if self._controlled():
+            _lib.check(self.lib.smz_cartpole_step_ctl(P(self.state), P(action), P(self.obs), P(self.reward), P(self.terminated),
+                                                      C.byref(self._ctl_struct()), P(chunk_data), T, int(t), P(policy),
+                                                      P(child_visits), P(root_value), self.B, s))
+        elif chunk_data is None:
+            _lib.check(self.lib.smz_cartpole_step(P(self.state), P(action), P(self.obs), P(self.reward), P(self.terminated),
+                                                  self.B, s))
+        else:
+            _lib.check(self.lib.smz_cartpole_step_pack(P(self.state), P(action), P(self.obs), P(self.reward),
+                                                       P(self.terminated), P(chunk_data), T, int(t), P(policy),
+                                                       P(child_visits), P(root_value), self.B, s))
         return self.obs, self.reward, self.terminated
 
 
 class SyntheticVec:
-    """Observation-only stand-in (e.g. LunarLander-shaped: obs 8 ~ N(0,1), 4 actions; Box2D is absent here)."""
+    """Observation-only stand-in (e.g. LunarLander-shaped: obs 8 ~ N(0,1), 4 actions; Box2D is absent here).  The
+    observations are generated on the device (smz_synthetic_obs): element (env, k) of step t is a pure function of
+    (seed, global env index, t, k), so a shard sees the rows it would see in a single-GPU run and an env step costs no
+    host work and no copy."""
 
     def __init__(self, num_envs, obs_dim, num_actions, device, seed=0, first_env=0, total_envs=None):
+        self.lib = _lib.load()
         self.B, self.obs_dim, self.num_actions = int(num_envs), int(obs_dim), int(num_actions)
         self.device = torch.device(device)
         self.seed, self.first_env = int(seed), int(first_env)
@@ -66,9 +114,8 @@ class SyntheticVec:
         self._t = 0
 
     def _draw(self):
-        g = np.random.RandomState(self.seed + 7919 * self._t)
-        rows = g.standard_normal(size=(self.total, self.obs_dim)).astype(np.float32)
-        self.obs.copy_(torch.from_numpy(rows[self.first_env:self.first_env + self.B]), non_blocking=False)
+        _lib.check(self.lib.smz_synthetic_obs(C.c_void_p(self.obs.data_ptr()), self.B, self.obs_dim, self.seed, self.first_env,
+                                              self._t, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         self._t += 1
 
     def reset(self):
@@ -105,3 +152,144 @@ class ImageVec:
     def step(self, action):
         self.obs.copy_(torch.roll(self.obs, shifts=1, dims=3))
         return self.obs, self.reward, self.terminated
+
+
+class HostCartPole:
+    """One CartPole-v1 shaped game on the host behind the gym call shape (reset(seed=) -> (obs, info); step(a) -> (obs,
+    reward, terminated, truncated, info)): float64 Euler physics with CartPole-v1's published constants, the arithmetic
+    of smz_cartpole_step.  gymnasium is not part of this build; this class is what the host-environment path is
+    exercised with, and what `muzero_cli.py` uses for a single-game run."""
+    metadata = {"render_fps": 50}
+
+    def __init__(self):
+        self.state = None
+
+    def reset(self, seed=None):
+        self.state = np.random.RandomState(seed).uniform(-0.05, 0.05, size=4)
+        return self.state.astype(np.float32), {}
+
+    def step(self, action):
+        if action not in (0, 1):
+            raise ValueError(f"illegal action {action!r}")
+        x, xd, th, thd = (float(v) for v in self.state)
+        force = 10.0 if action == 1 else -10.0
+        ct, sn = np.cos(th), np.sin(th)
+        temp = (force + 0.05 * thd * thd * sn) / 1.1
+        tha = (9.8 * sn - ct * temp) / (0.5 * (4.0 / 3.0 - 0.1 * ct * ct / 1.1))
+        xa = temp - 0.05 * tha * ct / 1.1
+        self.state = np.array([x + 0.02 * xd, xd + 0.02 * xa, th + 0.02 * thd, thd + 0.02 * tha])
+        term = bool(abs(self.state[0]) > 2.4 or abs(self.state[2]) > 12 * 2 * np.pi / 360)
+        return self.state.astype(np.float32), 1.0, term, False, {}
+
+    def close(self):
+        pass
+
+
+class HostVecEnv:
+    """B environments that live on the HOST (gymnasium-style objects) behind the interface the batched loop drives
+    (SURVEY 8f-4): per env step one pinned-memory download of the B actions and one pinned-memory upload of the B
+    observations / rewards / flags, both asynchronous on the engine's stream; the only host wait is for the actions.
+
+    `envs`: a list of B single environments (reset(seed=) -> obs | (obs, info); step(a) -> (obs, reward, terminated, ...)).
+    Per env the wrapper keeps what the reference's Game keeps around env.step (game.py:96-131, 223-273):
+      * the first observation comes from env.reset(seed=env_seed + global env index) (game.py:102 draws that seed from
+        Python's unseeded `random`; a reproducible rule replaces the draw);
+      * a step that raises is an illegal move: observation unchanged, reward min(-steps so far, -limit, -1), termination
+        flag unchanged (game.py:123-131);
+      * flags as smz_cartpole_step_ctl: 1 terminated, 2 stopped by `limit` (game.py:270-271), 3 no step (switched off);
+      * on_end "mask": a finished env is switched off (`active`, handed to the search); "reset": it is reset at once and
+        the NEXT search sees the fresh observation while the record keeps the post-step one (`record_obs`).
+    Observations are flattened float32 vectors (game.py:145-167); image observations go through `transform`."""
+
+    def __init__(self, envs, obs_dim, num_actions, device, action_map=None, env_seed=0, limit=0, on_end="reset", first_env=0,
+                 transform=None):
+        assert on_end in ("mask", "reset")
+        self.envs, self.B = list(envs), len(envs)
+        self.obs_dim, self.num_actions = int(obs_dim), int(num_actions)
+        self.device = torch.device(device)
+        self.action_map = list(action_map) if action_map is not None else list(range(self.num_actions))
+        self.env_seed, self.limit, self.on_end, self.first_env = int(env_seed), int(limit), on_end, int(first_env)
+        self.transform = transform
+        B, o = self.B, self.obs_dim
+        pin = dict(pin_memory=torch.cuda.is_available())
+        self._h_obs = torch.zeros(B, o, dtype=torch.float32, **pin)          # next search's input
+        self._h_rec = torch.zeros(B, o, dtype=torch.float32, **pin)          # post-step observation (the record's)
+        self._h_reward = torch.zeros(B, dtype=torch.float32, **pin)
+        self._h_flag = torch.zeros(B, dtype=torch.uint8, **pin)
+        self._h_active = torch.ones(B, dtype=torch.uint8, **pin)
+        self._h_action = torch.zeros(B, dtype=torch.int32, **pin)
+        self.obs = torch.zeros(B, o, dtype=torch.float32, device=self.device)
+        self.record_obs = torch.zeros(B, o, dtype=torch.float32, device=self.device)
+        self.reward = torch.zeros(B, dtype=torch.float32, device=self.device)
+        self.terminated = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        self.active = torch.ones(B, dtype=torch.uint8, device=self.device) if on_end == "mask" else None
+        self.step_count = np.zeros(B, np.int64)
+        self.episode = np.zeros(B, np.int64)
+        self.done = np.zeros(B, bool)
+        self.transfer_seconds = 0.0            # host time spent waiting for the action download (diagnostic)
+
+    def _flat(self, obs):
+        obs = obs[0] if isinstance(obs, tuple) else obs
+        if self.transform is not None:
+            obs = self.transform(obs)
+        return np.asarray(obs, dtype=np.float32).reshape(-1)
+
+    def _reset_one(self, i):
+        seed = self.env_seed + self.first_env + i + 1000003 * int(self.episode[i])
+        self._h_obs[i] = torch.from_numpy(self._flat(self.envs[i].reset(seed=seed)))
+        self.step_count[i] = 0
+        self.done[i] = False
+
+    def reset(self):
+        self.episode[:] = 0
+        for i in range(self.B):
+            self._reset_one(i)
+        self._h_active.fill_(1)
+        self.obs.copy_(self._h_obs, non_blocking=True)
+        if self.active is not None:
+            self.active.copy_(self._h_active, non_blocking=True)
+        return self.obs
+
+    def step(self, action):
+        import time
+        stream = torch.cuda.current_stream(self.device)
+        self._h_action.copy_(action, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        t0 = time.perf_counter()
+        ev.synchronize()                                  # the search of this step has to finish before the env can move
+        self.transfer_seconds += time.perf_counter() - t0
+        acts = self._h_action.numpy()
+        rec, nxt, rew, flag, act_h = self._h_rec.numpy(), self._h_obs.numpy(), self._h_reward.numpy(), self._h_flag.numpy(), self._h_active.numpy()
+        for i, env in enumerate(self.envs):
+            if not act_h[i]:
+                flag[i], rew[i] = 3, 0.0
+                continue
+            try:
+                out = env.step(self.action_map[int(acts[i])])
+                obs_i, r, term = self._flat(out[0]), float(out[1]), bool(out[2])
+            except Exception:                             # illegal move (game.py:123-131)
+                limit = self.limit if self.limit > 0 else float("inf")          # Game's default limit_of_game_play
+                obs_i, r, term = nxt[i].copy(), float(min(-int(self.step_count[i]), -limit, -1)), bool(self.done[i])
+            self.step_count[i] += 1
+            f = 2 if (self.limit > 0 and self.step_count[i] == self.limit) else (1 if term else 0)
+            self.done[i] = term and f != 2
+            rec[i], rew[i], flag[i] = obs_i, r, f
+            nxt[i] = obs_i
+            if f:
+                if self.on_end == "reset":
+                    self.episode[i] += 1
+                    self._reset_one(i)
+                else:
+                    act_h[i] = 0
+        self.obs.copy_(self._h_obs, non_blocking=True)
+        self.record_obs.copy_(self._h_rec, non_blocking=True)
+        self.reward.copy_(self._h_reward, non_blocking=True)
+        self.terminated.copy_(self._h_flag, non_blocking=True)
+        if self.active is not None:
+            self.active.copy_(self._h_active, non_blocking=True)
+        return self.obs, self.reward, self.terminated
+
+    def close(self):
+        for e in self.envs:
+            e.close()

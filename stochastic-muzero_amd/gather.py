@@ -62,5 +62,5 @@ def broadcast_model(model, src=0, group=None, device=None):
                 n = t.numel()
                 t.copy_(flat[off:off + n].reshape(t.shape).to(t.device, t.dtype))
                 off += n
-    model._heads = {}
+    model.refresh_heads()
     return model

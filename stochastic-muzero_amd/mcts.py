@@ -8,9 +8,12 @@
                               reference's five `*_inference` methods.  The tree lives on the GPU; the process-global
                               numpy stream is carried in and out so the draws are the reference's draws.
 """
+import warnings
+
 import numpy as np
 import torch
 
+from . import _lib
 from .engine import SearchEngine
 
 
@@ -96,6 +99,8 @@ class BatchedMCTS(_Hyper):
                 self.engine.close()
             self.engine = SearchEngine(self.num_trees, num_actions, hidden_size, device=self.device,
                                        **self._engine_kwargs())
+            if getattr(self, "_active", None) is not None:
+                self.engine.set_active(self._active)
             self._graph = None
         return self.engine
 
@@ -105,6 +110,14 @@ class BatchedMCTS(_Hyper):
             self._pending_seed = seeds
         else:
             self.engine.seed(seeds)
+
+    def set_active(self, active):
+        """uint8 [num_trees] device tensor (or None): trees whose byte is 0 are skipped by run() and act() -- finished
+        games stop consuming simulations (self_play.py:79).  A captured graph holds the pointer, so it is dropped."""
+        self._active = active
+        self._graph = None
+        if self.engine is not None:
+            self.engine.set_active(active)
 
     def _search(self, obs, heads, train):
         hidden, policy = heads.initial(obs)
@@ -166,10 +179,14 @@ class BatchedMCTS(_Hyper):
                 eng.search_mlp(heads.desc, heads.weights, observations, train=train, act_temperature=act_temperature)
                 self._single = True
                 return eng
-            except Exception:
-                if self._single is True:
+            except _lib.SmzError as err:
+                # only "the working set does not fit a CU's LDS for this geometry" selects the step-wise path (once,
+                # said aloud); a HIP error, a bad descriptor or a bad observation tensor is a failure, not a slow path
+                if err.code != _lib.SMZ_ERR_TOO_LARGE or self._single is True:
                     raise
-                self._single = False     # does not fit in LDS for this batch geometry: use the step-wise path
+                self._single = False
+                warnings.warn("single-launch search does not fit in LDS for this batch geometry "
+                              f"({self.num_trees} trees x {self.num_simulations} simulations): using the step-wise kernels")
         if not self.use_graph:
             self._search(observations, heads, train)
             return self.engine

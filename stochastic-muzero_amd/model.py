@@ -35,10 +35,38 @@ for _n in ("Representation_function", "Prediction_function", "Afterstate_predict
     getattr(compat_vision, _n).__module__ = "neural_network_vision_model"
 
 
-def install_compat_modules():
-    """Makes `neural_network_mlp_model.*` resolvable for torch.load when the reference's file is not importable."""
-    sys.modules.setdefault("neural_network_mlp_model", compat_mlp)
-    sys.modules.setdefault("neural_network_vision_model", compat_vision)
+_COMPAT = {"neural_network_mlp_model": compat_mlp, "neural_network_vision_model": compat_vision}
+
+
+def _is_compat_class(cls):
+    """True for this package's re-declaration of a head class (its __module__ carries the reference's module name, so
+    only identity tells it from the reference's own class)."""
+    return cls.__module__ in _COMPAT and getattr(_COMPAT[cls.__module__], cls.__name__, None) is cls
+
+
+class _compat_modules_bound:
+    """While inside: `neural_network_{mlp,vision}_model` resolve to this package's re-declarations, so that torch.save
+    writes -- and torch.load of a reference checkpoint finds -- the class paths the reference's pickles carry.  Whatever
+    was registered under those names before (the reference's real modules, when a process has imported them) is put
+    back afterwards; nothing stays registered globally."""
+
+    def __init__(self, force=True):
+        self.force = force
+
+    def __enter__(self):
+        self.saved = {n: sys.modules.get(n) for n in _COMPAT}
+        for n, m in _COMPAT.items():
+            if self.force or self.saved[n] is None:
+                sys.modules[n] = m
+        return self
+
+    def __exit__(self, *exc):
+        for n, old in self.saved.items():
+            if old is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = old
+        return False
 
 
 def _linears(seq):
@@ -90,6 +118,7 @@ class Muzero:
         self.random_tag = int(random_tag) if random_tag is not None else int(np.random.RandomState().randint(0, 100000000))
         self.extra = dict(extra_init_variables or {})
         self._heads = {}
+        self._heads_version = {}
         if load:
             return
         if model_structure not in ("mlp_model", "vision_model"):
@@ -107,7 +136,8 @@ class Muzero:
         kw = dict(state_dimension=self.state_dimension, action_dimension=self.action_dimension,
                   observation_space_dimensions=self.observation_dimension,
                   hidden_layer_dimensions=self.hidden_layer_dimension, number_of_hidden_layer=self.number_of_hidden_layer)
-        # construction order = muzero_model.py:300-335, so an equal torch seed gives the reference's initial weights
+        # construction order and generator draws = muzero_model.py:300-335 (compat_mlp._unused_draws), so an equal torch
+        # seed gives the reference's initial weights (pinned for both families by goldens the reference initialised)
         self.representation_function = family.Representation_function(**kw)
         self.prediction_function = family.Prediction_function(**kw)
         self.afterstate_prediction_function = family.Afterstate_prediction_function(**kw)
@@ -137,11 +167,14 @@ class Muzero:
         if model_update_or_backtrack is not None:
             return
         os.makedirs(directory, exist_ok=True)
-        install_compat_modules()      # the pickles must name neural_network_mlp_model.* like the reference's
-        if tag:
+        if tag != 0:                  # (the reference's rule, muzero_model.py:917-918)
             self.random_tag = tag
-        for f in _FUNCS:
-            torch.save(getattr(self, f + "_function"), f"{directory}/{self.random_tag}_muzero_{f}_function.pt")
+        ours = all(_is_compat_class(type(getattr(self, f + "_function"))) for f in _FUNCS)
+        # modules of this package pickle under the reference's class paths; modules that ARE the reference's (a model
+        # trained by the reference and handed over) pickle through whatever is registered
+        with _compat_modules_bound(force=ours):
+            for f in _FUNCS:
+                torch.save(getattr(self, f + "_function"), f"{directory}/{self.random_tag}_muzero_{f}_function.pt")
         with open(f"{directory}/{self.random_tag}_muzero_init_variables.json", "w") as fh:
             json.dump(self.init_variables(), fh)
 
@@ -159,11 +192,11 @@ class Muzero:
         self.action_dimension = len(self.action_dictionnary)
         self.device = device if device is not None else iv["device"]
         self.is_RGB = self.model_structure == "vision_model"
-        install_compat_modules()
-        for f in _FUNCS:
-            path = f'{model_directory}/{iv["random_tag"]}_muzero_{f}_function.pt'
-            mod = torch.load(path, map_location="cpu", weights_only=False)   # whole-module pickle
-            setattr(self, f + "_function", mod.to(torch.float32).eval())
+        with _compat_modules_bound(force=False):      # the reference's own modules win when they are importable
+            for f in _FUNCS:
+                path = f'{model_directory}/{iv["random_tag"]}_muzero_{f}_function.pt'
+                mod = torch.load(path, map_location="cpu", weights_only=False)   # whole-module pickle
+                setattr(self, f + "_function", mod.to(torch.float32).eval())
         self.random_tag = tag if tag > 0 else iv["random_tag"]
         self._heads = {}
         return self
@@ -216,11 +249,33 @@ class Muzero:
         return m
 
     # ---- batched heads for the GPU engine -----------------------------------------------------------------------
+    def weights_version(self):
+        """Changes whenever a parameter or buffer of the five search-side modules is replaced or written in place
+        (torch bumps a tensor's _version on every in-place write: optimizer steps, copy_, load_state_dict)."""
+        out = []
+        for f in _FUNCS[:5]:
+            mod = getattr(self, f + "_function", None)
+            if mod is None:
+                continue
+            for t in list(mod.parameters()) + list(mod.buffers()):
+                out.append((id(t), t._version))
+        return hash(tuple(out))
+
+    def refresh_heads(self):
+        """Drops every packed / copied evaluator: the next heads() call packs the modules' current weights.  heads()
+        does this by itself when weights_version() changed; call it after swapping whole modules by other means."""
+        self._heads = {}
+        self._heads_version = {}
+
     def heads(self, device, instance=0, backend="auto"):
         """Batched evaluator on `device`.  backend: "hip" = the fused LDS-resident HIP kernel (mlp_model only, when
         the networks fit a CU's LDS), "torch" = torch-ROCm GEMMs + HIP epilogues, "auto" = hip when possible.
         `instance` distinguishes evaluators that must not share output buffers (one per concurrent stream group)."""
         key = (str(device), instance, backend)
+        version = self.weights_version()
+        if key in self._heads and self._heads_version.get(key) != version:
+            del self._heads[key]              # the modules were updated in place (optimizer step, load_state_dict, ...)
+        self._heads_version[key] = version
         if key not in self._heads:
             if self.model_structure == "mlp_model" and backend in ("auto", "hip"):
                 arrays = mlp_arrays_from_modules(self.representation_function, self.prediction_function,

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .game import Game, GameRecord  # noqa: F401  (GameRecord is re-exported: selfplay.GameRecord)
 
 
 def temperature_scheduler(epoch=1, actual_epoch=1, mode="static_temperature"):
@@ -83,79 +84,42 @@ def chunk_targets(chunk_data, obs_dim, A, discount, td_steps, ignore_termination
     return length, target, err
 
 
-class GameRecord:
-    """What self-play hands to ReplayBuffer.save_game: the trajectory lists of game.py:72-77 plus the few members
-    the buffer reads (game_length, reanalyzed, make_priority: replay_buffer.py:109-137, game.py:174-177, 316-337)."""
-
-    def __init__(self, discount, action_space_size, priority_scale=1, limit_of_game_play=float("inf")):
-        self.discount, self.action_space_size = discount, action_space_size
-        self.priority_scale, self.limit_of_game_play = priority_scale, limit_of_game_play
-        self.action_history, self.rewards, self.policies = [], [], []
-        self.root_values, self.child_visits, self.observations = [], [], []
-        self.done, self.reanalyzed, self.env = False, False, None
-
-    @property
-    def terminal(self):
-        return self.done
-
-    @property
-    def game_length(self):
-        return len(self.action_history)
-
-    def make_target(self, state_index, num_unroll, td_steps):
-        """[value target, last reward, child_visits] for num_unroll consecutive positions (game.py:291-314):
-        n-step return bootstrapped from the search value td_steps ahead; positions past the end are absorbing."""
-        n = len(self.root_values)
-        targets = []
-        for cur in range(state_index, state_index + num_unroll):
-            b = cur + td_steps
-            value = self.root_values[b] * self.discount ** td_steps if b < n else 0.0
-            for i, reward in enumerate(self.rewards[cur:b]):
-                value += reward * self.discount ** i
-            last_reward = self.rewards[cur - 1] if 0 < cur <= len(self.rewards) else 0.0
-            if cur < n:
-                targets.append([value, last_reward, self.child_visits[cur]])
-            else:
-                targets.append([0.0, last_reward, np.zeros(self.action_space_size, dtype=np.float64)])
-        return targets
-
-    def make_priority(self, td_steps):
-        """|root value - n-step return| ** priority_scale per position, and its maximum (game.py:316-337)."""
-        n = len(self.root_values)
-        rv = np.array(self.root_values)
-        target = []
-        for i in range(n):
-            b = i + td_steps
-            value = self.root_values[b] * self.discount ** td_steps if b < n else 0
-            for k, r in enumerate(self.rewards[i:b]):
-                value += r * self.discount ** k
-            target.append(value)
-        pos = np.abs(rv - np.array(target)) ** self.priority_scale
-        return pos, np.max(pos)
-
-
 def chunk_to_games(chunk_data, obs_dim, A, discount, priority_scale=1, limit_of_game_play=float("inf"),
-                   ignore_termination=False):
-    """[T][B][F] (host or device) -> list of B GameRecord, each cut after its first terminated step."""
+                   ignore_termination=False, keep_partial=True, after_end="drop"):
+    """[T][B][F] (host or device) -> list of GameRecord, env-major.  The record's flag slot cuts the games: 1 = terminated
+    (Game.done True), 2 = stopped by limit_of_game_play (done False, game.py:270-271), 3 = no step (env switched off).
+    after_end: what the rows behind an env's finished game are -- "drop": nothing (an env that is stepped on past its end,
+    the fixed-length episodes of on_end="continue"), "new_game": its next game (on_end="reset": several games per env and
+    chunk).  The rows behind the last finished game form an unfinished one, kept when keep_partial (a chunk without any
+    end flag is then one game per env)."""
+    assert after_end in ("drop", "new_game")
     d = chunk_data.detach().cpu().numpy() if torch.is_tensor(chunk_data) else np.asarray(chunk_data)
     T, B, F = d.shape
     o = obs_dim
     games = []
     for e in range(B):
-        g = GameRecord(discount, A, priority_scale, limit_of_game_play)
+        g = None
         for t in range(T):
             r = d[t, e]
+            flag = 0 if ignore_termination else int(r[o + 1])
+            if flag == 3:
+                continue
+            if g is None:
+                g = GameRecord(discount, A, priority_scale, limit_of_game_play)
             g.observations.append(torch.from_numpy(r[:o].astype(np.float32))[None, ...])   # game.py:145-167 shape [1,obs]
             g.rewards.append(float(r[o]))
             g.policies.append(r[o + 2:o + 2 + A].copy())
             g.action_history.append(r[o + 2 + A:o + 2 + 2 * A].copy())
             g.root_values.append(np.float32(r[o + 2 + 2 * A]))
             g.child_visits.append(r[o + 3 + 2 * A:o + 3 + 3 * A].copy())
-            term = bool(r[o + 1]) and not ignore_termination
-            g.done = term if limit_of_game_play != len(g.observations) else False             # game.py:270-271
-            if term:
-                break
-        games.append(g)
+            g.done = (flag == 1) if limit_of_game_play != len(g.observations) else False     # game.py:270-271
+            if flag != 0:
+                games.append(g)
+                g = None
+                if after_end == "drop":
+                    break
+        if g is not None and keep_partial:
+            games.append(g)
     return games
 
 
@@ -170,6 +134,8 @@ def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
     assert chunk.T >= steps and chunk.B == env.B
     obs = env.obs
     P = lambda t: C.c_void_p(t.data_ptr())
+    if getattr(env, "active", None) is not None or getattr(mcts, "_active", None) is not None:
+        mcts.set_active(getattr(env, "active", None))      # finished games stop consuming simulations (self_play.py:79)
     for t in range(steps):
         eng = mcts.run(obs, heads, train=train, act_temperature=temperature)
         action, policy, child_visits, root_value = eng.act(temperature)
@@ -177,9 +143,10 @@ def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
             obs, reward, terminated = env.step_and_record(action, chunk.data, t, policy, child_visits, root_value)
         else:
             obs, reward, terminated = env.step(action)
-            _lib.check(lib.smz_traj_pack(P(chunk.data), chunk.T, t, env.obs_dim, A, P(obs), P(reward), P(terminated),
-                                         P(action), P(policy), P(child_visits), P(root_value), env.B,
-                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            rec_obs = getattr(env, "record_obs", None)       # post-step observation when `obs` already is a reset one
+            _lib.check(lib.smz_traj_pack(P(chunk.data), chunk.T, t, env.obs_dim, A, P(obs if rec_obs is None else rec_obs),
+                                         P(reward), P(terminated), P(action), P(policy), P(child_visits), P(root_value),
+                                         env.B, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return chunk
 
 
@@ -254,10 +221,82 @@ def reanalyse_games(games, model, mcts, device, train=False):
     return done
 
 
+def reanalyse_replay_games(games, model, mcts, device, temperature=0.0, train=True):
+    """The reanalyse branch of the reference's play_game (self_play.py:70-81) for many stored games at once: the stored
+    game is the environment.  Step i of a stored game with n observations searches observations[i] with the CURRENT
+    networks, picks an action from the new tree (game.py:197-216) and records observations[i + 1], the reward
+    `rewards[action + 1]` (indexed by the ACTION: game.py:255), the new policy / root value / child visits; the replay
+    ends with the step for which i + 2 >= n - 1 (game.py:256), i.e. after n - 2 steps.  The observation sequence does
+    not depend on the new actions, so all steps of all games are searched as ONE batch (tree k <-> (game, step) in
+    game-major order; its random stream is tree k's).  Returns one GameRecord per stored game with at least 3
+    observations, `reanalyzed` set.  `mcts.num_trees` is the batch size per launch (the last batch is padded)."""
+    heads = model.heads(device)
+    obs, index = [], []
+    for gi, g in enumerate(games):
+        n = len(g.observations)
+        for i in range(max(0, n - 2)):
+            obs.append(torch.as_tensor(g.observations[i]).reshape(-1))
+            index.append((gi, i))
+    out = {}
+    B = mcts.num_trees
+    for lo in range(0, len(obs), B):
+        rows = obs[lo:lo + B]
+        batch = torch.stack(rows + [rows[-1]] * (B - len(rows))).to(device=device, dtype=torch.float32).contiguous()
+        eng = mcts.run(batch, heads, train=train, act_temperature=temperature)
+        action, policy, child_visits, root_value = eng.act(temperature)
+        torch.cuda.synchronize(device)
+        a, p, cv, rv = (t.cpu().numpy() for t in (action, policy, child_visits, root_value))
+        for k, (gi, i) in enumerate(index[lo:lo + B]):
+            src = games[gi]
+            rec = out.get(gi)
+            if rec is None:
+                rec = out[gi] = GameRecord(src.discount, src.action_space_size, src.priority_scale, src.limit_of_game_play)
+                rec.reanalyzed = True
+            if rec.done or rec.game_length >= rec.limit_of_game_play:
+                continue                                              # the reference's loop has already stopped
+            onehot = np.zeros(src.action_space_size)
+            onehot[int(a[k])] = 1
+            rec.observations.append(src.observations[i + 1])
+            rec.rewards.append(src.rewards[int(a[k]) + 1])
+            rec.policies.append(p[k].copy())
+            rec.action_history.append(onehot)
+            rec.root_values.append(np.float32(rv[k]))
+            rec.child_visits.append(cv[k].copy())
+            done = i + 2 >= len(src.observations) - 1
+            rec.done = done if rec.limit_of_game_play != len(rec.observations) else False
+    return [out[gi] for gi in sorted(out)]
+
+
+def play_game(environment=None, model=None, monte_carlo_tree_search=None, temperature=1, replay_buffer=None):
+    """The reference's per-game loop (self_play.py:63-98) with its exact call sequence, for ONE game: `environment` is a
+    Game (this package's or the reference's), `monte_carlo_tree_search` any object with run(observation=, model=, train=)
+    -> root and `.cycle.global_reset()` -- this package's Monte_carlo_tree_search keeps the tree on the GPU.  Returns
+    the played copy of `environment`.  Many games at once: play_games / self_play_iteration."""
+    import copy
+    environment = copy.deepcopy(environment)
+    reanalyse = replay_buffer.should_reanalyse()
+    stored = replay_buffer.reanalyse_buffer_sample_game() if reanalyse else None
+    if not reanalyse and environment.env.metadata["render_fps"] is None:
+        environment.env.metadata["render_fps"] = 30
+    counter, step_output = 0, None
+    while not environment.terminal and counter < environment.limit_of_game_play:
+        feedback = stored if reanalyse else step_output
+        state = environment.observation(iteration=counter, feedback=feedback)
+        tree = monte_carlo_tree_search.run(observation=state, model=model, train=True)
+        step_output = environment.policy_step(root=tree, temperature=temperature, feedback=feedback, iteration=counter)
+        environment.store_search_statistics(tree)
+        counter += 1
+    monte_carlo_tree_search.cycle.global_reset()
+    environment.close()
+    return environment
+
+
 def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None, gather=None, priority_scale=1,
-                        ignore_termination=False):
+                        ignore_termination=False, limit_of_game_play=None):
     """Self-play half of one learning_cycle iteration (self_play.py:245-271): play, gather to the learner rank,
-    hand the games to replay_buffer.save_game, return (games, mean reward) on the learner rank."""
+    hand the games to replay_buffer.save_game, return (games, mean reward) on the learner rank.
+    An env built with on_end="reset" plays game after game inside the chunk (only finished games are handed on, the
+    unfinished tail is dropped); on_end="mask" plays one game per env and stops searching it when it ends."""
     heads = model.heads(env.device)
     env.reset()
     chunk = play_games(env, heads, mcts, temperature, steps)
@@ -268,11 +307,79 @@ def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None
             return None, None
         data = torch.cat([p for p in parts], dim=1)
     torch.cuda.synchronize(env.device)
+    on_end = getattr(env, "on_end", "continue")
+    limit = limit_of_game_play if limit_of_game_play is not None else (getattr(env, "limit", 0) or steps)
     games = chunk_to_games(data, env.obs_dim, env.num_actions, mcts.discount, priority_scale,
-                           limit_of_game_play=steps, ignore_termination=ignore_termination)
+                           limit_of_game_play=limit, ignore_termination=ignore_termination,
+                           keep_partial=on_end != "reset", after_end="new_game" if on_end == "reset" else "drop")
     rewards = []
     for g in games:
         if replay_buffer is not None:
             replay_buffer.save_game(g)
         rewards.append(sum(g.rewards))
-    return games, sum(rewards) / len(rewards)
+    return games, (sum(rewards) / len(rewards) if rewards else float("nan"))
+
+
+def learning_cycle(number_of_iteration=10000, number_of_self_play_before_training=1, number_of_training_before_self_play=1,
+                   model_tag_number=124, number_of_worker_selfplay=1, temperature_type="static_temperature", verbose=True,
+                   muzero_model=None, gameplay=None, monte_carlo_tree_search=None, replay_buffer=None,
+                   steps_per_iteration=None, gather=None, model_directory="model_checkpoint"):
+    """The reference's learning_cycle (self_play.py:168-306), same keyword arguments, assertions and return value
+    (epoch_pr, loss, reward, configuration).  What plays the games is chosen the way the reference chooses its backend
+    (self_play.py:237-243), by `number_of_worker_selfplay` and by what `gameplay` is:
+
+      * `gameplay` is a vectorised device environment (it has `.B`; envs.CartPoleVec, envs.HostVecEnv ...) and
+        `monte_carlo_tree_search` a BatchedMCTS -- or number_of_worker_selfplay == "gpu": the batched GPU engine plays
+        all gameplay.B games of an iteration at once (self_play_iteration; `steps_per_iteration` env steps, default
+        the env's limit or 500) -- this replaces the Ray fan-out of self_play.py:248-256;
+      * otherwise: `number_of_self_play_before_training` sequential play_game calls (self_play.py:258-265; the Ray
+        workers of the reference are not part of this build -- a worker count >= 2 with a single-game `gameplay` is
+        served sequentially).
+
+    The training half (self_play.py:285-288) calls muzero_model.train(replay_buffer.sample_batch()) exactly as the
+    reference does; this package's Muzero raises NotImplementedError there (training is the reference's), any model
+    object with the reference's train() works."""
+    assert isinstance(number_of_iteration, int) and number_of_iteration >= 1, "number_of_iterationt ∈ int | {1 < number_of_iteration < +inf)"
+    assert isinstance(number_of_self_play_before_training, int) and number_of_self_play_before_training >= 0, "number_of_self_play_before_training ∈ int | {0 < number_of_self_play_before_training < +inf)"
+    assert isinstance(number_of_training_before_self_play, int) and number_of_training_before_self_play >= 0, "number_of_training_before_self_play ∈ int | {0 < number_of_training_before_self_play < +inf)"
+    assert isinstance(model_tag_number, int) and model_tag_number >= 0, "model_tag_number ∈ int | {0 < model_tag_number < +inf)"
+    assert number_of_worker_selfplay in ("max", "all", "gpu") or (isinstance(number_of_worker_selfplay, int) and number_of_worker_selfplay >= 0), "number_of_worker_selfplay ∈ float | {0 < discount < +inf)"
+    assert isinstance(temperature_type, str) and temperature_type in ["reversal_tanh_temperature", "extreme_temperature", "linear_decrease_temperature", "static_temperature", "static_one_temperature"], "temperature_type ∈ {reversal_tanh_temperature,extreme_temperature,linear_decrease_temperature,static_temperature,static_one_temperature} ⊆ str "
+    assert isinstance(verbose, bool), "verbose ∈ bool"
+    batched = number_of_worker_selfplay == "gpu" or hasattr(gameplay, "B")
+    reward, epoch_pr, loss = [-float("inf")], [], []
+    for ep in range(1, number_of_iteration + 1):
+        temperature = temperature_scheduler(number_of_iteration + 1, ep, mode=temperature_type)
+        if isinstance(temperature, np.ndarray):
+            temperature = float(temperature.reshape(-1)[0])
+        if batched:
+            steps = steps_per_iteration or getattr(gameplay, "limit", 0) or 500
+            game, _ = self_play_iteration(gameplay, muzero_model, monte_carlo_tree_search, temperature, steps, gather=gather)
+            game = game or []
+        else:
+            game = [play_game(environment=gameplay, model=muzero_model, monte_carlo_tree_search=monte_carlo_tree_search,
+                              temperature=temperature, replay_buffer=replay_buffer)
+                    for _ in range(number_of_self_play_before_training)]
+        cache_reward, cache_loss = [], []
+        for g in game:
+            replay_buffer.save_game(g)
+            cache_reward.append(sum(g.rewards))
+        reward.append(sum(cache_reward) / len(cache_reward))
+        did_better = None if reward[-1] == max(reward) and not all(g.reanalyzed for g in game) else "do not save"
+        if did_better is None and verbose:
+            print("save model with : ", reward[-1], " reward")
+        muzero_model.save_model(directory=model_directory, tag=model_tag_number, model_update_or_backtrack=did_better)
+        for _ in range(number_of_training_before_self_play):
+            new_priority, batch_game_position = muzero_model.train(replay_buffer.sample_batch())
+            replay_buffer.update_value(new_priority, batch_game_position)
+            cache_loss.append(muzero_model.store_loss[-1][0])
+        loss.append(sum(cache_loss) / len(cache_loss) if cache_loss else float("nan"))   # (the reference divides by 0 here)
+        epoch_pr.append(f"EPOCH {ep} || selfplay reward: {reward[-1]} || training loss: {loss[-1]}||")
+        if verbose:
+            print(epoch_pr[-1], end="\r")
+    configuration = {"number_of_iteration": number_of_iteration,
+                     "number_of_self_play_before_training": number_of_self_play_before_training,
+                     "number_of_training_before_self_play": number_of_training_before_self_play,
+                     "model_tag_number": model_tag_number, "number_of_worker_selfplay": number_of_worker_selfplay,
+                     "temperature_type": temperature_type, "verbose": verbose}
+    return epoch_pr, loss, reward, configuration

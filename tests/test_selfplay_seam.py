@@ -1,0 +1,271 @@
+"""The self-play drop-in seam on the CPU: play_game / Game / learning_cycle driven exactly as self_play.py:63-98, 168-306
+drive them, against games the REFERENCE itself played (goldens of oracle/gen_golden.py and gen_golden_r2.py).  The tree
+arithmetic underneath is the CPU oracle's here (seam_harness.OracleSearch); tests/test_gpu_selfplay_seam.py runs the
+same sequences over the GPU engine."""
+import os
+import random
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import seam_harness as sh
+
+
+def _pkg(name):
+    import stochastic_muzero_amd  # noqa: F401
+    return import_module("stochastic-muzero_amd." + name)
+
+
+def _game(env, limit, obs_dim=4, priority_scale=0.5):
+    return _pkg("game").Game(gym_env=env, discount=0.999, limit_of_game_play=limit, observation_dimension=obs_dim,
+                             action_dimension=2, rgb_observation=False, action_map=[0, 1], priority_scale=priority_scale)
+
+
+@pytest.mark.parametrize("name", gu.SELFPLAY_FIXTURES)
+def test_play_game_reproduces_the_references_own_games(name):
+    """play_game(environment, model, monte_carlo_tree_search, temperature, replay_buffer) -> Game with the reference's
+    call sequence: every list of the reference's game (observations, rewards, policies, actions, root values, child
+    visits), Game.done, the reset seed drawn from Python's `random`, and numpy's stream position afterwards."""
+    sp = _pkg("selfplay")
+    cfg, data = gu.load(name)
+    search = sh.OracleSearch(cfg)
+    random.seed(int(data["seed"]))
+    np.random.seed(int(data["seed"]))
+    g = sp.play_game(environment=_game(sh.MathCartPole(), int(data["limit"])), model=sh.TapePlayer(data),
+                     monte_carlo_tree_search=search, temperature=float(data["temperature"]), replay_buffer=sh.FakeBuffer())
+    sh.assert_game_equals(g, data)
+    assert np.random.random_sample() == data["probe"]
+    assert search.cycle.resets == 1 and search.runs == g.game_length and not g.reanalyzed
+    pos, top = g.make_priority(50)
+    np.testing.assert_allclose(pos, data["buffer_prio_position"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["reanalyse421_sims10_T1", "reanalyse421_sims10_T0"])
+def test_play_game_reanalyse_branch_replays_a_stored_game_like_the_reference(name):
+    """self_play.py:70-81 with game.py:112-115, 254-257: the stored game is the environment -- observation i + 1, the
+    reward `rewards[action + 1]`, done once i + 2 >= n - 1 -- searched afresh.  The reference's own reanalysed game."""
+    sp = _pkg("selfplay")
+    cfg, data = gu.load(name)
+    GameRecord = _pkg("game").GameRecord
+    stored = GameRecord(0.999, 2, 0.5, int(data["limit"]))
+    stored.observations = [torch.from_numpy(o[None].copy()) for o in data["src_observations"]]
+    stored.rewards = [float(r) for r in data["src_rewards"]]
+    buf = sh.FakeBuffer(stored, (data["np_key_before_first_search"], data["np_pos_before_first_search"]))
+    search = sh.OracleSearch(cfg)
+    g = sp.play_game(environment=_game(sh.MathCartPole(), int(data["limit"])), model=sh.TapePlayer(data),
+                     monte_carlo_tree_search=search, temperature=float(data["temperature"]), replay_buffer=buf)
+    sh.assert_game_equals(g, data)
+    assert g.reanalyzed and g.game_length == len(stored.observations) - 2
+    assert np.random.random_sample() == data["probe"]
+
+
+def test_illegal_moves_get_the_references_penalty():
+    """game.py:123-131 through the whole loop: an env.step that raises leaves the observation where it was, costs
+    min(-len(rewards), -limit_of_game_play, -1) and does not end the game.  The reference's own game on the same env."""
+    sp = _pkg("selfplay")
+    cfg, data = gu.load("game_illegal_moves")
+    random.seed(int(data["seed"]))
+    np.random.seed(int(data["seed"]))
+    g = sp.play_game(environment=_game(sh.PickyWalk(), int(data["limit"]), obs_dim=1, priority_scale=1),
+                     model=sh.TapePlayer(data), monte_carlo_tree_search=sh.OracleSearch(cfg), temperature=1.0,
+                     replay_buffer=sh.FakeBuffer())
+    sh.assert_game_equals(g, data)
+    assert min(g.rewards) == -14 and np.random.random_sample() == data["probe"]
+    # the rule's own quirk, kept: the handler hands back an already flattened observation, which flatten_state only
+    # takes for single-component observations (game.py:145-167) -- wider ones raise, as in the reference
+    wide = _game(sh.MathCartPole(), 5)
+    wide.observation(iteration=0, feedback=None)
+    wide.env.step = lambda a: (_ for _ in ()).throw(ValueError("illegal"))
+    with pytest.raises(ValueError):
+        wide.policy_step(root=_root([3, 7]), temperature=0, feedback=None, iteration=0)
+
+
+class _Child:
+    def __init__(self, n, prior):
+        self.visit_count, self.prior, self.reward = n, prior, 0.0
+
+
+class _Root:
+    def __init__(self, visits, priors):
+        self.children = {a: _Child(n, p) for a, (n, p) in enumerate(zip(visits, priors))}
+        self.visit_count = sum(visits)
+
+    def value(self):
+        return np.float32(1.5)
+
+
+def _root(visits, priors=(0.4, 0.6)):
+    return _Root(visits, priors)
+
+
+def test_game_policy_step_rules():
+    """game.py:179-232 case by case: visit-count policy, priors when the root was hardly visited, the temperature
+    thresholds (>= 0.3 power, > 0.1 sampling), first-maximum arg-max, the >= 3 rule of store_search_statistics."""
+    g = _game(sh.MathCartPole(), 50)
+    g.observation(iteration=0, feedback=None)
+    np.random.seed(0)
+    g.policy_step(root=_root([3, 7]), temperature=0, feedback=None, iteration=0)
+    assert np.array_equal(g.policies[-1], [0.3, 0.7]) and np.argmax(g.action_history[-1]) == 1
+    g.policy_step(root=_root([1, 0]), temperature=0, feedback=None, iteration=1)          # sum <= 1: priors
+    assert np.array_equal(g.policies[-1], np.array([0.4, 0.6]) / 1.0)
+    g.policy_step(root=_root([4, 4]), temperature=0, feedback=None, iteration=2)          # all equal: sampled
+    g.policy_step(root=_root([1, 3]), temperature=0.5, feedback=None, iteration=3)
+    np.testing.assert_allclose(g.policies[-1], np.array([1.0, 9.0]) / 10.0)
+    g.store_search_statistics(_root([1, 1]))
+    np.testing.assert_allclose(g.child_visits[-1], [0.4, 0.6])
+    g.store_search_statistics(_root([1, 2]))
+    np.testing.assert_allclose(g.child_visits[-1], [1 / 3, 2 / 3])
+    assert g.root_values == [np.float32(1.5)] * 2 and g.game_length == 4
+    for bad in (dict(discount=1), dict(action_dimension=0), dict(rgb_observation=None), dict(priority_scale=2),
+                dict(limit_of_game_play=-1)):
+        kw = dict(gym_env=None, discount=0.9, limit_of_game_play=5, observation_dimension=4, action_dimension=2,
+                  rgb_observation=False, action_map=[0, 1], priority_scale=1)
+        kw.update(bad)
+        with pytest.raises(AssertionError):
+            _pkg("game").Game(**kw)
+
+
+def test_rgb_observations_are_resized_to_the_model_frame():
+    """game.py:82-89: HWC uint8 frame -> [1, 3, 98, 98] float32 in [0, 1] (torch bilinear; torchvision is absent here, so
+    the resize itself is parity-unpinned -- shape, range and the exactness of a same-size pass are checked)."""
+    class Frames:
+        metadata = {"render_fps": 30}
+        def reset(self, seed=None):
+            return np.zeros(4), {}
+        def render(self):
+            return np.full((196, 196, 3), 255, np.uint8)
+        def step(self, a):
+            return np.zeros(4), 1.0, False, False, {}
+        def close(self):
+            pass
+    g = _pkg("game").Game(gym_env=Frames(), discount=0.9, limit_of_game_play=5, observation_dimension=(98, 98, 3),
+                          action_dimension=2, rgb_observation=True, action_map=[0, 1])
+    s = g.observation(iteration=0, feedback=None)
+    assert tuple(s.shape) == (1, 3, 98, 98) and s.dtype == torch.float32 and float(s.min()) == 1.0 == float(s.max())
+    same = g.transform_rgb(np.arange(98 * 98 * 3, dtype=np.uint8).reshape(98, 98, 3))
+    assert torch.equal(same[0], torch.from_numpy(np.arange(98 * 98 * 3, dtype=np.uint8).reshape(98, 98, 3)).permute(2, 0, 1) / 255)
+
+
+class _TrainableStub:
+    """A model as learning_cycle needs it: save_model + train + store_loss (self_play.py:273-288)."""
+    def __init__(self, data):
+        self.tape, self.saved, self.trained, self.store_loss = sh.TapePlayer(data), [], 0, []
+
+    def __getattr__(self, k):
+        return getattr(self.tape, k)
+
+    def save_model(self, directory=None, tag=None, model_update_or_backtrack=None):
+        self.saved.append((tag, model_update_or_backtrack))
+
+    def train(self, batch):
+        self.trained += 1
+        self.store_loss.append([0.25 * self.trained])
+        return "prio", "pos"
+
+
+def test_learning_cycle_keeps_the_references_call_sequence():
+    """learning_cycle(...) with the reference's keyword arguments (self_play.py:168-178): games through play_game,
+    save_game per game, best-model gating, train / update_value per training step, the four return values."""
+    sp = _pkg("selfplay")
+    cfg, data = gu.load("selfplay421_sims10_T0")          # temperature 0 == "static_temperature"
+    model, buf, search = _TrainableStub(data), sh.FakeBuffer(), sh.OracleSearch(cfg)
+    random.seed(int(data["seed"]))
+    np.random.seed(int(data["seed"]))
+    epoch_pr, loss, reward, conf = sp.learning_cycle(
+        number_of_iteration=1, number_of_self_play_before_training=1, number_of_training_before_self_play=2,
+        model_tag_number=421, number_of_worker_selfplay=1, temperature_type="static_temperature", verbose=False,
+        muzero_model=model, gameplay=_game(sh.MathCartPole(), int(data["limit"])), monte_carlo_tree_search=search,
+        replay_buffer=buf)
+    assert len(buf.saved) == 1
+    sh.assert_game_equals(buf.saved[0], data)
+    assert reward == [-float("inf"), float(sum(data["game_rewards"]))] and loss == [(0.25 + 0.5) / 2]
+    assert model.saved == [(421, None)] and model.trained == 2 and buf.updated == ("prio", "pos")
+    assert conf == {"number_of_iteration": 1, "number_of_self_play_before_training": 1,
+                    "number_of_training_before_self_play": 2, "model_tag_number": 421, "number_of_worker_selfplay": 1,
+                    "temperature_type": "static_temperature", "verbose": False}
+    assert epoch_pr[0].startswith("EPOCH 1 || selfplay reward: ")
+    for bad in (dict(number_of_iteration=0), dict(temperature_type="hot"), dict(verbose=1), dict(model_tag_number=-1)):
+        kw = dict(number_of_iteration=1, temperature_type="static_temperature", verbose=False, model_tag_number=1)
+        kw.update(bad)
+        with pytest.raises(AssertionError):
+            sp.learning_cycle(**kw)
+
+
+def test_chunk_flags_cut_games_like_the_loop_does():
+    """Trajectory records -> games: flag 1 ends a game with done True, 2 (limit_of_game_play) with done False
+    (game.py:270-271), 3 marks rows of a switched-off env; a restarting env yields several games per chunk."""
+    sp = _pkg("selfplay")
+    T, B, o, A = 9, 3, 4, 2
+    F = o + 3 * A + 3
+    d = np.zeros((T, B, F))
+    d[..., o] = 1.0
+    d[..., o + 2 + 2 * A] = np.arange(T)[:, None]
+    d[[2, 6], 0, o + 1] = [1, 2]                 # env 0: games of 3 and 4 steps, then an unfinished one of 2
+    d[2, 1, o + 1] = 1; d[3:, 1, o + 1] = 3      # env 1: one game of 3 steps, then switched off
+    games = sp.chunk_to_games(d, o, A, 0.99, after_end="new_game", keep_partial=False, limit_of_game_play=4)
+    assert [g.game_length for g in games] == [3, 4, 3] and [g.done for g in games] == [True, False, True]
+    games = sp.chunk_to_games(d, o, A, 0.99, after_end="new_game", keep_partial=True)
+    assert [g.game_length for g in games] == [3, 4, 2, 3, 9]
+    games = sp.chunk_to_games(d, o, A, 0.99)      # default: rows behind an env's first finished game are dropped
+    assert [g.game_length for g in games] == [3, 3, 9]
+    assert [float(v) for v in games[0].root_values] == [0.0, 1.0, 2.0]
+
+
+def test_fresh_mlp_models_reproduce_the_references_initial_weights():
+    """Same torch seed, same constructor => the parameters the reference's Muzero(...) starts from, bit for bit
+    (muzero_model.py:300-358; the reference builds one Linear it never uses in two of the six classes)."""
+    model = _pkg("model")
+    z = np.load(os.path.join(gu.GOLDEN, "mlpnet_seed7.npz"))
+    torch.manual_seed(int(z["meta_torch_seed"]))
+    m = model.Muzero(model_structure="mlp_model", observation_space_dimensions=int(z["meta_obs"]),
+                     action_space_dimensions=int(z["meta_A"]), state_space_dimensions=int(z["meta_S"]),
+                     hidden_layer_dimensions=int(z["meta_H"]), number_of_hidden_layer=int(z["meta_L"]), random_tag=1)
+    n = 0
+    for f in ("representation", "prediction", "afterstate_prediction", "afterstate_dynamics", "dynamics", "encoder"):
+        for k, v in getattr(m, f + "_function").state_dict().items():
+            assert np.array_equal(v.numpy(), z[f + "/" + k]), (f, k)
+            n += 1
+    assert n == len([k for k in z.files if "/" in k])
+
+
+def test_heads_cache_follows_in_place_weight_updates():
+    """Muzero.heads() re-packs when a module was written in place (optimizer step, load_state_dict, copy_): the cache is
+    keyed on the parameters' versions.  (Packing itself needs the HIP library only for the layout call.)"""
+    model = _pkg("model")
+    m = model.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_ckpt421.npz"))
+    v0 = m.weights_version()
+    assert m.weights_version() == v0
+    with torch.no_grad():
+        m.dynamics_function.next_state_normalized[0].weight.mul_(1.5)
+    v1 = m.weights_version()
+    assert v1 != v0
+    m.prediction_function.load_state_dict(m.prediction_function.state_dict())
+    assert m.weights_version() != v1
+    m._heads[("cpu", 0, "x")] = "stale"; m._heads_version[("cpu", 0, "x")] = v0
+    m.refresh_heads()
+    assert m._heads == {} and m._heads_version == {}
+
+
+def test_checkpoints_pickle_beside_an_imported_reference_module(tmp_path):
+    """save_model while ANOTHER module is registered as neural_network_mlp_model (a process that has imported the
+    reference's own file): the pickles still carry the reference's class paths, and whatever was registered is back in
+    place afterwards; nothing of this package stays in sys.modules."""
+    import sys
+    import types
+    model = _pkg("model")
+    other = types.ModuleType("neural_network_mlp_model")
+    other.Representation_function = type("Representation_function", (), {})
+    sys.modules["neural_network_mlp_model"] = other
+    try:
+        m = model.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_lunar_L2.npz"))
+        m.save_model(directory=str(tmp_path), tag=5)
+        assert sys.modules["neural_network_mlp_model"] is other
+        assert b"neural_network_mlp_model" in open(tmp_path / "5_muzero_dynamics_function.pt", "rb").read()
+    finally:
+        del sys.modules["neural_network_mlp_model"]
+    m2 = model.Muzero.from_checkpoint(str(tmp_path), tag=5)
+    assert "neural_network_mlp_model" not in sys.modules and "neural_network_vision_model" not in sys.modules
+    assert m2.state_dimension == 16
