@@ -16,7 +16,7 @@
 // Eval-mode batch-norm is folded on the host to y = x * scale + shift exactly as ATen does on the CPU
 // (scale = weight / sqrt(var + eps), shift = bias - mean * scale); multiply and add stay separate instructions.
 // Floating-point parity class: 2e-5 on hidden planes / policies against the reference's recorded outputs
-// (tests/test_gpu_vision.py), like the MLP family.
+// (tests/test_gpu_end_to_end.py::test_vision_*), like the MLP family.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

@@ -201,7 +201,8 @@ def test_single_tree_drop_in_matches_reference_game():
     assert np.random.random_sample() == data["probe"]
 
 
-@pytest.mark.parametrize("wname,B,sims,K", [("weights_ckpt421", 4096, 50, 2), ("weights_ckpt421", 100, 11, 2),
+@pytest.mark.parametrize("wname,B,sims,K", [("weights_ckpt421", 4096, 50, 2), ("weights_ckpt421", 4096, 100, 2),
+                                            ("weights_lunar_L0", 4096, 50, 2), ("weights_ckpt421", 100, 11, 2),
                                             ("weights_ckpt421", 2049, 8, 2), ("weights_ckpt421", 4097, 9, 2),
                                             ("weights_lunar_L0", 4096, 12, 2),
                                             ("weights_lunar_L0", 700, 30, 4), ("weights_lunar_L2", 256, 24, 3),
