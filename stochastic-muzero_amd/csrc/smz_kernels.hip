@@ -962,7 +962,7 @@ __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, i
         double v;
         if (k < obs_dim) v = (double)obs[(size_t)e * obs_dim + k];
         else if (k == obs_dim) v = reward ? (double)reward[e] : 0.0;
-        else if (k == obs_dim + 1) v = (terminated && terminated[e]) ? 1.0 : 0.0;
+        else if (k == obs_dim + 1) v = terminated ? (double)terminated[e] : 0.0;     // the flag itself: 0 / 1 / 2 / 3
         else {
             const int j = k - obs_dim - 2;
             if (j < A) v = policy[(size_t)e * A + j];

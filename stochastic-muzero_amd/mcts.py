@@ -169,7 +169,7 @@ class BatchedMCTS(_Hyper):
         With HipMlpHeads the whole search is ONE kernel launch (smz_search_mlp) when it fits in LDS; otherwise the
         step-wise kernels run, captured in a HIP graph unless use_graph is off."""
         # beyond ~32k trees the step-wise kernels (64 trees per wavefront, every lane busy) overtake the single launch
-        if (self.single_launch and getattr(heads, "desc", None) is not None and self._single is not False
+        if (self.single_launch and isinstance(getattr(heads, "desc", None), _lib.MlpDesc) and self._single is not False
                 and self.num_trees <= self.single_launch_max_trees):
             eng = self._ensure_engine(heads.A, heads.S)
             if getattr(self, "_pending_seed", None) is not None:

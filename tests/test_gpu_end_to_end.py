@@ -36,8 +36,13 @@ def test_batched_heads_match_reference_head_outputs(name, wname, backend):
     ncase, sims = data["tape_branch"].shape
     A = data["root_policy"].shape[-1]
     hid, pol = heads.initial(torch.from_numpy(data["obs"]).cuda())
-    torch.testing.assert_close(hid.cpu(), torch.from_numpy(data["root_hidden"]), rtol=0, atol=1e-5)
-    torch.testing.assert_close(pol.cpu(), torch.from_numpy(data["root_policy"]), rtol=0, atol=1e-5)
+    # Tolerances follow what is MEASURED on MI355X (tools/head_error_report.py -> profiles/r02_head_errors.json): hidden
+    # states and policies differ from the reference's torch-CPU numbers by <= 3.6e-7 / 2.4e-7 absolute; decoded scalars
+    # (inverse support transform, muzero_model.py:575-591) by <= 1.9e-5 relative on checkpoint 421 (values ~ 70) and
+    # <= 1.3e-4 absolute near zero -- the float32 cancellation of sqrt(1 + 4 eps (|y| + 1 + eps)) - 1, which the
+    # torch-ROCm GEMM path shows to the same digit.  north_star's 1e-5 is met by everything but that transform.
+    torch.testing.assert_close(hid.cpu(), torch.from_numpy(data["root_hidden"]), rtol=0, atol=1e-6)
+    torch.testing.assert_close(pol.cpu(), torch.from_numpy(data["root_policy"]), rtol=0, atol=1e-6)
     fe = _FakeEngine()
     hin = torch.from_numpy(data["tape_hidden_in"].reshape(ncase * sims, -1))
     onehot = torch.eye(A)[torch.from_numpy(data["tape_action"].reshape(-1)).long()]
@@ -45,11 +50,10 @@ def test_batched_heads_match_reference_head_outputs(name, wname, backend):
     fe.branch = torch.from_numpy(data["tape_branch"].reshape(-1).astype(np.uint8)).cuda()
     h2, rw, p2, v2 = heads.recurrent(fe)
     torch.cuda.synchronize()
-    torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(ncase * sims, -1)), rtol=0, atol=2e-5)
-    torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1)), rtol=0, atol=1e-5)
-    # decoded scalars: float32 cancellation in the inverse support transform (see test_oracle_golden) -> 5e-4
-    torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=1e-4, atol=5e-4)
-    torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(ncase * sims, -1)), rtol=0, atol=1e-6)
+    torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1)), rtol=0, atol=1e-6)
+    torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=3e-5, atol=2e-4)
+    torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=3e-5, atol=2e-4)
     assert (rw.cpu()[torch.from_numpy(data["tape_branch"].reshape(-1)) == 0] == 0).all()
 
 
@@ -396,8 +400,9 @@ def _frame(seed):
 def test_vision_family_heads_on_gpu_match_the_reference_tape(backend):
     """a22: the reference's ResNet-v2 family on the GPU -- the hand-written HIP kernels (HipVisionHeads:
     smz_vision_initial / smz_vision_recurrent) and the torch-ROCm module path (ModuleHeads) -- vs every network call the
-    reference (torch CPU) recorded in vision_sims50.npz.  Accumulation orders differ from ATen's CPU kernels: 2e-5 on
-    hidden planes and policies, 5e-4 on decoded scalars (inverse-transform cancellation)."""
+    reference (torch CPU) recorded in vision_sims50.npz.  Accumulation orders differ from ATen's CPU kernels; tolerances
+    follow the measured errors (profiles/r02_head_errors.json): 1e-5 on hidden planes, 1e-6 on policies, 3e-5 relative
+    + 2e-4 absolute on decoded scalars (inverse-transform cancellation)."""
     _, model_mod, _, _ = _mods()
     cfg, data = gu.load("vision_sims50")
     model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L1_seed0.npz"))
@@ -406,8 +411,8 @@ def test_vision_family_heads_on_gpu_match_the_reference_tape(backend):
     ncase, sims = data["tape_branch"].shape
     obs = torch.cat([_frame(3000 + int(s)) for s in data["seed"]]).cuda()
     hid, pol = heads.initial(obs)
-    torch.testing.assert_close(hid.cpu(), torch.from_numpy(data["root_hidden"]), rtol=0, atol=2e-5)
-    torch.testing.assert_close(pol.cpu(), torch.from_numpy(data["root_policy"]), rtol=0, atol=2e-5)
+    torch.testing.assert_close(hid.cpu(), torch.from_numpy(data["root_hidden"]), rtol=0, atol=1e-5)   # measured 6.9e-6
+    torch.testing.assert_close(pol.cpu(), torch.from_numpy(data["root_policy"]), rtol=0, atol=1e-6)   # measured 6e-8
     fe = _FakeEngine()
     fe.B, fe.S = ncase * sims, 147
     fe.parent_hidden = torch.from_numpy(data["tape_hidden_in"].reshape(fe.B, -1)).cuda().contiguous()
@@ -415,10 +420,10 @@ def test_vision_family_heads_on_gpu_match_the_reference_tape(backend):
     fe.branch = torch.from_numpy(data["tape_branch"].reshape(-1).astype(np.uint8)).cuda()
     h2, rw, p2, v2 = heads.recurrent(fe)
     torch.cuda.synchronize()
-    torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(fe.B, -1)), rtol=0, atol=2e-5)
-    torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(fe.B, -1)), rtol=0, atol=2e-5)
-    torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=1e-4, atol=5e-4)
-    torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(fe.B, -1)), rtol=0, atol=1e-5)
+    torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(fe.B, -1)), rtol=0, atol=1e-6)
+    torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=3e-5, atol=2e-4)
+    torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=3e-5, atol=2e-4)
 
 
 @pytest.mark.parametrize("backend", ["hip", "torch"])
@@ -443,7 +448,7 @@ def test_vision_search_reproduces_the_reference_visit_counts(use_graph, backend)
     torch.cuda.synchronize()
     assert np.array_equal(visits.cpu().numpy(), data["root_visits"])
     np.testing.assert_allclose(priors.cpu().numpy(), data["root_priors"], rtol=0, atol=2e-5)
-    np.testing.assert_allclose(root_value.cpu().numpy(), data["root_value"], rtol=1e-4, atol=5e-4)
+    np.testing.assert_allclose(root_value.cpu().numpy(), data["root_value"], rtol=5e-5, atol=2e-4)
 
 
 def test_hip_vision_heads_agree_with_the_torch_modules_on_a_large_batch():
@@ -483,8 +488,8 @@ def test_hip_vision_heads_agree_with_the_torch_modules_on_a_large_batch():
         rw_ref = torch.where(branch, model.inverse_transform_with_support(r_logits).flatten(), torch.zeros(B))
     torch.testing.assert_close(h2, h_ref.reshape(B, -1), rtol=0, atol=2e-5)
     torch.testing.assert_close(pol, pol_ref, rtol=0, atol=2e-5)
-    torch.testing.assert_close(rw, rw_ref, rtol=1e-4, atol=5e-4)
-    torch.testing.assert_close(val, val_ref, rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(rw, rw_ref, rtol=5e-5, atol=2e-4)
+    torch.testing.assert_close(val, val_ref, rtol=5e-5, atol=2e-4)
     assert (rw[~branch] == 0).all() and (rw[branch] != 0).any()
 
 
@@ -507,7 +512,7 @@ def test_drop_in_search_with_the_vision_family_on_its_own_inference_functions():
         assert [c.visit_count for c in root.children.values()] == list(data["root_visits"][i])
         # the network runs on THIS host's CPU (ATen picks kernels per ISA): float32 policy rounding, 1e-6 relative
         np.testing.assert_allclose([c.prior for c in root.children.values()], data["root_priors"][i], rtol=1e-6)
-        np.testing.assert_allclose(root.value(), data["root_value"][i], rtol=1e-4, atol=5e-4)
+        np.testing.assert_allclose(root.value(), data["root_value"][i], rtol=5e-5, atol=2e-4)
         assert np.random.random_sample() == data["probe"][i]          # the global stream is where the reference left it
         m.cycle.global_reset()
 

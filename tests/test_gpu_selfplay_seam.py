@@ -80,7 +80,8 @@ def test_finished_games_stop_consuming_simulations(single_launch):
     B, T, sims, limit = 96, 30, 8, 22
     env = envs_mod.CartPoleVec(B, "cuda:0", seed=2, on_end="mask", limit=limit)
     env.reset()
-    env.state[:24, 2] = 0.2                       # these poles are about to fall: early terminations
+    env.state[:24, 2] = 0.2                       # these poles are falling and cannot be caught: early terminations
+    env.state[:24, 3] = 3.0
     env.obs.copy_(env.state.float())
     m = _batched(B, sims)
     m.single_launch = single_launch

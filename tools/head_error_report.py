@@ -41,6 +41,9 @@ def main():
         A = data["root_policy"].shape[-1]
         for backend in ("hip", "torch"):
             heads = model.heads("cuda:0", backend=backend)
+            if loader == "sd":      # the module path learns the hidden-state shape from a representation call
+                frames = np.stack([np.random.RandomState(3000 + int(s)).rand(3, 98, 98).astype(np.float32) for s in data["seed"]])
+                heads.initial(torch.from_numpy(frames).cuda())
             fe = FE()
             hin = torch.from_numpy(data["tape_hidden_in"].reshape(ncase * sims, -1))
             fe.B, fe.S = ncase * sims, hin.shape[1]
