@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmz.so")
+LIB_PATH = os.environ.get("SMZ_LIB_PATH") or os.path.join(_HERE, "libsmz.so")   # (SMZ_LIB_PATH: A/B builds, tools/)
 
 SMZ_OK, SMZ_ERR_INVALID, SMZ_ERR_HIP, SMZ_ERR_NOMEM, SMZ_ERR_STATE, SMZ_ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5
 RNG_MT19937_NUMPY, RNG_PHILOX = 0, 1

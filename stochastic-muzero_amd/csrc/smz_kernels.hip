@@ -418,9 +418,11 @@ struct MegaLds {
     int x_off, pv_off, rng_off, out_off;                   // float offsets inside a wave's region
 };
 __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
-__host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params &P, int tpw) {
+// mf: the matrix-core evaluation (heads16_mfma) keeps its weights in registers: no LDS copy of the networks, one
+// workgroup-wide tile region (smz_mlp::kMfFloats) behind the per-wave regions
+__host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params &P, int tpw, bool mf = false) {
     MegaLds m;
-    m.pbc_off = r4(d.total_floats - smz_mlp::rep_floats(d));
+    m.pbc_off = mf ? 0 : r4(d.total_floats - smz_mlp::rep_floats(d));
     m.wave_off = m.pbc_off + r4(2 * 2 * (P.sims + 2));     // pb_c table + reciprocal table (div_by_count)
     m.x_off = r4(2 * smz_mlp::row_scratch_floats(d));     // two rows' scratch: a same-branch pair is evaluated together
     m.pv_off = m.x_off + tpw * smz_mlp::up4(P.S + P.A);
@@ -447,20 +449,30 @@ struct ActOut {              // smz_search_mlp_act: Game.policy_step folded into
 };
 constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
 #if SMZ_PART == 0 || SMZ_PART == 2 || SMZ_PART == 4
-template <int MAXA, int KS, int U, bool INSTR, bool AEX>
+// MF (only with AEX, 8 waves): the 16 leaves of the workgroup are evaluated together on the matrix cores
+// (smz_mlp::heads16_mfma): five workgroup barriers per round, weights in registers, no LDS copy of the networks.
+template <int MAXA, int KS, int U, bool INSTR, bool AEX, bool MF = false>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train, ActOut act) {
+    static_assert(!MF || (AEX && KS == 2), "the matrix-core evaluation belongs to the specialised instantiation");
     Params P = Pin;
     if (AEX) { P.A = MAXA; P.tpw = kFastTpw; d.A = MAXA; d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = smz_mlp::kWave; P.S = kFastS; }
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);
     if (AEX) P.hs = (kFastS + 15) & ~15;
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
-    const smz_mlp_desc dl = smz_mlp::lds_desc_without_rep(d);      // LDS copy: everything but the representation matrices
-    smz_mlp::stage_weights_without_rep(lds, weights, d);
+    const smz_mlp_desc dl = MF ? d : smz_mlp::lds_desc_without_rep(d);      // LDS copy: everything but the representation matrices
+    if (!MF) smz_mlp::stage_weights_without_rep(lds, weights, d);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, waves = blockDim.x / kWave;
     const int A = P.A, S = P.S, tpw = P.tpw;
-    const MegaLds ml = mega_lds(d, P, tpw);
+    const MegaLds ml = mega_lds(d, P, tpw, MF);
+    float *mf = lds + ml.wave_off + waves * ml.per_wave;                          // (MF) the workgroup's matrix-core tiles
+    smz_mlp::MfmaWeights mfw;
+    if constexpr (MF) {
+        smz_mlp::mfma_load_weights(weights, d, wave, lane, mfw);
+        for (int i = threadIdx.x; i < smz_mlp::kMfFloats; i += blockDim.x) mf[i] = 0.f;   // zero padding rows stay zero
+    }
+    const float *wsrc = MF ? weights : lds;                                       // where initial_row finds the prediction net
     double *pbc_lds = reinterpret_cast<double *>(lds + ml.pbc_off);
     const int n_pbc = P.sims + 2;
     for (int i = threadIdx.x; i < n_pbc; i += blockDim.x) {
@@ -481,14 +493,14 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
     const bool valid = lane < tpw && tree < P.B && tree_active(P, tree);
     // a wave none of whose trees is searched (beyond B, or switched off with smz_set_active) is done: there is no
     // workgroup barrier after the weight staging above
-    if (__ballot(valid) == 0ull) return;
+    if (!MF && __ballot(valid) == 0ull) return;                      // (MF: every wave takes part in the barriers and tiles)
 
     // ---- root: representation + prediction per row, then root expansion per lane ---------------------------------
     for (int t = 0; t < tpw; t++) {
         const int row = tree0 + t;
         if (row >= P.B) break;                                   // wave-uniform
         if (!__shfl((int)valid, t)) continue;                    // wave-uniform: the tree is switched off
-        smz_mlp::initial_row<U>(lds, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * P.hs,
+        smz_mlp::initial_row<U>(wsrc, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * P.hs,
                                 nullptr, outs + t * slot);
     }
     int packed = wave_stage_rng(P, tree, valid, rng_tile);
@@ -588,8 +600,35 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         StagePre<SU> pre;       // (after the fence: it drains the vector-memory counter)
         if (split && !(dbg & 8)) stage_issue<SU>(P, tree, valid, packed, pre);
+        if constexpr (MF) {
+            // the wave's two leaves into the workgroup's k-major input tile (column 2 wave + t), then all 16 together
+            const bool live[2] = {__builtin_amdgcn_readlane((int)valid, 0) != 0, __builtin_amdgcn_readlane((int)valid, 1) != 0};
+            bool dyn[2];
+            float *dh[2], *dp[2] = {outs, outs + slot};
+            float reward[2], value[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int parent = __builtin_amdgcn_readlane(L.parent_id, t), act = __builtin_amdgcn_readlane(L.action, t);
+                const int leaf = __builtin_amdgcn_readlane(L.leaf_id, t), b = __builtin_amdgcn_readlane(L.branch, t);
+                const int row = live[t] ? tree0 + t : 0;
+                const float *src = P.hidden + ((size_t)row * P.N + parent) * P.hs;
+                if (lane < K4in)
+                    mf[smz_mlp::kMfXk + lane * smz_mlp::kMfLeaves + 2 * wave + t] =
+                        !live[t] ? 0.f : (lane < S ? src[lane] : ((lane < S + A && (lane - S) == act) ? 1.f : 0.f));
+                if (lane == 0) reinterpret_cast<int *>(mf + smz_mlp::kMfBr)[2 * wave + t] = b;
+                dyn[t] = b != 0;
+                dh[t] = P.hidden + ((size_t)row * P.N + leaf) * P.hs;
+            }
+            unsigned long long t_wait = 0;
+            smz_mlp::heads16_mfma<MAXA>(mfw, mf, wave, lane, dyn, live, dh, dp, reward, value, (INSTR && prof) ? &t_wait : nullptr, INSTR ? (dbg >> 8) : 0);
+            if (INSTR && prof) { t_stage += t_wait; t0 += t_wait; }      // (stamps: the `stage` slot carries the barrier wait)
+            if (lane == 0) {
+                outs[A] = value[0]; outs[A + 1] = reward[0];
+                outs[slot + A] = value[1]; outs[slot + A + 1] = reward[1];
+            }
+        }
         // all rows' network inputs first (independent global loads, one latency), then the rows one after another
-        for (int t = 0; t < tpw; t++) {
+        for (int t = 0; t < tpw && !MF; t++) {
             const int row = tree0 + t;
             if (row >= P.B) break;                               // wave-uniform
             const int parent = __builtin_amdgcn_readlane(L.parent_id, t), act = __builtin_amdgcn_readlane(L.action, t);
@@ -598,8 +637,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
                 xall[t * K4in + k] = (k < S) ? src[k] : ((k < S + A && (k - S) == act) ? 1.f : 0.f);
         }
         smz_mlp::lds_sync();
-        bool paired = false;
-        if (tpw == 2 && !(dbg & 1)) {
+        bool paired = MF;
+        if (tpw == 2 && !(dbg & 1) && !MF) {
             // the wave's two leaves need the same pair of networks: one pass, weights read from LDS once for both rows
             const int b0 = __builtin_amdgcn_readlane(L.branch, 0), b1 = __builtin_amdgcn_readlane(L.branch, 1);
             if (tree0 + 1 < P.B) {
@@ -1505,8 +1544,13 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     while (tpw < kFastTpw && (size_t)256 * kWaves * tpw < (size_t)P.B) tpw <<= 1;
     if (const char *e = getenv("SMZ_SEARCH_TPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) tpw = v; }
     P.tpw = tpw;
-    const MegaLds ml = mega_lds(*desc, P, tpw);
-    const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave) * sizeof(float);
+    const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL;
+    // matrix-core evaluation of the workgroup's 16 leaves (k_search_mlp<..., MF>): the specialised geometry with two
+    // children per expansion and 8 waves; SMZ_SEARCH_MFMA=0 keeps the vector evaluation (A/B runs)
+    bool mf = fast && kWaves == 8 && h->K == 2 && h->maxa <= 4 && (!(P.stats || P.dbg) || ((P.dbg & 64) && h->maxa == 2));
+    if (const char *e = getenv("SMZ_SEARCH_MFMA")) mf = mf && atoi(e) != 0;
+    const MegaLds ml = mega_lds(*desc, P, tpw, mf);
+    const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave + (mf ? smz_mlp::kMfFloats : 0)) * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_TOO_LARGE, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
 #define SMZ_LAUNCH_SEARCH(UU, INSTR, AEX)                                                                              \
@@ -1524,8 +1568,30 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     })
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
-    const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL;
 #if SMZ_PART != 4
+    if (mf) {
+#define SMZ_LAUNCH_MF(MA)                                                                                               \
+        {                                                                                                               \
+            static size_t granted_dev[64] = {};                                                                        \
+            size_t &granted = granted_dev[h->cfg.device & 63];                                                         \
+            if (lds > granted) {                                                                                       \
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, 2, 1, false, true, true>),     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
+                    return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                        \
+                granted = lds;                                                                                         \
+            }                                                                                                          \
+            hipLaunchKernelGGL((k_search_mlp<MA, 2, 1, false, true, true>), dim3(blocks), dim3(kWaves * kWave), lds,   \
+                               (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act);                       \
+        }
+        if (P.dbg & 64) {      // phase stamps of the matrix-core kernel (SMZ_DEBUG_SKIP=80 with level statistics on)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<2, 2, 1, true, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_search_mlp<2, 2, 1, true, true, true>), dim3(blocks), dim3(kWaves * kWave), lds,
+                               (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act);
+        } else
+        if (h->maxa == 2) SMZ_LAUNCH_MF(2) else SMZ_LAUNCH_MF(4)
+#undef SMZ_LAUNCH_MF
+    } else
     if ((P.stats || P.dbg) && fast && (P.dbg & 32) && h->maxa == 2 && h->K == 2) {
         // phase stamps of the specialised instantiation itself (SMZ_DEBUG_SKIP=48), for the headline geometry only
         constexpr int MA = 2, KS = 2;
