@@ -181,6 +181,9 @@ def main():
                     help="independent env groups per GPU, each on its own HIP stream")
     ap.add_argument("--min-timed-seconds", type=float, default=0.5, help="repeat the K-step block until this much is timed")
     ap.add_argument("--max-blocks", type=int, default=200)
+    ap.add_argument("--rng", default="mt19937", choices=["mt19937", "philox"],
+                    help="mt19937: per-tree numpy-legacy streams (parity mode, the headline); philox: counter-based "
+                         "streams (throughput mode: same distributions, different numbers) -- reported as its own workload")
     ap.add_argument("--host-env", action="store_true",
                     help="cartpole workloads: step the envs on the HOST (envs.HostVecEnv over numpy CartPoles): the "
                          "PCIe-inclusive rate of the boundary's host-buffer variant")
@@ -251,7 +254,8 @@ def main():
             env = envs_mod.SyntheticVec(Bg, wl["obs"], wl["A"], dev, seed=0, first_env=glo, total_envs=total)
         m = mcts_mod.BatchedMCTS(Bg, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
                                  root_dirichlet_alpha=0.25, root_exploration_fraction=0.1, device=local_rank,
-                                 use_graph=not args.no_graph, fused=True, single_launch=not args.stepwise)
+                                 use_graph=not args.no_graph, fused=True, single_launch=not args.stepwise,
+                                 rng_mode=smz._lib.RNG_PHILOX if args.rng == "philox" else smz._lib.RNG_MT19937_NUMPY)
         m.seed(np.arange(glo, glo + Bg, dtype=np.uint64))
         env.reset()
         groups.append(sp.StreamGroup(env, model.heads(dev, instance=gi, backend=args.heads), m, T))
@@ -308,7 +312,7 @@ def main():
         dist.all_gather_object(rates, mine)
         per_rank_rate = [float(r) for r in rates]
     sims_total = total * wl["sims"] * args.steps
-    headline = args.workload == "cartpole_mlp_4096x50" and B == 4096 and not args.host_env
+    headline = args.workload == "cartpole_mlp_4096x50" and B == 4096 and not args.host_env and args.rng == "mt19937"
     single = getattr(mcts, "_single", None) is True
     data_note = {"cartpole": "synthetic (CartPole-shaped Euler env, fixed-length episodes; checkpoint-421 weights)",
                  "synthetic": "synthetic (N(0,1) observations of LunarLander width generated on the device; random-init weights, reference init rule)",
@@ -316,7 +320,8 @@ def main():
     config = {"workload": args.workload, "envs_per_gpu": B, "num_simulations": wl["sims"],
               "actions": wl["A"], "children_per_expansion": wl["K"],
               "hidden_floats": int(groups[0].heads.S) if hasattr(groups[0].heads, "S") else model.state_dimension,
-              "rng": "per-tree MT19937 (numpy-legacy, parity mode)",
+              "rng": "per-tree MT19937 (numpy-legacy, parity mode)" if args.rng == "mt19937" else
+                     "per-tree Philox4x32-10 (throughput mode: the numpy-legacy algorithms on counter-based words; NOT the reference's draws)",
               "search": "one launch per env step (smz_search_mlp_act)" if single else
                         ("step-wise kernels" + ("" if args.no_graph else ", one HIP graph per env step")),
               "stream_groups": G, "heads": type(groups[0].heads).__name__,
@@ -327,7 +332,8 @@ def main():
         config["ranks"] = world
         config["gpus_visible"] = n_dev
     out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs x 50 sims" if headline else
-                     f"MCTS simulations/sec (whole node), {args.workload} at {B} envs/GPU" + (" (host-resident envs)" if args.host_env else ""),
+                     f"MCTS simulations/sec (whole node), {args.workload} at {B} envs/GPU" + (" (host-resident envs)" if args.host_env else "")
+                     + (" (Philox throughput-mode random streams)" if args.rng == "philox" else ""),
            "value": sims_total / dt, "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32 (tree values, heads) + f64 (pUCT scores, root priors) + i32 (counts)",

@@ -46,7 +46,11 @@ typedef enum {
 
 typedef enum {
     SMZ_RNG_MT19937_NUMPY = 0, /* per-tree numpy-legacy RandomState stream: bit-parity with the reference */
-    SMZ_RNG_PHILOX = 1         /* counter-based stream (throughput mode; same distributions, different numbers) */
+    SMZ_RNG_PHILOX = 1         /* counter-based stream (throughput mode): the SAME numpy-legacy algorithms (random_sample,
+                                  choice, dirichlet ...) drawing their 32-bit words from Philox4x32-10 keyed by the tree's
+                                  64-bit seed instead of from MT19937 -- same distributions, different numbers, no
+                                  generator state in memory.  Word i of the stream = component i & 3 of
+                                  philox(counter = i / 4, key = seed); smz_philox_words evaluates it on the host. */
 } smz_rng_mode;
 
 typedef void *smz_stream; /* hipStream_t */
@@ -103,6 +107,11 @@ int smz_seed(smz_handle *h, const uint64_t *host_seeds, smz_stream stream);
  * "regenerate before the next draw").  Lets a single-tree caller continue the process-global numpy stream. */
 int smz_set_rng_state(smz_handle *h, int tree, const uint32_t *host_key, int pos);
 int smz_get_rng_state(smz_handle *h, int tree, uint32_t *host_key, int *pos);
+
+/* SMZ_RNG_PHILOX: host evaluation of n consecutive words of the stream keyed by `seed`, starting at word `idx` (< 624) of
+ * 624-word block `block`, and the position (block, idx) a tree of a Philox handle has reached [sync]. */
+int smz_philox_words(uint64_t seed, uint32_t block, int idx, int n, uint32_t *host_out);
+int smz_get_philox_position(smz_handle *h, int tree, uint32_t *block_out, int *idx_out);
 
 /* Asynchronous device-side snapshot / restore of ALL trees' streams (one backup slot per handle).  Lets a caller
  * run throw-away warm-up searches (e.g. before capturing a HIP graph) without disturbing the per-tree streams. */

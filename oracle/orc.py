@@ -46,6 +46,9 @@ def lib():
         L.orc_tree_new.argtypes = [C.POINTER(Cfg), C.c_void_p]
         L.orc_tree_free.argtypes = [C.c_void_p]
         L.orc_tree_seed.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_tree_seed_philox.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_tree_philox_position.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_philox_block.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_tree_set_rng.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.orc_tree_get_rng.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_tree_random_sample.restype = C.c_double
@@ -140,6 +143,15 @@ class Tree:
 
     def seed(self, s):
         self.L.orc_tree_seed(self.h, int(s) & 0xFFFFFFFF)
+
+    def seed_philox(self, s):
+        """The engine's throughput mode (SMZ_RNG_PHILOX): words from Philox4x32-10 keyed by the 64-bit seed."""
+        self.L.orc_tree_seed_philox(self.h, int(s) & 0xFFFFFFFFFFFFFFFF)
+
+    def philox_position(self):
+        b, p = C.c_uint32(), C.c_int32()
+        self.L.orc_tree_philox_position(self.h, C.byref(b), C.byref(p))
+        return b.value, p.value
 
     def set_rng(self, key, pos):
         key = np.ascontiguousarray(key, dtype=np.uint32)

@@ -63,6 +63,8 @@ SIGNATURES = {
     "smz_seed": (C.c_int, [_P, _P, _P]),
     "smz_set_rng_state": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "smz_get_rng_state": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int)]),
+    "smz_philox_words": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int, C.c_int, _P]),
+    "smz_get_philox_position": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "smz_rng_snapshot": (C.c_int, [_P, _P]),
     "smz_rng_restore": (C.c_int, [_P, _P]),
     "smz_root_init": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
@@ -111,7 +113,12 @@ def load():
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the search engine.")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+            try:
+                fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+            except AttributeError:
+                if os.environ.get("SMZ_LIB_PATH"):      # an older build loaded on purpose for an A/B run (tools/ab_lib.sh)
+                    continue
+                raise
             fn.restype, fn.argtypes = res, args
         if lib.smz_abi_version() != 1:
             raise RuntimeError("libsmz.so ABI version mismatch")

@@ -58,6 +58,10 @@ struct Params {
     const double *pow_table;  // [sims+1] or nullptr
     unsigned long long *stats;  // [4] or nullptr
     const uint8_t *active;      // [B] or nullptr: trees with active[i] == 0 are skipped by every entry point (smz_set_active)
+    int32_t philox;             // SMZ_RNG_PHILOX: words come from Philox4x32-10 (key = the tree's seed) instead of MT19937
+    uint32_t *rng_block;        // [B]  (philox) 624-word blocks consumed so far: word (block, idx) of a tree is component
+                                //      idx & 3 of philox(counter = block * 156 + idx / 4, key); rng_pos keeps idx
+    const uint32_t *rng_key;    // [B][2] (philox)
 };
 __device__ inline bool tree_active(const Params &P, int tree) { return !P.active || P.active[tree] != 0; }
 
@@ -90,22 +94,87 @@ __device__ inline uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {
     return c ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
 }
 
-struct Rng {
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter (c0, c1, 0, 0), key (k0, k1).
+// (Scalars in, four scalars out: small local arrays indexed at run time end up in scratch memory on this compiler.)
+struct PhiloxOut { uint32_t x, y, z, w; };
+__device__ __host__ inline PhiloxOut philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1) {
+    uint32_t c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return PhiloxOut{c0, c1, c2, c3};
+}
+// word `idx` of 624-word block `block` of the stream with key (k0, k1)
+__device__ __host__ inline uint32_t philox_word(uint32_t block, int idx, uint32_t k0, uint32_t k1) {
+    const uint64_t n = (uint64_t)block * (kMtN / 4) + (uint64_t)(idx >> 2);
+    const PhiloxOut o = philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), k0, k1);
+    const int c = idx & 3;
+    return c == 0 ? o.x : (c == 1 ? o.y : (c == 2 ? o.z : o.w));
+}
+
+// the same word for the rare draw beyond the staged words: rounds in a rolled loop (this body is inlined at every draw
+// site of the philox-capable kernels)
+__device__ inline uint32_t philox_word_compact(uint32_t block, int idx, uint32_t k0, uint32_t k1) {
+    const uint64_t n = (uint64_t)block * (kMtN / 4) + (uint64_t)(idx >> 2);
+    uint32_t c0 = (uint32_t)n, c1 = (uint32_t)(n >> 32), c2 = 0u, c3 = 0u;
+#pragma unroll 1
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const int c = idx & 3;
+    return c == 0 ? c0 : (c == 1 ? c1 : (c == 2 ? c2 : c3));
+}
+
+// PHC ("philox capable"): RngT<true> can draw from either generator (a run-time flag per handle); RngT<false> is the
+// MT19937-only form with no extra state -- what the specialised (AEX) kernels of the parity-mode headline path
+// instantiate, so that the second generator costs them nothing (a Philox handle runs the generic instantiations).
+template <bool PHC> struct PhiloxState { uint32_t block, k0, k1; bool on; };
+template <> struct PhiloxState<false> {};
+
+template <bool PHC>
+struct RngT {
     uint32_t *mt;           // this tree's 624 words in global memory
     const uint32_t *stage;  // this lane's staged (tempered) words in LDS, or nullptr
     int idx, ready, used, staged;
+    PhiloxState<PHC> ph;    // (PHC) blocks consumed, key, generator switch
+    __device__ bool philox() const { if constexpr (PHC) return ph.on; else return false; }
+    __device__ uint32_t block() const { if constexpr (PHC) return ph.block; else return 0u; }
+    __device__ void wrapped() { if constexpr (PHC) ++ph.block; }
     __device__ void load(uint32_t *state, int packed, const uint32_t *lds_row, int n_staged) {
         mt = state; idx = packed & 0xffff; ready = packed >> 16; stage = lds_row; staged = n_staged; used = 0;
+        if (philox()) { staged = n_staged - (idx & 3); if (staged < 0) staged = 0; }   // philox tiles start on a 4-word boundary
     }
+    // per-kernel set-up, before the first load(): which generator, and (philox) this tree's key and block counter
+    __device__ void bind(const Params &P, int tree, bool valid) {
+        if constexpr (PHC) {
+            ph.on = P.philox != 0; ph.block = 0u; ph.k0 = ph.k1 = 0u;
+            if (ph.on && valid) { ph.block = P.rng_block[tree]; ph.k0 = P.rng_key[2 * tree]; ph.k1 = P.rng_key[2 * tree + 1]; }
+        }
+    }
+    __device__ void save(const Params &P, int tree) const { if constexpr (PHC) { if (ph.on) P.rng_block[tree] = ph.block; } }
     __device__ int pack() const { return (ready << 16) | idx; }
     __device__ uint32_t next32() {
         if (__builtin_expect(used < staged, 1)) {   // fast path: word was twisted and tempered by the staging pass
             const uint32_t y = stage[used++];
             --ready;
-            idx = (idx + 1 == kMtN) ? 0 : idx + 1;
+            if (idx + 1 == kMtN) { idx = 0; wrapped(); } else ++idx;
             return y;
         }
         const int i = idx;
+        if constexpr (PHC) {
+            if (ph.on) {
+                const uint32_t y = philox_word_compact(ph.block, i, ph.k0, ph.k1);
+                if (i + 1 == kMtN) { idx = 0; ++ph.block; } else idx = i + 1;
+                return y;
+            }
+        }
         uint32_t y;
         if (ready > 0) {
             y = mt[i];
@@ -129,7 +198,7 @@ struct Rng {
             used += N;
             ready -= N;
             idx += N;
-            if (idx >= kMtN) idx -= kMtN;
+            if (idx >= kMtN) { idx -= kMtN; wrapped(); }
         } else {
 #pragma unroll
             for (int i = 0; i < N; i++) out[i] = next32();
@@ -147,6 +216,8 @@ struct Rng {
         return to_double(w[0], w[1]);
     }
 };
+using Rng = RngT<true>;      // the general form (step-wise root / act kernels, generic instantiations)
+using RngMt = RngT<false>;   // MT19937 only (specialised instantiations)
 
 // ndarray.sum() of n <= 128 contiguous elements: sequential below 8, else numpy's 8-lane unrolled pairwise block.
 template <typename T, int MAXA>
@@ -199,8 +270,8 @@ __device__ inline void reg_set(T (&a)[N], int i, T v) {
 }
 
 // RandomState.choice(n, size, p=p, replace=False) -- picks in draw order.  `p` is clobbered.
-template <int MAXA>
-__device__ inline void choice_noreplace(Rng &rng, double (&p)[MAXA], int n, int size, int32_t (&out)[MAXA]) {
+template <int MAXA, class RNG>
+__device__ inline void choice_noreplace(RNG &rng, double (&p)[MAXA], int n, int size, int32_t (&out)[MAXA]) {
     constexpr bool REG = MAXA <= 8;     // small arrays: select chains; larger ones: plain indexing
     double cdf[MAXA], x[MAXA];
     int32_t cand[MAXA];
@@ -211,7 +282,7 @@ __device__ inline void choice_noreplace(Rng &rng, double (&p)[MAXA], int n, int 
             uint32_t w[MAXA <= 4 ? 2 * MAXA : 2];
             rng.template take<MAXA <= 4 ? 2 * MAXA : 2>(w);
 #pragma unroll
-            for (int i = 0; i < MAXA; i++) x[i] = Rng::to_double(w[MAXA <= 4 ? 2 * i : 0], w[MAXA <= 4 ? 2 * i + 1 : 1]);
+            for (int i = 0; i < MAXA; i++) x[i] = RNG::to_double(w[MAXA <= 4 ? 2 * i : 0], w[MAXA <= 4 ? 2 * i + 1 : 1]);
         } else {
 #pragma unroll
             for (int i = 0; i < MAXA; i++) if (i < m) x[i] = rng.random_sample();
@@ -280,7 +351,8 @@ __device__ inline void sort_picks(int32_t (&v)[MAXA], int size) {
 
 // legacy_standard_gamma for shape <= 1 (numpy/random/src/legacy/legacy-distributions.c); log/pow are the device
 // library's (correct to < 1 ulp, not guaranteed bit-identical to glibc's -- see DESIGN.md "Dirichlet noise").
-__device__ inline double legacy_gamma(Rng &rng, double shape) {
+template <class RNG>
+__device__ inline double legacy_gamma(RNG &rng, double shape) {
     if (shape == 1.0) return -log(1.0 - rng.random_sample());
     if (shape == 0.0) return 0.0;
     for (;;) {
@@ -312,8 +384,8 @@ __device__ inline int depth_flag(int depth) { return (depth >> 1) & 1; }  // F F
 // ---------------------------------------------------------------------------------------------------------------
 // root (monte_carlo_tree_search.py:179-225)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAXA>
-__device__ inline void root_init_tree(const Params &P, int tree, Rng &rng, const float *policy_row,
+template <int MAXA, class RNG>
+__device__ inline void root_init_tree(const Params &P, int tree, RNG &rng, const float *policy_row,
                                       const double *noise_override_row, bool train) {
     const int A = P.A;
     uint32_t *rb = tree_base(P, tree);
@@ -420,8 +492,8 @@ __device__ inline void load_kids_static(const uint32_t *bp, Kids<N> &k) {
 }
 
 // chance-flagged node: sample an outcome from the smoothed priors (mcts:247-255)
-template <int N>
-__device__ inline int pick_chance(const Kids<N> &k, int cnt, Rng &rng) {
+template <int N, class RNG>
+__device__ inline int pick_chance(const Kids<N> &k, int cnt, RNG &rng) {
     float tmp[N];
     double q64[N];
 #pragma unroll
@@ -467,9 +539,9 @@ __device__ inline double puct_score(const Kids<N> &k, int j, double sp, bool nor
     const double jitter = 1e-7 + (2e-7 - 1e-7) * u;
     return (prior_score + value_score) + jitter;
 }
-template <int N>
+template <int N, class RNG>
 __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool norm, float mn, float span, float disc32,
-                                    Rng &rng, const double *r64 = nullptr) {
+                                    RNG &rng, const double *r64 = nullptr) {
     double best = 0.0;
     int pick = 0;
     // the jitter words of all children at once when the child count is the (small) compile-time N: one staged-words
@@ -481,7 +553,7 @@ __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool n
 #pragma unroll
     for (int j = 0; j < N; j++) {
         if (j < cnt) {
-            const double u = batched ? Rng::to_double(jw[kBatch ? 2 * j : 0], jw[kBatch ? 2 * j + 1 : 1]) : rng.random_sample();
+            const double u = batched ? RNG::to_double(jw[kBatch ? 2 * j : 0], jw[kBatch ? 2 * j + 1 : 1]) : rng.random_sample();
             const double score = puct_score<N>(k, j, sp, norm, mn, span, disc32, u, r64);
             if (j == 0 || score >= best) { best = score; pick = j; }  // exact tie -> larger action
         }
@@ -498,8 +570,9 @@ __device__ inline double quad_partner(double v) {          // value held by lane
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+template <class RNG>
 __device__ inline int pick_decision_pair(const Kids<2> &k, int me, double sp, bool norm, float mn, float span,
-                                         float disc32, Rng &rng, const double *r64) {
+                                         float disc32, RNG &rng, const double *r64) {
     uint32_t jw[4];
     rng.template take<4>(jw);
     Kids<2> mine;                 // slot 0 = this lane's child
@@ -507,7 +580,7 @@ __device__ inline int pick_decision_pair(const Kids<2> &k, int me, double sp, bo
     mine.vsum[0] = me ? k.vsum[1] : k.vsum[0];
     mine.rew[0] = me ? k.rew[1] : k.rew[0];
     mine.pri64[0] = me ? k.pri64[1] : k.pri64[0];
-    const double u = Rng::to_double(me ? jw[2] : jw[0], me ? jw[3] : jw[1]);
+    const double u = RNG::to_double(me ? jw[2] : jw[0], me ? jw[3] : jw[1]);
     const double s_me = puct_score<2>(mine, 0, sp, norm, mn, span, disc32, u, r64);
     const double s_other = quad_partner(s_me);
     const double s0 = me ? s_other : s_me, s1 = me ? s_me : s_other;
@@ -517,8 +590,8 @@ __device__ inline int pick_decision_pair(const Kids<2> &k, int me, double sp, bo
 // LUT: the reciprocal table of div_by_count follows the pb_c table (pbc_sqrt[sims + 2 + n] = 1 / n)
 // PAIR (MAXA == 2, KS == 2, A == 2): two lanes per tree, see pick_decision_pair; `me` = 0 for the tree's lane (which
 // alone writes the path records), 1 for its helper.  Chance levels are evaluated redundantly by both lanes.
-template <int MAXA, int KS, bool STATS = true, bool LUT = false, bool PAIR = false>
-__device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const TreeHdr &h, const double *pbc_sqrt,
+template <int MAXA, int KS, bool STATS = true, bool LUT = false, bool PAIR = false, class RNG = Rng>
+__device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const TreeHdr &h, const double *pbc_sqrt,
                                    int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children,
                                    uint4 *rec, int me = 0) {
     constexpr int NK = KS > 0 ? KS : MAXA;     // register arrays of the expansion levels
@@ -586,8 +659,8 @@ __device__ inline Leaf select_tree(const Params &P, int tree, Rng &rng, const Tr
 // ---------------------------------------------------------------------------------------------------------------
 // EXPAND_ONLY: stop after the expansion and return the leaf reward through *leaf_reward_out -- the caller runs the
 // backup with backup_levels_lanes (several lanes per tree).
-template <int MAXA, int KS, bool EXPAND_ONLY = false>
-__device__ inline int expand_backup_tree(const Params &P, int tree, Rng &rng, TreeHdr &h, const float *policy_row,
+template <int MAXA, int KS, bool EXPAND_ONLY = false, class RNG = Rng>
+__device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, TreeHdr &h, const float *policy_row,
                                          float reward, float value, const uint4 *rec, float *leaf_reward_out = nullptr) {
     constexpr int CH = 8;   // path records fetched per round trip
     const int A = P.A, K = P.K;
@@ -732,8 +805,8 @@ __device__ inline void backup_levels_lanes(const Params &P, int tree, int j, int
 // ---------------------------------------------------------------------------------------------------------------
 // post-search policy / action (game.py:179-232)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAXA>
-__device__ inline void act_tree(const Params &P, int tree, Rng &rng, double temperature, int32_t *action_out,
+template <int MAXA, class RNG>
+__device__ inline void act_tree(const Params &P, int tree, RNG &rng, double temperature, int32_t *action_out,
                                 double *policy_out, double *child_visits_out, float *root_value_out) {
     const int A = P.A;
     const uint32_t *rb = tree_base(P, tree);

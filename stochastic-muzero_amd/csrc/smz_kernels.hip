@@ -64,6 +64,13 @@ __host__ __device__ inline RowGeom row_geom(int width) {
 __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
     if (tree >= P.B) return;
+    if (P.philox) {          // counter-based stream: the seed is the key, nothing else to initialise
+        const_cast<uint32_t *>(P.rng_key)[2 * tree] = (uint32_t)(seeds[tree] & 0xffffffffull);
+        const_cast<uint32_t *>(P.rng_key)[2 * tree + 1] = (uint32_t)(seeds[tree] >> 32);
+        P.rng_block[tree] = 0u;
+        P.rng_pos[tree] = 0;
+        return;
+    }
     uint32_t s = (uint32_t)(seeds[tree] & 0xffffffffull);
     uint32_t *mt = P.mt + (size_t)tree * kMtN;
     for (int i = 0; i < kMtN; i++) {
@@ -80,10 +87,46 @@ __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds)
 // sources of word p are p, p+1 and p+397 and at most 64 consecutive words change) -- and the tempered words go to
 // this wave's LDS tile [tree lane][word].  Global traffic is coalesced 256-byte segments.  Returns the lane's
 // packed (ready << 16 | idx) after staging.
-template <int U = 8>   // U trees in flight: their loads are all issued before the first dependent store
-__device__ inline int wave_stage_rng_from(const Params &P, int tree, bool valid, uint32_t *lds_tile, int packed) {
+// Philox mode: the next words of the wave's trees are computed, not loaded -- lanes 0..15 of tree slot t evaluate the 16
+// counter blocks that cover words [idx & ~3, (idx & ~3) + 64) of its stream and write those at or after idx to the tile
+// row (Rng::load knows the row then holds 64 - (idx & 3) words).  `block`: each lane's own tree's block counter.
+__device__ inline void philox_stage(const Params &P, int tree, bool valid, uint32_t *lds_tile, int packed, uint32_t block, int ntrees) {
+    if (!lds_tile) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int tree0 = tree - lane;
+    for (int t0 = 0; t0 < ntrees; t0 += 4) {                      // four trees per pass: 16 lanes each
+        const int t = t0 + (lane >> 4), j = lane & 15;
+        const int src = t < ntrees ? t : 0;
+        const int pk = __shfl(packed, src);
+        const uint32_t kb = (uint32_t)__shfl((int)block, src);
+        const bool vt = t < ntrees && __shfl((int)valid, src) != 0;
+        if (vt) {
+            const int idx = pk & 0xffff;
+            int q = (idx >> 2) + j;
+            uint32_t b = kb;
+            if (q >= kMtN / 4) { q -= kMtN / 4; ++b; }
+            const uint64_t n = (uint64_t)b * (kMtN / 4) + (uint64_t)q;
+            const PhiloxOut o = philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), P.rng_key[2 * (tree0 + t)], P.rng_key[2 * (tree0 + t) + 1]);
+            const int pos = 4 * j - (idx & 3);
+            uint32_t *row = lds_tile + t * kRngStride;
+            if (pos >= 0) row[pos] = o.x;
+            if (pos + 1 >= 0) row[pos + 1] = o.y;
+            if (pos + 2 >= 0) row[pos + 2] = o.z;
+            row[pos + 3] = o.w;
+        }
+    }
+}
+
+template <int U = 8, bool PHC = true>   // U trees in flight: their loads are all issued before the first dependent store
+__device__ inline int wave_stage_rng_from(const Params &P, int tree, bool valid, uint32_t *lds_tile, int packed, uint32_t block = 0u) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tree0 = tree - lane;
+    if constexpr (PHC) {
+        if (P.philox) {
+            philox_stage(P, tree, valid, lds_tile, packed, block, P.tpw);
+            return ((kRngStage) << 16) | (packed & 0xffff);
+        }
+    }
     for (int t0 = 0; t0 < P.tpw; t0 += U) {
         uint32_t w[U], b[U], c[U];
         int pos[U];
@@ -121,8 +164,10 @@ __device__ inline int wave_stage_rng_from(const Params &P, int tree, bool valid,
     return ((ready > kRngStage ? ready : kRngStage) << 16) | idx;
 }
 
+template <bool PHC = true>
 __device__ inline int wave_stage_rng(const Params &P, int tree, bool valid, uint32_t *lds_tile) {
-    return wave_stage_rng_from<8>(P, tree, valid, lds_tile, valid ? P.rng_pos[tree] : 0);
+    return wave_stage_rng_from<8, PHC>(P, tree, valid, lds_tile, valid ? P.rng_pos[tree] : 0,
+                                       (PHC && P.philox && valid) ? P.rng_block[tree] : 0u);
 }
 
 // The same staging split in two for waves that own at most U trees: stage_issue requests the source words (the loads
@@ -132,10 +177,11 @@ template <int U>
 struct StagePre {
     uint32_t w[U], b[U], c[U];
 };
-template <int U>
+template <int U, bool PHC = true>
 __device__ inline void stage_issue(const Params &P, int tree, bool valid, int packed, StagePre<U> &pre) {
     const int lane = threadIdx.x & (kWave - 1);
     const int tree0 = tree - lane;
+    if (PHC && P.philox) return;                            // nothing to load: stage_finish computes the words
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int pk = __shfl(packed, u);
@@ -155,10 +201,17 @@ __device__ inline void stage_issue(const Params &P, int tree, bool valid, int pa
         }
     }
 }
-template <int U>
-__device__ inline int stage_finish(const Params &P, int tree, bool valid, uint32_t *lds_tile, int packed, const StagePre<U> &pre) {
+template <int U, bool PHC = true>
+__device__ inline int stage_finish(const Params &P, int tree, bool valid, uint32_t *lds_tile, int packed, const StagePre<U> &pre,
+                                   uint32_t block = 0u) {
     const int lane = threadIdx.x & (kWave - 1);
     const int tree0 = tree - lane;
+    if constexpr (PHC) {
+        if (P.philox) {
+            philox_stage(P, tree, valid, lds_tile, packed, block, P.tpw < U ? P.tpw : U);
+            return ((kRngStage) << 16) | (packed & 0xffff);
+        }
+    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int pk = __shfl(packed, u);
@@ -296,10 +349,12 @@ __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidd
     const int packed = wave_stage_rng(P, tree, valid, rng_tile);
     if (valid) {
         Rng rng;
+        rng.bind(P, tree, valid);
         rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + threadIdx.x * kRngStride, n_staged);
         root_init_tree<MAXA>(P, tree, rng, policy + (size_t)tree * P.A,
                              noise_override ? noise_override + (size_t)tree * P.A : nullptr, train != 0);
         P.rng_pos[tree] = rng.pack();
+        rng.save(P, tree);
     }
     if (P.S > 0 && hidden) {
         const int t = valid ? tree : 0;
@@ -308,14 +363,14 @@ __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidd
 }
 #endif
 
-template <int MAXA, int KS>
-__device__ inline void select_phase(const Params &P, int tree, bool valid, Rng &rng, TreeHdr &h, const double *pbc_lds,
+template <int MAXA, int KS, class RNG>
+__device__ inline void select_phase(const Params &P, int tree, bool valid, RNG &rng, TreeHdr &h, const double *pbc_lds,
                                     float *parent_hidden, int32_t *last_action, uint8_t *branch, float *mlp_input) {
     Leaf L = {0, 0, 0, 0};
     unsigned n_dec = 0, n_chance = 0, n_children = 0;
     if (valid) {
         int len = 0;
-        L = select_tree<MAXA, KS>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, P.path + (size_t)tree * P.P);
+        L = select_tree<MAXA, KS, true, false, false>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, P.path + (size_t)tree * P.P);
         h.path_len = len;
         if (last_action) last_action[tree] = L.action;
         if (branch) branch[tree] = (uint8_t)L.branch;
@@ -346,8 +401,9 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
     const bool valid = (int)threadIdx.x < P.tpw && tree < P.B && tree_active(P, tree);
     const double *pbc_lds = stage_pbc(P);
-    const int packed = wave_stage_rng(P, tree, valid, rng_tile);
-    Rng rng;
+    const int packed = wave_stage_rng<!AEX>(P, tree, valid, rng_tile);
+    RngT<!AEX> rng;          // (the specialised instantiations serve MT19937 handles only: see smz_select)
+    rng.bind(P, tree, valid);
     TreeHdr h = {0, 0, 0.f, 0.f, 0, 0.f, 0, 0};
     if (valid) {
         rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + threadIdx.x * kRngStride, n_staged);
@@ -356,6 +412,7 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
     select_phase<MAXA, KS>(P, tree, valid, rng, h, pbc_lds, parent_hidden, last_action, branch, mlp_input);
     if (valid) {
         P.rng_pos[tree] = rng.pack();
+        rng.save(P, tree);
         P.hdr[tree] = h;
     }
 }
@@ -376,8 +433,9 @@ __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const fl
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
     const bool valid = (int)threadIdx.x < P.tpw && tree < P.B && tree_active(P, tree);
     const double *pbc_lds = stage_pbc(P);
-    const int packed = wave_stage_rng(P, tree, valid, rng_tile);
-    Rng rng;
+    const int packed = wave_stage_rng<!AEX>(P, tree, valid, rng_tile);
+    RngT<!AEX> rng;
+    rng.bind(P, tree, valid);
     TreeHdr h = {0, 0, 0.f, 0.f, 0, 0.f, 0, 0};
     int leaf = 0;
     if (valid) {
@@ -397,6 +455,7 @@ __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const fl
     }
     if (valid) {
         P.rng_pos[tree] = rng.pack();
+        rng.save(P, tree);
         P.hdr[tree] = h;
     }
 }
@@ -418,11 +477,9 @@ struct MegaLds {
     int x_off, pv_off, rng_off, out_off;                   // float offsets inside a wave's region
 };
 __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
-// mf: the matrix-core evaluation (heads16_mfma) keeps its weights in registers: no LDS copy of the networks, one
-// workgroup-wide tile region (smz_mlp::kMfFloats) behind the per-wave regions
-__host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params &P, int tpw, bool mf = false) {
+__host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params &P, int tpw) {
     MegaLds m;
-    m.pbc_off = mf ? 0 : r4(d.total_floats - smz_mlp::rep_floats(d));
+    m.pbc_off = r4(d.total_floats - smz_mlp::rep_floats(d));
     m.wave_off = m.pbc_off + r4(2 * 2 * (P.sims + 2));     // pb_c table + reciprocal table (div_by_count)
     m.x_off = r4(2 * smz_mlp::row_scratch_floats(d));     // two rows' scratch: a same-branch pair is evaluated together
     m.pv_off = m.x_off + tpw * smz_mlp::up4(P.S + P.A);
@@ -449,30 +506,20 @@ struct ActOut {              // smz_search_mlp_act: Game.policy_step folded into
 };
 constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
 #if SMZ_PART == 0 || SMZ_PART == 2 || SMZ_PART == 4
-// MF (only with AEX, 8 waves): the 16 leaves of the workgroup are evaluated together on the matrix cores
-// (smz_mlp::heads16_mfma): five workgroup barriers per round, weights in registers, no LDS copy of the networks.
-template <int MAXA, int KS, int U, bool INSTR, bool AEX, bool MF = false>
+template <int MAXA, int KS, int U, bool INSTR, bool AEX>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train, ActOut act) {
-    static_assert(!MF || (AEX && KS == 2), "the matrix-core evaluation belongs to the specialised instantiation");
     Params P = Pin;
     if (AEX) { P.A = MAXA; P.tpw = kFastTpw; d.A = MAXA; d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = smz_mlp::kWave; P.S = kFastS; }
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);
     if (AEX) P.hs = (kFastS + 15) & ~15;
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
-    const smz_mlp_desc dl = MF ? d : smz_mlp::lds_desc_without_rep(d);      // LDS copy: everything but the representation matrices
-    if (!MF) smz_mlp::stage_weights_without_rep(lds, weights, d);
+    const smz_mlp_desc dl = smz_mlp::lds_desc_without_rep(d);      // LDS copy: everything but the representation matrices
+    smz_mlp::stage_weights_without_rep(lds, weights, d);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, waves = blockDim.x / kWave;
     const int A = P.A, S = P.S, tpw = P.tpw;
-    const MegaLds ml = mega_lds(d, P, tpw, MF);
-    float *mf = lds + ml.wave_off + waves * ml.per_wave;                          // (MF) the workgroup's matrix-core tiles
-    smz_mlp::MfmaWeights mfw;
-    if constexpr (MF) {
-        smz_mlp::mfma_load_weights(weights, d, wave, lane, mfw);
-        for (int i = threadIdx.x; i < smz_mlp::kMfFloats; i += blockDim.x) mf[i] = 0.f;   // zero padding rows stay zero
-    }
-    const float *wsrc = MF ? weights : lds;                                       // where initial_row finds the prediction net
+    const MegaLds ml = mega_lds(d, P, tpw);
     double *pbc_lds = reinterpret_cast<double *>(lds + ml.pbc_off);
     const int n_pbc = P.sims + 2;
     for (int i = threadIdx.x; i < n_pbc; i += blockDim.x) {
@@ -493,18 +540,20 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
     const bool valid = lane < tpw && tree < P.B && tree_active(P, tree);
     // a wave none of whose trees is searched (beyond B, or switched off with smz_set_active) is done: there is no
     // workgroup barrier after the weight staging above
-    if (!MF && __ballot(valid) == 0ull) return;                      // (MF: every wave takes part in the barriers and tiles)
+    if (__ballot(valid) == 0ull) return;
 
     // ---- root: representation + prediction per row, then root expansion per lane ---------------------------------
     for (int t = 0; t < tpw; t++) {
         const int row = tree0 + t;
         if (row >= P.B) break;                                   // wave-uniform
         if (!__shfl((int)valid, t)) continue;                    // wave-uniform: the tree is switched off
-        smz_mlp::initial_row<U>(wsrc, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * P.hs,
+        smz_mlp::initial_row<U>(lds, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * P.hs,
                                 nullptr, outs + t * slot);
     }
-    int packed = wave_stage_rng(P, tree, valid, rng_tile);
-    Rng rng;
+    constexpr bool PHC = !AEX;       // the specialised instantiation serves MT19937 handles only (see the launcher)
+    int packed = wave_stage_rng<PHC>(P, tree, valid, rng_tile);
+    RngT<PHC> rng;
+    rng.bind(P, tree, valid);
     TreeHdr h = {0, 0, 0.f, 0.f, 0, 0.f, 0, 0};
     if (valid) {
         rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
@@ -522,7 +571,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
     // selection (the stream position is final then) and the loads fly during the network evaluation.
     constexpr int SU = 2;
     const bool split = P.tpw <= SU;
-    if (P.sims > 0 && !(dbg & 8)) packed = wave_stage_rng_from<4>(P, tree, valid, rng_tile, packed);
+    if (P.sims > 0 && !(dbg & 8)) packed = wave_stage_rng_from<4, PHC>(P, tree, valid, rng_tile, packed, rng.block());
     for (int s = 0; s < P.sims; s++) {
         if (INSTR && prof) t0 = __builtin_amdgcn_s_memtime();
         Leaf L = {0, 0, 0, 0};
@@ -567,6 +616,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         if constexpr (PAIR) {
             const int src = lane & 1;
             const int pk = __shfl(valid ? rng.pack() : 0, src), us = __shfl(valid ? rng.used : 0, src);
+
             const float hmn = __shfl(h.mn, src), hmx = __shfl(h.mx, src);
             const int hrv = __shfl(h.root_visit, src);
             const bool src_valid = __shfl((int)valid, src) != 0;
@@ -599,36 +649,9 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         // hidden rows written in earlier rounds (by any lane of this wave) may be this round's parent rows
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         StagePre<SU> pre;       // (after the fence: it drains the vector-memory counter)
-        if (split && !(dbg & 8)) stage_issue<SU>(P, tree, valid, packed, pre);
-        if constexpr (MF) {
-            // the wave's two leaves into the workgroup's k-major input tile (column 2 wave + t), then all 16 together
-            const bool live[2] = {__builtin_amdgcn_readlane((int)valid, 0) != 0, __builtin_amdgcn_readlane((int)valid, 1) != 0};
-            bool dyn[2];
-            float *dh[2], *dp[2] = {outs, outs + slot};
-            float reward[2], value[2];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int parent = __builtin_amdgcn_readlane(L.parent_id, t), act = __builtin_amdgcn_readlane(L.action, t);
-                const int leaf = __builtin_amdgcn_readlane(L.leaf_id, t), b = __builtin_amdgcn_readlane(L.branch, t);
-                const int row = live[t] ? tree0 + t : 0;
-                const float *src = P.hidden + ((size_t)row * P.N + parent) * P.hs;
-                if (lane < K4in)
-                    mf[smz_mlp::kMfXk + lane * smz_mlp::kMfLeaves + 2 * wave + t] =
-                        !live[t] ? 0.f : (lane < S ? src[lane] : ((lane < S + A && (lane - S) == act) ? 1.f : 0.f));
-                if (lane == 0) reinterpret_cast<int *>(mf + smz_mlp::kMfBr)[2 * wave + t] = b;
-                dyn[t] = b != 0;
-                dh[t] = P.hidden + ((size_t)row * P.N + leaf) * P.hs;
-            }
-            unsigned long long t_wait = 0;
-            smz_mlp::heads16_mfma<MAXA>(mfw, mf, wave, lane, dyn, live, dh, dp, reward, value, (INSTR && prof) ? &t_wait : nullptr, INSTR ? (dbg >> 8) : 0);
-            if (INSTR && prof) { t_stage += t_wait; t0 += t_wait; }      // (stamps: the `stage` slot carries the barrier wait)
-            if (lane == 0) {
-                outs[A] = value[0]; outs[A + 1] = reward[0];
-                outs[slot + A] = value[1]; outs[slot + A + 1] = reward[1];
-            }
-        }
+        if (split && !(dbg & 8)) stage_issue<SU, PHC>(P, tree, valid, packed, pre);
         // all rows' network inputs first (independent global loads, one latency), then the rows one after another
-        for (int t = 0; t < tpw && !MF; t++) {
+        for (int t = 0; t < tpw; t++) {
             const int row = tree0 + t;
             if (row >= P.B) break;                               // wave-uniform
             const int parent = __builtin_amdgcn_readlane(L.parent_id, t), act = __builtin_amdgcn_readlane(L.action, t);
@@ -637,8 +660,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
                 xall[t * K4in + k] = (k < S) ? src[k] : ((k < S + A && (k - S) == act) ? 1.f : 0.f);
         }
         smz_mlp::lds_sync();
-        bool paired = MF;
-        if (tpw == 2 && !(dbg & 1) && !MF) {
+        bool paired = false;
+        if (tpw == 2 && !(dbg & 1)) {
             // the wave's two leaves need the same pair of networks: one pass, weights read from LDS once for both rows
             const int b0 = __builtin_amdgcn_readlane(L.branch, 0), b1 = __builtin_amdgcn_readlane(L.branch, 1);
             if (tree0 + 1 < P.B) {
@@ -685,8 +708,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         }
         smz_mlp::lds_sync();
         SMZ_STAMP(t_mlp)
-        if (!(dbg & 8)) packed = split ? stage_finish<SU>(P, tree, valid, rng_tile, packed, pre)
-                                       : wave_stage_rng_from<4>(P, tree, valid, rng_tile, packed);
+        if (!(dbg & 8)) packed = split ? stage_finish<SU, PHC>(P, tree, valid, rng_tile, packed, pre, rng.block())
+                                       : wave_stage_rng_from<4, PHC>(P, tree, valid, rng_tile, packed, rng.block());
         SMZ_STAMP(t_stage)
     }
 #undef SMZ_STAMP
@@ -711,6 +734,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
             packed = rng.pack();
         }
         P.rng_pos[tree] = packed;
+        rng.save(P, tree);
     }
     if (INSTR) wave_add_stats(P.stats, n_dec, n_chance, n_desc, n_children);
 }
@@ -742,9 +766,11 @@ __global__ void __launch_bounds__(kWave) k_act(Params P, double temperature, int
     const int tree = blockIdx.x * kWave + threadIdx.x;
     if (tree >= P.B || !tree_active(P, tree)) return;
     Rng rng;
+    rng.bind(P, tree, true);
     rng.load(P.mt + (size_t)tree * kMtN, P.rng_pos[tree], nullptr, 0);
     act_tree<MAXA>(P, tree, rng, temperature, action, policy, child_visits, root_value);
     P.rng_pos[tree] = rng.pack();
+    rng.save(P, tree);
 }
 #endif
 
@@ -1094,6 +1120,7 @@ struct smz_handle {
     bool stats_on;
     uint32_t *d_mt_backup;
     int32_t *d_pos_backup;
+    uint32_t *d_block_backup;
     bool has_backup;
     std::vector<void *> allocs;
 };
@@ -1221,8 +1248,8 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
         return fail(SMZ_ERR_INVALID, "num_actions must be in [1, SMZ_MAX_ACTIONS]%s");
     if (cfg->hidden_size < 0) return fail(SMZ_ERR_INVALID, "hidden_size must be >= 0%s");
     if (cfg->num_simulations > 32000) return fail(SMZ_ERR_INVALID, "num_simulations above 32000 is not supported%s");
-    if (cfg->rng_mode != SMZ_RNG_MT19937_NUMPY)
-        return fail(SMZ_ERR_INVALID, "rng_mode: only SMZ_RNG_MT19937_NUMPY is built%s");
+    if (cfg->rng_mode != SMZ_RNG_MT19937_NUMPY && cfg->rng_mode != SMZ_RNG_PHILOX)
+        return fail(SMZ_ERR_INVALID, "rng_mode must be SMZ_RNG_MT19937_NUMPY or SMZ_RNG_PHILOX%s");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) return fail(SMZ_ERR_INVALID, "device ordinal out of range%s");
@@ -1283,6 +1310,14 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     A_(dev_alloc(h, &h->d_stats, (size_t)8));
     A_(dev_alloc(h, &h->d_mt_backup, (size_t)B * kMtN));
     A_(dev_alloc(h, &h->d_pos_backup, (size_t)B));
+    A_(dev_alloc(h, &h->d_block_backup, (size_t)B));
+    {
+        uint32_t *key = nullptr;
+        A_(dev_alloc(h, &P.rng_block, (size_t)B));
+        A_(dev_alloc(h, &key, (size_t)2 * B));
+        P.rng_key = key;
+    }
+    P.philox = cfg->rng_mode == SMZ_RNG_PHILOX ? 1 : 0;
     h->has_backup = false;
     if (rc != SMZ_OK) { smz_destroy(h); return rc; }
     P.pbc_sqrt = h->d_pbc;
@@ -1294,6 +1329,8 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(P.rng_pos, 0, (size_t)B * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(P.mt, 0, (size_t)B * kMtN * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(P.rng_block, 0, (size_t)B * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(const_cast<uint32_t *>(P.rng_key), 0, (size_t)2 * B * sizeof(uint32_t));
     if (e != hipSuccess) { smz_destroy(h); return fail(SMZ_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e)); }
     std::vector<double> tab((size_t)sims + 2);
     for (int n = 0; n < sims + 2; n++)
@@ -1344,6 +1381,7 @@ int smz_seed(smz_handle *h, const uint64_t *host_seeds, smz_stream stream) {
 int smz_set_rng_state(smz_handle *h, int tree, const uint32_t *host_key, int pos) {
     if (!h || !host_key || tree < 0 || tree >= h->cfg.num_trees || pos < 0 || pos > kMtN)
         return fail(SMZ_ERR_INVALID, "smz_set_rng_state: bad argument%s");
+    if (h->P.philox) return fail(SMZ_ERR_STATE, "smz_set_rng_state: numpy (MT19937) states belong to SMZ_RNG_MT19937_NUMPY handles%s");
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h->P.mt + (size_t)tree * kMtN, host_key, kMtN * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1357,6 +1395,7 @@ int smz_set_rng_state(smz_handle *h, int tree, const uint32_t *host_key, int pos
 int smz_get_rng_state(smz_handle *h, int tree, uint32_t *host_key, int *pos) {
     if (!h || !host_key || !pos || tree < 0 || tree >= h->cfg.num_trees)
         return fail(SMZ_ERR_INVALID, "smz_get_rng_state: bad argument%s");
+    if (h->P.philox) return fail(SMZ_ERR_STATE, "smz_get_rng_state: numpy (MT19937) states belong to SMZ_RNG_MT19937_NUMPY handles%s");
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     int32_t packed = 0;
@@ -1402,6 +1441,7 @@ int smz_rng_snapshot(smz_handle *h, smz_stream stream) {
     const size_t B = (size_t)h->cfg.num_trees;
     HIP_TRY(hipMemcpyAsync(h->d_mt_backup, h->P.mt, B * kMtN * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_TRY(hipMemcpyAsync(h->d_pos_backup, h->P.rng_pos, B * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(h->d_block_backup, h->P.rng_block, B * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     h->has_backup = true;
     return SMZ_OK;
 }
@@ -1413,6 +1453,7 @@ int smz_rng_restore(smz_handle *h, smz_stream stream) {
     const size_t B = (size_t)h->cfg.num_trees;
     HIP_TRY(hipMemcpyAsync(h->P.mt, h->d_mt_backup, B * kMtN * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_TRY(hipMemcpyAsync(h->P.rng_pos, h->d_pos_backup, B * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(h->P.rng_block, h->d_block_backup, B * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SMZ_OK;
 }
 
@@ -1435,7 +1476,7 @@ int smz_select(smz_handle *h, float *parent_hidden_dev, int32_t *last_action_dev
     if (!h) return fail(SMZ_ERR_INVALID, "smz_select: null handle%s");
     if (!h->root_ready) return fail(SMZ_ERR_STATE, "smz_select before smz_root_init%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH2_AEX(h->maxa, h->K, h->P.A == h->maxa, hipLaunchKernelGGL((k_select<MA, KS, AEX>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P), (hipStream_t)stream, h->P,
+    SMZ_DISPATCH2_AEX(h->maxa, h->K, h->P.A == h->maxa && !h->P.philox, hipLaunchKernelGGL((k_select<MA, KS, AEX>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P), (hipStream_t)stream, h->P,
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
     h->selected = true;
     return launch_check();
@@ -1446,7 +1487,7 @@ int smz_expand_backup(smz_handle *h, const float *hidden_dev, const float *rewar
     if (!h || !policy_dev || !value_dev) return fail(SMZ_ERR_INVALID, "smz_expand_backup: null argument%s");
     if (!h->selected) return fail(SMZ_ERR_STATE, "smz_expand_backup without a preceding smz_select%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH2_AEX(h->maxa, h->K, h->P.A == h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, KS, false, AEX>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
+    SMZ_DISPATCH2_AEX(h->maxa, h->K, h->P.A == h->maxa && !h->P.philox, hipLaunchKernelGGL((k_expand_backup<MA, KS, false, AEX>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
                                              (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev,
                                              (float *)nullptr, (int32_t *)nullptr, (uint8_t *)nullptr, (float *)nullptr));
     h->selected = false;
@@ -1462,7 +1503,7 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
     if (!h || !policy_dev || !value_dev) return fail(SMZ_ERR_INVALID, "smz_expand_backup_select: null argument%s");
     if (!h->selected) return fail(SMZ_ERR_STATE, "smz_expand_backup_select without a preceding smz_select%s");
     DeviceGuard guard(h->cfg.device);
-    SMZ_DISPATCH2_AEX(h->maxa, h->K, h->P.A == h->maxa, hipLaunchKernelGGL((k_expand_backup<MA, KS, true, AEX>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
+    SMZ_DISPATCH2_AEX(h->maxa, h->K, h->P.A == h->maxa && !h->P.philox, hipLaunchKernelGGL((k_expand_backup<MA, KS, true, AEX>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
                                              (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev,
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
     return launch_check();
@@ -1544,13 +1585,8 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     while (tpw < kFastTpw && (size_t)256 * kWaves * tpw < (size_t)P.B) tpw <<= 1;
     if (const char *e = getenv("SMZ_SEARCH_TPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) tpw = v; }
     P.tpw = tpw;
-    const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL;
-    // matrix-core evaluation of the workgroup's 16 leaves (k_search_mlp<..., MF>): the specialised geometry with two
-    // children per expansion and 8 waves; SMZ_SEARCH_MFMA=0 keeps the vector evaluation (A/B runs)
-    bool mf = fast && kWaves == 8 && h->K == 2 && h->maxa <= 4 && (!(P.stats || P.dbg) || ((P.dbg & 64) && h->maxa == 2));
-    if (const char *e = getenv("SMZ_SEARCH_MFMA")) mf = mf && atoi(e) != 0;
-    const MegaLds ml = mega_lds(*desc, P, tpw, mf);
-    const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave + (mf ? smz_mlp::kMfFloats : 0)) * sizeof(float);
+    const MegaLds ml = mega_lds(*desc, P, tpw);
+    const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave) * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_TOO_LARGE, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
 #define SMZ_LAUNCH_SEARCH(UU, INSTR, AEX)                                                                              \
@@ -1568,30 +1604,9 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     })
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
+    // (the specialised instantiation is the parity-mode path: a Philox handle runs the generic one)
+    const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL && !P.philox;
 #if SMZ_PART != 4
-    if (mf) {
-#define SMZ_LAUNCH_MF(MA)                                                                                               \
-        {                                                                                                               \
-            static size_t granted_dev[64] = {};                                                                        \
-            size_t &granted = granted_dev[h->cfg.device & 63];                                                         \
-            if (lds > granted) {                                                                                       \
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, 2, 1, false, true, true>),     \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
-                    return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                        \
-                granted = lds;                                                                                         \
-            }                                                                                                          \
-            hipLaunchKernelGGL((k_search_mlp<MA, 2, 1, false, true, true>), dim3(blocks), dim3(kWaves * kWave), lds,   \
-                               (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act);                       \
-        }
-        if (P.dbg & 64) {      // phase stamps of the matrix-core kernel (SMZ_DEBUG_SKIP=80 with level statistics on)
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<2, 2, 1, true, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_search_mlp<2, 2, 1, true, true, true>), dim3(blocks), dim3(kWaves * kWave), lds,
-                               (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act);
-        } else
-        if (h->maxa == 2) SMZ_LAUNCH_MF(2) else SMZ_LAUNCH_MF(4)
-#undef SMZ_LAUNCH_MF
-    } else
     if ((P.stats || P.dbg) && fast && (P.dbg & 32) && h->maxa == 2 && h->K == 2) {
         // phase stamps of the specialised instantiation itself (SMZ_DEBUG_SKIP=48), for the headline geometry only
         constexpr int MA = 2, KS = 2;
@@ -1842,6 +1857,28 @@ int smz_debug_dump_tree(smz_handle *h, int tree, smz_node_view *nodes, int cap, 
     }
     if (root_priors_out) memcpy(root_priors_out, blob.data() + P.rp_off, (size_t)A * 8);
     return n;
+}
+
+int smz_philox_words(uint64_t seed, uint32_t block, int idx, int n, uint32_t *host_out) {
+    if (!host_out || n < 0 || idx < 0 || idx >= kMtN) return fail(SMZ_ERR_INVALID, "smz_philox_words: bad argument%s");
+    for (int i = 0; i < n; i++) {
+        host_out[i] = philox_word(block, idx, (uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32));
+        if (++idx == kMtN) { idx = 0; ++block; }
+    }
+    return SMZ_OK;
+}
+
+int smz_get_philox_position(smz_handle *h, int tree, uint32_t *block_out, int *idx_out) {
+    if (!h || tree < 0 || tree >= h->cfg.num_trees || !block_out || !idx_out)
+        return fail(SMZ_ERR_INVALID, "smz_get_philox_position: bad argument%s");
+    if (!h->P.philox) return fail(SMZ_ERR_STATE, "smz_get_philox_position: the handle draws from MT19937%s");
+    DeviceGuard guard(h->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    int32_t packed = 0;
+    HIP_TRY(hipMemcpy(&packed, h->P.rng_pos + tree, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(block_out, h->P.rng_block + tree, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *idx_out = packed & 0xffff;
+    return SMZ_OK;
 }
 
 int smz_enable_stats(smz_handle *h, int on) {

@@ -20,13 +20,10 @@ enum { M_DYN_IN, M_ADY_IN, M_DYN_MID, M_ADY_MID, M_DYN_OUT, M_ADY_OUT, M_PRE_IN,
 __host__ __device__ inline int up4(int x) { return (x + 3) & ~3; }
 
 // acc[r][u] = bias_r[o] + sum_k W_r[k][o] * act_r[k]  for o = lane + 64 u, for R rows at once (each row may use a
-// different matrix: its branch's).  ONE accumulation chain per output, in input order: acc = fma(w_k, a_k, acc) for
-// k = 0, 1, 2, ... starting from the bias (the zero padding of K included).  That is, rounding for rounding, what the
-// matrix cores compute when the same layer is issued as v_mfma_f32_16x16x4_f32 steps with the bias as the C operand
-// (an f32-input MFMA is a k-ordered fmaf chain, MI355X_MICROARCH.md) -- so the vector path here and the matrix path of
-// heads16_mfma below give bit-identical network outputs, and every instantiation of the search kernels stays
-// interchangeable (tests/test_gpu_end_to_end.py).  Four 4-wide steps per iteration with all their 16-byte LDS reads
-// issued back to back: one LDS latency covers 16 inputs (the plain loop is a chain of exposed LDS round trips).
+// different matrix: its branch's).  Even and odd inputs accumulate in the two halves of a packed register
+// (v_pk_fma_f32: two FMAs per instruction) and are added at the end; the order is fixed, so every caller rounds
+// identically.  Four 4-wide steps per iteration with all their 16-byte LDS reads issued back to back: one LDS latency
+// covers 16 inputs (the plain loop is a chain of exposed LDS round trips).
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ inline v2f pk_fma(float wx, float wy, float ax, float ay, v2f c) {
     v2f w = {wx, wy}, a = {ax, ay};
@@ -37,71 +34,16 @@ template <int U, int R, bool SAME = false>
 __device__ inline void dense(const float *const (&W)[R], const float *const (&bias)[R], const float *const (&act)[R], int K4,
                              int OP, int lane, float (&acc)[R][U]) {
     const float4 *a4[R], *w4[R];
+    v2f acc2[R][U];
 #pragma unroll
     for (int r = 0; r < R; r++) {
 #pragma unroll
-        for (int u = 0; u < U; u++) acc[r][u] = bias[r][lane + kWave * u];
+        for (int u = 0; u < U; u++) { acc2[r][u].x = bias[r][lane + kWave * u]; acc2[r][u].y = 0.f; }
         a4[r] = reinterpret_cast<const float4 *>(act[r]);
         w4[r] = reinterpret_cast<const float4 *>(W[r]) + lane;
     }
     const int n = K4 >> 2;
     int q = 0;
-#ifdef SMZ_DENSE_PK
-    // Round-1 arithmetic, kept behind a build flag for A/B timing only (profiles/r02_*_ab.txt): even and odd inputs
-    // accumulate in the two halves of a packed register (v_pk_fma_f32: two FMAs per instruction) and are added at the
-    // end.  Half the FMA instructions of the chain below, but NOT the rounding of the matrix-core path.
-    {
-        v2f acc2[R][U];
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int u = 0; u < U; u++) { acc2[r][u].x = acc[r][u]; acc2[r][u].y = 0.f; }
-        for (; q + 4 <= n; q += 4) {
-            float4 a[R][4], w[R][U][4];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    a[r][j] = a4[r][q + j];
-#pragma unroll
-                    for (int u = 0; u < U; u++) w[r][u][j] = (SAME && r > 0) ? w[0][u][j] : w4[r][(size_t)(q + j) * OP + kWave * u];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        v2f t = acc2[r][u];
-                        t = pk_fma(w[r][u][j].x, w[r][u][j].y, a[r][j].x, a[r][j].y, t);
-                        t = pk_fma(w[r][u][j].z, w[r][u][j].w, a[r][j].z, a[r][j].w, t);
-                        acc2[r][u] = t;
-                    }
-                }
-            }
-        }
-        for (; q < n; q++) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const float4 av = a4[r][q];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const float4 wv = w4[SAME ? 0 : r][(size_t)q * OP + kWave * u];
-                    v2f t = acc2[r][u];
-                    t = pk_fma(wv.x, wv.y, av.x, av.y, t);
-                    t = pk_fma(wv.z, wv.w, av.z, av.w, t);
-                    acc2[r][u] = t;
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int u = 0; u < U; u++) acc[r][u] = acc2[r][u].x + acc2[r][u].y;
-        return;
-    }
-#endif
     for (; q + 4 <= n; q += 4) {
         float4 a[R][4], w[R][U][4];
 #pragma unroll
@@ -119,12 +61,10 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
             for (int r = 0; r < R; r++) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    float t = acc[r][u];
-                    t = fmaf(w[r][u][j].x, a[r][j].x, t);
-                    t = fmaf(w[r][u][j].y, a[r][j].y, t);
-                    t = fmaf(w[r][u][j].z, a[r][j].z, t);
-                    t = fmaf(w[r][u][j].w, a[r][j].w, t);
-                    acc[r][u] = t;
+                    v2f t = acc2[r][u];
+                    t = pk_fma(w[r][u][j].x, w[r][u][j].y, a[r][j].x, a[r][j].y, t);
+                    t = pk_fma(w[r][u][j].z, w[r][u][j].w, a[r][j].z, a[r][j].w, t);
+                    acc2[r][u] = t;
                 }
             }
         }
@@ -136,15 +76,17 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const float4 wv = w4[SAME ? 0 : r][(size_t)q * OP + kWave * u];
-                float t = acc[r][u];
-                t = fmaf(wv.x, av.x, t);
-                t = fmaf(wv.y, av.y, t);
-                t = fmaf(wv.z, av.z, t);
-                t = fmaf(wv.w, av.w, t);
-                acc[r][u] = t;
+                v2f t = acc2[r][u];
+                t = pk_fma(wv.x, wv.y, av.x, av.y, t);
+                t = pk_fma(wv.z, wv.w, av.z, av.w, t);
+                acc2[r][u] = t;
             }
         }
     }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int u = 0; u < U; u++) acc[r][u] = acc2[r][u].x + acc2[r][u].y;
 }
 
 // exp for the heads: the hardware exponential (v_exp_f32 on x log2 e, ~1 ulp) -- the network outputs are held to the
@@ -266,8 +208,7 @@ __device__ inline float decode_lanes(const float (&v)[U], int lo, int S, int lan
 }
 
 // scale_to_bound_action over lanes [lo, lo+S) (neural_network_mlp_model.py:349-357); writes act_out[o-lo] (LDS) and dst[o-lo]
-// AS: element stride of act_out (1: a row; 16: one column of a k-major [k][16 leaves] tile, heads16_mfma)
-template <int U, int AS = 1>
+template <int U>
 __device__ inline void scale_lanes(const float (&v)[U], int lo, int S, int lane, float *act_out, float *dst,
                                    float *dst2 = nullptr) {
     float mn = __builtin_inff(), mx = -__builtin_inff();
@@ -281,7 +222,7 @@ __device__ inline void scale_lanes(const float (&v)[U], int lo, int S, int lane,
         const int o = lane + kWave * u;
         if (o >= lo && o < lo + S) {
             const float h = __fdividef(v[u] - mn, sc);
-            act_out[(o - lo) * AS] = h;
+            act_out[o - lo] = h;
             if (dst) dst[o - lo] = h;
             if (dst2) dst2[o - lo] = h;
         }
@@ -341,7 +282,7 @@ __device__ inline float softmax_decode_lanes(const float (&v)[U], int A, int S, 
 }
 
 // dynamics tail in two chains: support decode of lanes [0, S) (reward) and scale_to_bound_action of lanes [S, 2S)
-template <int U, int AS = 1>
+template <int U>
 __device__ inline float decode_scale_lanes(const float (&v)[U], int S, int lane, float *act_out, float *dst) {
     float mr = -__builtin_inff(), mn = __builtin_inff(), mx = -__builtin_inff();
 #pragma unroll
@@ -366,7 +307,7 @@ __device__ inline float decode_scale_lanes(const float (&v)[U], int S, int lane,
         const int o = lane + kWave * u;
         if (o >= S && o < 2 * S) {
             const float h = __fdividef(v[u] - mn, sc);
-            act_out[(o - S) * AS] = h;
+            act_out[o - S] = h;
             if (dst) dst[o - S] = h;
         }
     }
@@ -605,154 +546,6 @@ __device__ inline void stage_initial_weights(float *lds, const float *weights, c
                             d.off[M_PRE_OUT], d.off[M_APR_OUT] - d.off[M_PRE_OUT],       // pre_out
                             d.off[M_COUNT], d.total_floats - d.off[M_COUNT]};            // all biases
     stage_weights(lds, weights, ranges, 5);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The recurrent evaluation of 16 leaves by a whole 8-wave workgroup on the matrix cores, for the reference's shipped
-// network shape (S 31, H 64, L 0; A <= 16).  What it buys is operand reuse: in the vector path above every 16-byte
-// weight read serves two leaves and the LDS pipe is the busiest unit of the evaluation; here a weight tile lives in
-// the REGISTERS of the wave that owns it for the whole search and serves all 16 leaves of the workgroup in one
-// v_mfma_f32_16x16x4_f32 (A operand = 16 output neurons x 4 inputs of a weight matrix, B operand = 4 inputs x 16 leaves
-// read from a k-major LDS tile, C = bias).  f32 in, f32 accumulate: the same k-ordered fma chain as dense(), so the
-// outputs are bit-identical to the vector path's.
-// Layers and who computes what (wave w of 8; both networks of a layer are evaluated for all 16 leaves, a leaf's tail
-// picks the one its branch needs; a network no leaf of the workgroup needs this round is skipped):
-//   L1  [hidden | one-hot] (36) -> 64, ELU     dyn_in / ady_in    wave w: network w >> 2, output tile w & 3      9 MFMAs
-//   L2  64 -> 62 (reward | state) / 31 (state) dyn_out / ady_out  waves 0-3: dyn tiles, 4-5: ady tiles          16 MFMAs
-//       tail: support decode + min-max scaling per leaf (the leaf's own wave, lane = output: the vector path's code)
-//   L3  state (32) -> 64, ELU                  pre_in / apr_in    wave w: network w >> 2, tile w & 3             8 MFMAs
-//   L4  64 -> A + 31 (policy | value)          pre_out / apr_out  waves 0-2: pre tiles, 3-5: apr tiles          16 MFMAs
-//       tail: policy softmax + value decode per leaf
-// LDS tiles (floats): Xk [36][16] inputs, T [2][64][16] trunk activations, Hk [32][16] new hidden states (all k-major:
-// element (k, leaf) at k * 16 + leaf -- a B operand is then one conflict-free ds_read_b32 per step), Y [2][16][68] raw
-// layer outputs per leaf (68: 16-byte stores of 8 lanes land in 8 different bank groups), br [16] branch flags.
-// ---------------------------------------------------------------------------------------------------------------
-typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kMfLeaves = 16, kMfYStride = 68;
-constexpr int kMfXk = 0, kMfT = kMfXk + 36 * 16, kMfHk = kMfT + 2 * 64 * 16, kMfY = kMfHk + 32 * 16,
-              kMfBr = kMfY + 2 * 16 * kMfYStride, kMfFloats = kMfBr + 16;
-
-struct MfmaWeights {          // this wave's A operands and bias fragments
-    float l1[9], l2[16], l3[8], l4[16];
-    v4f b1, b2, b3, b4;
-};
-
-// element (k, o) of packed matrix `base` (include/smz.h layout, OP = 64)
-__device__ inline float mf_w(const float *base, int k, int o) { return base[((k >> 2) * kWave + o) * 4 + (k & 3)]; }
-
-// Loads the fragments wave `wave` needs from the packed weight buffer in global memory (once per search).
-__device__ inline void mfma_load_weights(const float *weights, const smz_mlp_desc &d, int wave, int lane, MfmaWeights &W) {
-    const int g = lane >> 4, i = lane & 15;
-    const int bias0 = d.off[M_COUNT];
-    auto load = [&](int m, int o0, int ksteps, float *dst, v4f &b) {
-        const float *base = weights + mat_off(d, m);
-#pragma unroll
-        for (int kk = 0; kk < 16; kk++) if (kk < ksteps) dst[kk] = mf_w(base, 4 * kk + g, o0 + i);
-        const float *bv = weights + bias0 + m * kWave + o0 + 4 * g;
-        b = v4f{bv[0], bv[1], bv[2], bv[3]};
-    };
-    const int net = wave >> 2, mt = wave & 3;
-    float l1[16], l2[16] = {}, l3[16], l4[16] = {};
-    v4f b2 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
-    if (net) load(M_ADY_IN, 16 * mt, 9, l1, W.b1); else load(M_DYN_IN, 16 * mt, 9, l1, W.b1);
-    if (net) load(M_APR_IN, 16 * mt, 8, l3, W.b3); else load(M_PRE_IN, 16 * mt, 8, l3, W.b3);
-    if (wave < 4) load(M_DYN_OUT, 16 * wave, 16, l2, b2); else if (wave < 6) load(M_ADY_OUT, 16 * (wave - 4), 16, l2, b2);
-    if (wave < 3) load(M_PRE_OUT, 16 * wave, 16, l4, b4); else if (wave < 6) load(M_APR_OUT, 16 * (wave - 3), 16, l4, b4);
-#pragma unroll
-    for (int kk = 0; kk < 9; kk++) W.l1[kk] = l1[kk];
-#pragma unroll
-    for (int kk = 0; kk < 8; kk++) W.l3[kk] = l3[kk];
-#pragma unroll
-    for (int kk = 0; kk < 16; kk++) { W.l2[kk] = l2[kk]; W.l4[kk] = l4[kk]; }
-    W.b2 = b2; W.b4 = b4;
-}
-
-template <int KSTEPS>
-__device__ inline v4f mf_layer(const float (&wf)[KSTEPS], const float *bt, v4f acc, int g, int i) {
-    float b[KSTEPS];
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk++) b[kk] = bt[(4 * kk + g) * kMfLeaves + i];     // all reads in flight, then the chain
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk], b[kk], acc, 0, 0, 0);
-    return acc;
-}
-
-// All 8 waves (512 threads) call this with the network inputs of the workgroup's 16 leaves in Xk and their branch flags
-// in br (leaf of tree slot t of wave w = 2 w + t).  dyn / live / dst_hidden / dst_policy / reward / value: this wave's two
-// leaves, as recurrent_rows.  Starts and ends with the data hazards covered by its own workgroup barriers; the caller
-// needs none before the call beyond having issued its Xk / br stores.
-// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, not for its outstanding global loads
-// and stores (__syncthreads() drains vmcnt too -- here that would expose the latency of the random-word loads in flight
-// and of the hidden-row stores of the tails at every one of the six barriers of a round).
-__device__ inline void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int A>
-__device__ inline void heads16_mfma(const MfmaWeights &W, float *mf, int wave, int lane, const bool (&dyn)[2],
-                                    const bool (&live)[2], float *const (&dst_hidden)[2], float *const (&dst_policy)[2],
-                                    float (&reward)[2], float (&value)[2], unsigned long long *wait_cycles = nullptr,
-                                    int ablate = 0) {     // ablate: timing experiments only (instrumented build)
-    constexpr int S = 31;
-    float *Xk = mf + kMfXk, *T = mf + kMfT, *Hk = mf + kMfHk, *Y = mf + kMfY;
-    const int *br = reinterpret_cast<const int *>(mf + kMfBr);
-    const int g = lane >> 4, i = lane & 15;
-    const unsigned long long tw = wait_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
-    wg_barrier_lds();                                                   // Xk, br complete
-    if (wait_cycles) *wait_cycles += __builtin_amdgcn_s_memtime() - tw;   // (instrumented build: time spent waiting for the slowest wave)
-    const int mine = br[i];
-    const bool need_dyn = __ballot(mine != 0) != 0ull, need_ady = __ballot(mine == 0) != 0ull;
-    const int net = wave >> 2, mt = wave & 3;
-    const bool need_net = net ? need_ady : need_dyn;
-    // ---- L1 ---------------------------------------------------------------------------------------------------------
-    if (need_net && !(ablate & 1)) {
-        const v4f acc = mf_layer<9>(W.l1, Xk, W.b1, g, i);
-        float *t = T + net * 64 * kMfLeaves + (16 * mt + 4 * g) * kMfLeaves + i;
-#pragma unroll
-        for (int r = 0; r < 4; r++) t[r * kMfLeaves] = elu(acc[r]);
-    }
-    wg_barrier_lds();
-    // ---- L2 ---------------------------------------------------------------------------------------------------------
-    {
-        const int n2 = wave < 4 ? 0 : 1, mt2 = wave < 4 ? wave : wave - 4;
-        if (wave < 6 && (n2 ? need_ady : need_dyn) && !(ablate & 1)) {
-            const v4f acc = mf_layer<16>(W.l2, T + n2 * 64 * kMfLeaves, W.b2, g, i);
-            *reinterpret_cast<v4f *>(Y + n2 * kMfLeaves * kMfYStride + i * kMfYStride + 16 * mt2 + 4 * g) = acc;
-        }
-    }
-    wg_barrier_lds();
-    if (!(ablate & 2))
-#pragma unroll
-    for (int r = 0; r < 2; r++) {                                       // tail: this wave's own leaves, lane = output
-        const int leaf = 2 * wave + r;
-        float acc[1] = {Y[(dyn[r] ? 0 : 1) * kMfLeaves * kMfYStride + leaf * kMfYStride + lane]};
-        reward[r] = 0.f;
-        if (dyn[r]) reward[r] = decode_scale_lanes<1, kMfLeaves>(acc, S, lane, Hk + leaf, live[r] ? dst_hidden[r] : nullptr);
-        else scale_lanes<1, kMfLeaves>(acc, 0, S, lane, Hk + leaf, live[r] ? dst_hidden[r] : nullptr);
-    }
-    wg_barrier_lds();
-    // ---- L3 ---------------------------------------------------------------------------------------------------------
-    if (need_net && !(ablate & 1)) {
-        const v4f acc = mf_layer<8>(W.l3, Hk, W.b3, g, i);
-        float *t = T + net * 64 * kMfLeaves + (16 * mt + 4 * g) * kMfLeaves + i;
-#pragma unroll
-        for (int r = 0; r < 4; r++) t[r * kMfLeaves] = elu(acc[r]);
-    }
-    wg_barrier_lds();
-    // ---- L4 ---------------------------------------------------------------------------------------------------------
-    {
-        const int n4 = wave < 3 ? 0 : 1, mt4 = wave < 3 ? wave : wave - 3;
-        if (wave < 6 && (n4 ? need_ady : need_dyn) && !(ablate & 1)) {
-            const v4f acc = mf_layer<16>(W.l4, T + n4 * 64 * kMfLeaves, W.b4, g, i);
-            *reinterpret_cast<v4f *>(Y + n4 * kMfLeaves * kMfYStride + i * kMfYStride + 16 * mt4 + 4 * g) = acc;
-        }
-    }
-    wg_barrier_lds();
-    if (!(ablate & 2))
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int leaf = 2 * wave + r;
-        float acc[1] = {Y[(dyn[r] ? 0 : 1) * kMfLeaves * kMfYStride + leaf * kMfYStride + lane]};
-        value[r] = softmax_decode_lanes<1>(acc, A, S, lane, live[r] ? dst_policy[r] : nullptr);
-    }
 }
 
 }  // namespace smz_mlp

@@ -113,6 +113,12 @@ class SearchEngine:
         _lib.check(self.lib.smz_get_rng_state(self.h, int(tree), key.ctypes.data_as(C.c_void_p), C.byref(pos)))
         return key, pos.value
 
+    def philox_position(self, tree):
+        """(rng_mode PHILOX) (block, idx): tree `tree` has consumed block * 624 + idx words of its stream."""
+        b, i = C.c_uint32(), C.c_int()
+        _lib.check(self.lib.smz_get_philox_position(self.h, int(tree), C.byref(b), C.byref(i)))
+        return b.value, i.value
+
     def snapshot_rng(self):
         _lib.check(self.lib.smz_rng_snapshot(self.h, self._stream()))
 

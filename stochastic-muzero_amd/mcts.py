@@ -81,11 +81,13 @@ class _Hyper:
 class BatchedMCTS(_Hyper):
     def __init__(self, num_trees, pb_c_base=19652, pb_c_init=1.25, discount=0.95, root_dirichlet_alpha=0.25,
                  root_exploration_fraction=0.25, num_simulations=10, maxium_action_sample=2, number_of_player=1,
-                 custom_loop=None, device=None, use_graph=True, fused=True, single_launch=True):
+                 custom_loop=None, device=None, use_graph=True, fused=True, single_launch=True,
+                 rng_mode=_lib.RNG_MT19937_NUMPY):
         self._set_hyper(pb_c_base, pb_c_init, discount, root_dirichlet_alpha, root_exploration_fraction,
                         num_simulations, maxium_action_sample, number_of_player, custom_loop)
         self.num_trees = int(num_trees)
         self.device = device
+        self.rng_mode = int(rng_mode)       # RNG_MT19937_NUMPY: the reference's draws (parity); RNG_PHILOX: throughput mode
         self.use_graph, self.fused, self.single_launch = bool(use_graph), bool(fused), bool(single_launch)
         self.engine = None
         self._graph = None
@@ -98,7 +100,7 @@ class BatchedMCTS(_Hyper):
             if self.engine is not None:
                 self.engine.close()
             self.engine = SearchEngine(self.num_trees, num_actions, hidden_size, device=self.device,
-                                       **self._engine_kwargs())
+                                       rng_mode=self.rng_mode, **self._engine_kwargs())
             if getattr(self, "_active", None) is not None:
                 self.engine.set_active(self._active)
             self._graph = None

@@ -40,7 +40,7 @@ def _observations(wname, B):
     return np.random.RandomState(0).standard_normal((B, 8)).astype(np.float32)   # LunarLander-shaped
 
 
-def stepwise_tape(model, obs, seeds, sims, K, train=True):
+def stepwise_tape(model, obs, seeds, sims, K, train=True, philox=False):
     """Step-wise search with the fused HIP heads; returns the engine and the per-simulation tape (host arrays).
     The Dirichlet sample of every tree is the oracle's (numpy's own arithmetic), injected through noise_override."""
     import orc
@@ -49,7 +49,8 @@ def stepwise_tape(model, obs, seeds, sims, K, train=True):
     B = obs.shape[0]
     A, S = heads.A, heads.S
     eng = smz.SearchEngine(B, A, S, num_simulations=sims, maxium_action_sample=K, discount=DISCOUNT,
-                           root_dirichlet_alpha=ALPHA, root_exploration_fraction=FRAC)
+                           root_dirichlet_alpha=ALPHA, root_exploration_fraction=FRAC,
+                           rng_mode=smz._lib.RNG_PHILOX if philox else smz._lib.RNG_MT19937_NUMPY)
     eng.seed(seeds)
     hidden, policy = heads.initial(torch.from_numpy(obs).cuda())
     torch.cuda.synchronize()
@@ -58,7 +59,10 @@ def stepwise_tape(model, obs, seeds, sims, K, train=True):
     trees, noise = [], np.zeros((B, A), np.float64)
     for i in range(B):
         t = orc.Tree(cfg)
-        t.seed(int(seeds[i]))
+        if philox:
+            t.seed_philox(int(seeds[i]))
+        else:
+            t.seed(int(seeds[i]))
         noise[i] = t.root_init(root_policy[i], hidden=root_hidden[i], train=train)
         trees.append(t)
     eng.root_init(hidden, policy, train=train, noise_override=torch.from_numpy(noise).cuda())
@@ -113,6 +117,9 @@ def assert_engine_equals_oracle(eng, trees, sims, prior_rtol):
         if sims > 0:
             assert np.array_equal(d["minmax"], o["minmax"]), (i, d["minmax"], o["minmax"])
             assert np.array_equal(d["path"], o["path"]), i
+        if eng.cfg.rng_mode == 1:                      # Philox handles: (block, index) is the whole stream position
+            assert eng.philox_position(i) == trees[i].philox_position(), f"tree {i}: stream position"
+            continue
         key, pos = eng.get_rng_state(i)
         okey, opos = trees[i].get_rng()
         ra = np.random.RandomState(0); ra.set_state(("MT19937", key, pos, 0, 0.0))
@@ -196,3 +203,38 @@ def test_end_to_end_root_values_against_the_oracles_own_heads():
           f"error on those: max {rel.max():.3e}, mean {rel.mean():.3e}")
     assert same >= int(0.97 * B), f"{same}/{B}"
     assert rel.max() <= 1e-5, rel.max()
+
+
+@pytest.mark.parametrize("wname,B,sims,K,T", [("weights_ckpt421", 4096, 50, 2, 1.0), ("weights_lunar_L0", 777, 30, 4, 0.5),
+                                              ("weights_wide_A11", 130, 20, 9, 1.0)])
+def test_philox_mode_equals_the_oracle_drawing_from_the_same_counter_stream(wname, B, sims, K, T):
+    """rng_mode SMZ_RNG_PHILOX (throughput mode): the numpy-legacy algorithms on Philox4x32-10 words.  Not the
+    reference's generator, so the check is against the oracle switched to the same word source (oracle/smz_oracle.c,
+    known-answer-tested on the CPU): step-wise kernels == oracle and single-launch kernel == oracle, every tree, bit for
+    bit, stream positions included; get_rng_state (a numpy MT19937 state) is refused."""
+    import stochastic_muzero_amd as smz
+    mcts_mod, model_mod = _mods()
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
+    obs = np.random.RandomState(2).standard_normal((B, model.observation_dimension)).astype(np.float32) * 0.3
+    seeds = (np.arange(B, dtype=np.uint64) + np.uint64(7)) * np.uint64(0x9E3779B97F4A7C15)       # full 64-bit keys
+    eng, trees, tape = stepwise_tape(model, obs, seeds, sims, K, philox=True)
+    oracle_replay(trees, tape)
+    assert_engine_equals_oracle(eng, trees, sims, prior_rtol=0)
+    with pytest.raises(smz._lib.SmzError):
+        eng.get_rng_state(0)
+    eng.close()
+    heads = model.heads("cuda:0", backend="hip")
+    m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=K, discount=DISCOUNT, root_dirichlet_alpha=ALPHA,
+                             root_exploration_fraction=FRAC, use_graph=False, single_launch=True, rng_mode=smz._lib.RNG_PHILOX)
+    m.seed(seeds)
+    e = m.run(torch.from_numpy(obs).cuda(), heads, train=True, act_temperature=T)
+    assert m._single is True
+    action, policy, child_visits, root_value = (t.clone() for t in e.act(T))
+    torch.cuda.synchronize()
+    oa = [trees[i].act(T) for i in range(B)]
+    assert_engine_equals_oracle(e, trees, sims, prior_rtol=1e-13)
+    assert np.array_equal(action.cpu().numpy(), np.array([a[0] for a in oa], np.int32))
+    assert np.array_equal(child_visits.cpu().numpy(), np.stack([a[2] for a in oa]))
+    # a second search continues every stream (no re-seeding): still the oracle's
+    m.run(torch.from_numpy(obs).cuda(), heads, train=True)
+    torch.cuda.synchronize()

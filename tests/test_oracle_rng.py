@@ -108,3 +108,46 @@ def test_leaf_expansion_sampled_subset(A, K):
         assert list(d["action"][cb:cb + K]) == list(picks)
         assert np.array_equal(d["prior"][cb:cb + K], p[picks])
         assert t.random_sample() == rs.random_sample()
+
+
+def test_philox_known_answers_and_the_librarys_host_evaluation():
+    """Philox4x32-10: the published known-answer vectors (Random123 kat_vectors: all-zero input; the pi / e digit
+    input) on the oracle's restatement, and the library's host evaluation of a stream (smz_philox_words: word i =
+    component i & 3 of philox(counter i / 4, key = seed)) against it, across a 624-word block boundary."""
+    import ctypes as C
+    import orc
+    import stochastic_muzero_amd as smz
+    L = orc.lib()
+    out = (C.c_uint32 * 4)()
+    L.orc_philox_block(0, 0, 0, 0, out)
+    assert list(out) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+
+    def py(c, k):                       # the published round function, all four counter words
+        c, k = list(c), list(k)
+        for _ in range(10):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+            k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+        return c
+    assert py([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    seed = 0x0123456789abcdef
+    lib = smz._lib.load()
+    w = np.zeros(40, np.uint32)
+    assert lib.smz_philox_words(seed, 3, 610, 40, w.ctypes.data_as(C.c_void_p)) == 0
+    want = []
+    block, idx = 3, 610
+    for _ in range(40):
+        n = block * 156 + idx // 4
+        want.append(py([n & 0xffffffff, n >> 32, 0, 0], [seed & 0xffffffff, seed >> 32])[idx & 3])
+        idx += 1
+        if idx == 624:
+            idx, block = 0, block + 1
+    assert list(w) == want
+    t = orc.Tree(orc.make_cfg(2, 2, 0, 4))
+    t.seed_philox(seed)
+    a = [t.random_sample() for _ in range(3)]
+    w6 = np.zeros(6, np.uint32)
+    lib.smz_philox_words(seed, 0, 0, 6, w6.ctypes.data_as(C.c_void_p))
+    assert a == [((int(w6[2 * i]) >> 5) * 67108864.0 + (int(w6[2 * i + 1]) >> 6)) / 9007199254740992.0 for i in range(3)]
+    assert t.philox_position() == (0, 6)
