@@ -322,7 +322,8 @@ def main():
               "hidden_floats": int(groups[0].heads.S) if hasattr(groups[0].heads, "S") else model.state_dimension,
               "rng": "per-tree MT19937 (numpy-legacy, parity mode)" if args.rng == "mt19937" else
                      "per-tree Philox4x32-10 (throughput mode: the numpy-legacy algorithms on counter-based words; NOT the reference's draws)",
-              "search": "one launch per env step (smz_search_mlp_act)" if single else
+              "search": ("one launch per env step (smz_vision_initial + smz_search_vision_act)" if wl["env"] == "image" else
+                         "one launch per env step (smz_search_mlp_act)") if single else
                         ("step-wise kernels" + ("" if args.no_graph else ", one HIP graph per env step")),
               "stream_groups": G, "heads": type(groups[0].heads).__name__,
               "env": "host (envs.HostVecEnv, pinned-memory action download + observation upload per step)" if args.host_env else "device",
@@ -378,7 +379,9 @@ def main():
             ms = np.array([a.elapsed_time(b) for a, b in durs[1:]])
             mean_us = float(ms.mean() * 1e3)
             bytes_launch = (k2 + k5) * Bg * wl["sims"]
-            kernel = "k_search_mlp<MAXA,KS,U,INSTR,AEX> (root + num_simulations x [select, heads, expand, backup] in one launch)"
+            kernel = ("k_search_vision<MAXA> (root expansion + num_simulations x [select, conv nets + MFMA towers, expand, backup] in one launch)"
+                      if wl["env"] == "image" else
+                      "k_search_mlp<MAXA,KS,U,INSTR,AEX> (root + num_simulations x [select, heads, expand, backup] in one launch)")
         else:
             kernel = "k_expand_backup<MAXA,KS,true,AEX> (expand + backup + next select)"
             durs = []

@@ -293,6 +293,23 @@ int smz_search_mlp_act(smz_handle *h, const smz_mlp_desc *desc, const float *wei
                        double temperature, const double *pow_table_host, int32_t *action_dev, double *policy_dev,
                        double *child_visits_dev, float *root_value_dev, smz_stream stream);
 
+/* The same for the `vision_model` family: root expansion and noise, then num_simulations x (select, the leaf's
+ * (afterstate) dynamics + (afterstate) prediction networks, expansion, backup) in ONE launch.  The root's hidden state and
+ * policy come from smz_vision_initial (hidden0_dev [B,147], policy0_dev [B,A]): the representation network works on whole
+ * 98x98 frames, one workgroup per frame, and stays its own launch.  A workgroup of 8 wavefronts owns 16 trees; the
+ * convolutional part of a leaf is evaluated by its tree's wavefront, the five 147 -> H -> S/A towers for all 16 leaves at
+ * once on the matrix cores (f32 in / f32 accumulate: bit-identical to smz_vision_recurrent).  Results are read as after
+ * the step-wise calls.  SMZ_ERR_TOO_LARGE outside the kernel's limits (maxium_action_sample == 2, A <= 4, S <= 32,
+ * H <= 64, MT19937 streams, working set <= 160 KB of LDS): use the step-wise entry points then.
+ * monte_carlo_tree_search.py:311-349, neural_network_vision_model.py:41-515, muzero_model.py:802-909. */
+int smz_search_vision(smz_handle *h, const smz_vision_desc *desc, const float *weights_dev, const float *hidden0_dev,
+                      const float *policy0_dev, int train, smz_stream stream);
+/* ... followed by smz_act in the tail of the same launch (as smz_search_mlp_act). */
+int smz_search_vision_act(smz_handle *h, const smz_vision_desc *desc, const float *weights_dev, const float *hidden0_dev,
+                          const float *policy0_dev, int train, double temperature, const double *pow_table_host,
+                          int32_t *action_dev, double *policy_dev, double *child_visits_dev, float *root_value_dev,
+                          smz_stream stream);
+
 /* ---- synthetic environment + trajectory record (self_play.py:63-98 loop body around the search) -------------- */
 /* CartPole-v1 shaped Euler step on device (float64 state, float32 observation), used for the synthetic
  * fixed-length episodes of the benchmark: state_dev [B,4] f64 in/out, action_dev [B] i32,

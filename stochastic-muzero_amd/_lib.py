@@ -85,6 +85,8 @@ SIGNATURES = {
     "smz_vision_recurrent": (C.c_int, [C.POINTER(VisionDesc), _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_search_mlp_act": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
     "smz_search_mlp": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, _P]),
+    "smz_search_vision": (C.c_int, [_P, C.POINTER(VisionDesc), _P, _P, _P, C.c_int, _P]),
+    "smz_search_vision_act": (C.c_int, [_P, C.POINTER(VisionDesc), _P, _P, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
     "smz_cartpole_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_cartpole_step_pack": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
     "smz_cartpole_step_ctl": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(EpisodeCtl), _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),

@@ -11,8 +11,8 @@
 // SMZ_PART: 0 / undefined = the whole library part in one translation unit; the Makefile compiles this file twice --
 // 1 = everything but the single-launch search kernel and the fused expand+backup+select entry point, 2 = the search
 // kernel for the action buckets 2 and 4 with smz_search_mlp(_act), 4 = the search kernel for the buckets 8-32,
-// 3 = only smz_expand_backup_select -- the template instantiations behind those are most of the compile time, and the
-// parts build in parallel.
+// 3 = only smz_expand_backup_select, 5 = nothing but the shared helpers and the handle (included by smz_vision_search.hip)
+// -- the template instantiations behind those are most of the compile time, and the parts build in parallel.
 #ifndef SMZ_PART
 #define SMZ_PART 0
 #endif
@@ -60,7 +60,7 @@ __host__ __device__ inline RowGeom row_geom(int width) {
 }
 
 // numpy `seed(int)`: init_genrand (numpy/random/src/mt19937/mt19937.c mt19937_seed); pos = 624.
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
     if (tree >= P.B) return;
@@ -338,7 +338,7 @@ __device__ inline uint32_t *rng_tile_ptr(const Params &P) {
     return reinterpret_cast<uint32_t *>(smz_dyn_lds + n);
 }
 
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidden, const float *policy,
                                                      const double *noise_override, int train) {
@@ -388,7 +388,7 @@ __device__ inline void fix_layout(Params &P, bool a_const, bool k_const) {
 
 // AEX (instantiated for the MAXA 2 and 4 buckets): the action count equals the bucket, so A (and K when KS > 0) are
 // compile-time constants in everything inlined below (see k_search_mlp).
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 template <int MAXA, int KS, bool AEX>
 __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_hidden, int32_t *last_action,
                                                   uint8_t *branch, float *mlp_input) {
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 template <int MAXA, int KS, bool FUSE_SELECT, bool AEX>
 __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const float *hidden, const float *reward,
                                                          const float *policy, const float *value,
@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits, double *priors, float *root_value,
                                                       float *child_reward) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits,
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_act(Params P, double temperature, int32_t *action, double *policy,
                                                double *child_visits, float *root_value) {
@@ -818,7 +818,7 @@ __device__ inline void softmax_group(const float *row, int A, float *out, int li
     for (int i = li; i < A; i += lpr) out[i] = expf(row[i] - m) / den;
 }
 
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 __global__ void __launch_bounds__(256) k_support_decode(const float *logits, int S, float *out, int B, int lpr) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
     const int row = gid < B ? gid : B - 1;     // surplus groups recompute the last row (keeps shuffles convergent)
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(256) k_support_decode(const float *logits, int
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 __global__ void __launch_bounds__(256) k_policy_softmax(const float *logits, int A, float *out, int B, int lpr) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
     if (gid < B) softmax_group(logits + (size_t)gid * A, A, out + (size_t)gid * A, li, lpr);
@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(256) k_policy_softmax(const float *logits, int
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 __global__ void __launch_bounds__(256) k_dynamics_epilogue(const float *state_dyn, const float *state_after,
                                                            const float *reward_logits, int ld, const uint8_t *branch,
                                                            int S, float *hidden_out, float *reward_out, int B, int lpr) {
@@ -859,7 +859,7 @@ __global__ void __launch_bounds__(256) k_dynamics_epilogue(const float *state_dy
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pred, const float *val_pred,
                                                              const float *pol_after, const float *val_after,
                                                              int ld, const uint8_t *branch, int A, int S,
@@ -882,7 +882,7 @@ __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pr
 #endif
 
 // ---- synthetic env + trajectory record ---------------------------------------------------------------------------
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 // traj != nullptr: also appends the step's record (the layout of k_traj_pack, A = 2) -- one launch less per env step
 __global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int32_t *action, float *obs_out,
                                                        float *reward_out, uint8_t *term_out, int B, double *traj, int t,
@@ -934,7 +934,7 @@ __host__ __device__ inline double smz_unit(uint64_t seed, uint64_t env, uint64_t
     return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 // k_cartpole_step with the game bookkeeping of self_play.py:79 / game.py:270-271 per env: the flag written to
 // flag_out / the record's `terminated` slot is 0 running, 1 terminated (Game.done True), 2 stopped by
 // limit_of_game_play (the game is over but Game.done stays False, game.py:270-271), 3 no step taken (env switched off).
@@ -1014,7 +1014,7 @@ __global__ void __launch_bounds__(256) k_synthetic_obs(float *obs, int B, int ob
 //   [obs(obs_dim) | reward | terminated | policy(A) | action one-hot(A) | root_value | child_visits(A)]
 // One thread per float64 of the step's [B][F] slab: writes are contiguous across the whole slab and the observation
 // reads are contiguous per row, whatever obs_dim is (4 for CartPole, 28812 for a 98x98x3 frame).
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, int obs_dim, int A, const float *obs,
                                                    const float *reward, const uint8_t *terminated, const int32_t *action,
                                                    const double *policy, const double *child_visits,
@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, i
 
 // Game length of every env of a chunk: steps up to and including the first terminated one (chunk_to_games'/play_game's
 // cut, self_play.py:79-94), or T.
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T, int obs_dim, int A, int B, int ignore_term,
                                                       int32_t *length) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1062,7 +1062,7 @@ __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T,
 // float32 -- f32(root_value) * f32(discount^td), then one f32 add per reward of the f64 product reward * discount^i
 // rounded to f32 -- and a chain past the end of the game starts from a Python 0 and stays float64.
 // abs_td = |float64(root_value[t]) - target| (make_priority before ** priority_scale).  Positions t >= length are 0.
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 __global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T, int obs_dim, int A, int B, int td,
                                                       const double *disc_pow, const int32_t *length, double *target,
                                                       double *abs_td) {
@@ -1090,7 +1090,7 @@ __global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T,
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 // div_by_count against the IEEE division, element-wise (inspection: tests pin the table-based quotients)
 __global__ void __launch_bounds__(256) k_debug_div_by_count(const double *x, const int32_t *n, int count, int N, double *out) {
     for (int i = threadIdx.x; i < N; i += blockDim.x) smz_dyn_lds[i] = i > 0 ? 1.0 / (double)i : 0.0;
@@ -1896,7 +1896,7 @@ int smz_read_stats(smz_handle *h, uint64_t levels_out[4], int reset) {
     HIP_TRY(hipMemcpy(v, h->d_stats, sizeof(v), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) levels_out[i] = (uint64_t)v[i];
     if (getenv("SMZ_DEBUG_SKIP") && (atoi(getenv("SMZ_DEBUG_SKIP")) & 16))
-        fprintf(stderr, "[smz phase cycles, summed over waves] stage %llu expand %llu select %llu mlp %llu\n", v[4], v[5], v[6], v[7]);
+        fprintf(stderr, "[smz phase cycles, summed over waves] stage %llu expand %llu select %llu mlp %llu  (k_search_vision: tree, conv, wait, towers+tails)\n", v[4], v[5], v[6], v[7]);
     if (reset) HIP_TRY(hipMemset(h->d_stats, 0, sizeof(v)));
     return SMZ_OK;
 }

@@ -1,0 +1,250 @@
+// smz_vision_device.hpp -- device pieces of the `vision_model` family shared by the wave-per-leaf kernels (smz_vision.hip)
+// and the single-launch vision search (smz_vision_search.hip): the 3x7x7 hidden state lives one pixel per lane with its
+// three channels in registers; 3x3 convolutions read a zero-bordered float4 plane in LDS.
+// neural_network_vision_model.py:41-515 through muzero_model.py:802-909.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/smz.h"
+#include "smz_mlp_device.hpp"
+
+namespace smz_vision {
+using namespace smz_mlp;
+
+constexpr int kC = 3, kN = 7, kPix = kN * kN, kFlat = kC * kPix, kFlat4 = 148, kPad = kN + 2;
+constexpr int kFrame = 98;
+constexpr int kSmallMax = 1280;   // floats of convolution / batch-norm / 1x1 pieces of the four recurrent nets (1160 used)
+
+// -------------------------------------------------------------------------------------------------------------------
+// wave-per-leaf pieces
+// -------------------------------------------------------------------------------------------------------------------
+struct WaveLds {
+    float4 plane[kPad * kPad];   // zero border, interior written per layer
+    float flat[kFlat4];          // flattened 1x1-conv output, channel major (torch's Flatten of [3,7,7])
+    float hid[2][64];            // tower activations (ping-pong)
+};
+
+__device__ inline const float *uniform_ptr(const float *base, int off) {
+    return base + __builtin_amdgcn_readfirstlane(off);
+}
+
+// out[oc] = sum_{tap, ic} w[oc][ic][tap] * plane[pixel + tap][ic]; CIN = 3 or 4 (4th = action plane)
+// ROLL: the nine taps as a rolled loop (12 weights live at a time instead of up to 108: the single-launch vision search
+// keeps tree state and tower fragments in registers next to this code); same operations in the same order either way.
+template <int CIN, bool ROLL = false>
+__device__ inline void conv3x3(const float4 *plane, int pp, const float *__restrict__ w, float (&out)[kC]) {
+#pragma unroll
+    for (int oc = 0; oc < kC; oc++) out[oc] = 0.f;
+    if constexpr (ROLL) {
+#pragma unroll 1
+        for (int ty = 0; ty < 3; ty++) {                    // one row of taps per trip: 27-36 weights live, three plane reads in flight
+#pragma unroll
+            for (int tx = 0; tx < 3; tx++) {
+                const int t = ty * 3 + tx;
+                const float4 v = plane[pp + (ty - 1) * kPad + (tx - 1)];
+#pragma unroll
+                for (int oc = 0; oc < kC; oc++) {
+                    out[oc] = fmaf(w[(oc * CIN + 0) * 9 + t], v.x, out[oc]);
+                    out[oc] = fmaf(w[(oc * CIN + 1) * 9 + t], v.y, out[oc]);
+                    out[oc] = fmaf(w[(oc * CIN + 2) * 9 + t], v.z, out[oc]);
+                    if (CIN == 4) out[oc] = fmaf(w[(oc * CIN + 3) * 9 + t], v.w, out[oc]);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const float4 v = plane[pp + (t / 3 - 1) * kPad + (t % 3 - 1)];
+#pragma unroll
+        for (int oc = 0; oc < kC; oc++) {
+            out[oc] = fmaf(w[(oc * CIN + 0) * 9 + t], v.x, out[oc]);
+            out[oc] = fmaf(w[(oc * CIN + 1) * 9 + t], v.y, out[oc]);
+            out[oc] = fmaf(w[(oc * CIN + 2) * 9 + t], v.z, out[oc]);
+            if (CIN == 4) out[oc] = fmaf(w[(oc * CIN + 3) * 9 + t], v.w, out[oc]);
+        }
+    }
+}
+
+__device__ inline void bn_relu_store(float4 *plane, int pp, bool active, const float (&t)[kC], const float *__restrict__ bn) {
+    float u[kC];
+#pragma unroll
+    for (int c = 0; c < kC; c++) u[c] = fmaxf(t[c] * bn[c] + bn[kC + c], 0.f);
+    if (active) plane[pp] = make_float4(u[0], u[1], u[2], 0.f);
+    lds_sync();
+}
+
+// v2 residual block with ONE batch-norm and convA used twice (neural_network_vision_model.py:41-79)
+template <bool ROLL = false>
+__device__ inline void residual_block(float4 *plane, int pp, bool active, const float *__restrict__ wa,
+                                      const float *__restrict__ wb, const float *__restrict__ bn, float (&t)[kC]) {
+    float c[kC];
+    bn_relu_store(plane, pp, active, t, bn);
+    conv3x3<kC, ROLL>(plane, pp, wa, c);
+    lds_sync();                               // every lane has read its neighbours before the plane is rewritten
+    bn_relu_store(plane, pp, active, c, bn);
+    conv3x3<kC, ROLL>(plane, pp, wb, c);
+    lds_sync();
+    bn_relu_store(plane, pp, active, c, bn);
+    conv3x3<kC, ROLL>(plane, pp, wa, c);
+    lds_sync();
+#pragma unroll
+    for (int k = 0; k < kC; k++) t[k] = c[k] + t[k];
+}
+
+// The same convolutions on TAP-MAJOR weights: wt[(t * 3 + oc) * 4 + ic] (ic = 3 zero-padded when CIN == 3), one 16-byte LDS
+// read per (tap, output channel) instead of three or four scalar-width ones.  Operation order per output is unchanged
+// (taps 0..8, input channels 0..CIN-1 inside a tap): bit-identical to conv3x3.  One row of taps per loop trip.
+template <int CIN>
+__device__ inline void conv3x3_t(const float4 *plane, int pp, const float4 *__restrict__ wt, float (&out)[kC]) {
+#pragma unroll
+    for (int oc = 0; oc < kC; oc++) out[oc] = 0.f;
+#pragma unroll 1
+    for (int ty = 0; ty < 3; ty++) {
+        float4 v[3], w[3][kC];
+#pragma unroll
+        for (int tx = 0; tx < 3; tx++) {
+            v[tx] = plane[pp + (ty - 1) * kPad + (tx - 1)];
+#pragma unroll
+            for (int oc = 0; oc < kC; oc++) w[tx][oc] = wt[((ty * 3 + tx) * kC + oc)];
+        }
+#pragma unroll
+        for (int tx = 0; tx < 3; tx++)
+#pragma unroll
+            for (int oc = 0; oc < kC; oc++) {
+                out[oc] = fmaf(w[tx][oc].x, v[tx].x, out[oc]);
+                out[oc] = fmaf(w[tx][oc].y, v[tx].y, out[oc]);
+                out[oc] = fmaf(w[tx][oc].z, v[tx].z, out[oc]);
+                if (CIN == 4) out[oc] = fmaf(w[tx][oc].w, v[tx].w, out[oc]);
+            }
+    }
+}
+// tap-major copy of a [3][CIN][9] convolution weight piece (108 floats)
+template <int CIN>
+__device__ inline void tap_major(float *dst, const float *src, int tid, int nthreads) {
+    for (int i = tid; i < 9 * kC * 4; i += nthreads) {
+        const int t = i / (kC * 4), oc = (i / 4) % kC, ic = i & 3;
+        dst[i] = ic < CIN ? src[(oc * CIN + ic) * 9 + t] : 0.f;
+    }
+}
+__device__ inline void residual_block_t(float4 *plane, int pp, bool active, const float4 *__restrict__ wa,
+                                        const float4 *__restrict__ wb, const float *__restrict__ bn, float (&t)[kC]) {
+    float c[kC];
+    bn_relu_store(plane, pp, active, t, bn);
+    conv3x3_t<kC>(plane, pp, wa, c);
+    lds_sync();
+    bn_relu_store(plane, pp, active, c, bn);
+    conv3x3_t<kC>(plane, pp, wb, c);
+    lds_sync();
+    bn_relu_store(plane, pp, active, c, bn);
+    conv3x3_t<kC>(plane, pp, wa, c);
+    lds_sync();
+#pragma unroll
+    for (int k = 0; k < kC; k++) t[k] = c[k] + t[k];
+}
+
+// per-pixel min-max scaling across the channels (scale_to_bound_action with dim=1 on [B,3,7,7]: :494-503)
+__device__ inline void scale_channels(float (&t)[kC]) {
+    const float mn = fminf(fminf(t[0], t[1]), t[2]), mx = fmaxf(fmaxf(t[0], t[1]), t[2]);
+    float sc = mx - mn;
+    if (sc < 1e-5f) sc += 1e-5f;
+#pragma unroll
+    for (int c = 0; c < kC; c++) t[c] = (t[c] - mn) / sc;
+}
+
+// 1x1 convolution (with bias) of CIN input channels -> flattened [3*49] activations in LDS
+template <int CIN>
+__device__ inline void mix_to_flat(float *flat, int p, bool active, const float (&x)[4], const float *__restrict__ w,
+                                   const float *__restrict__ b) {
+#pragma unroll
+    for (int oc = 0; oc < kC; oc++) {
+        float s = 0.f;
+#pragma unroll
+        for (int ic = 0; ic < CIN; ic++) s = fmaf(w[oc * CIN + ic], x[ic], s);
+        s += b[oc];
+        if (active) flat[oc * kPix + p] = s;
+    }
+    lds_sync();
+}
+
+// acc = bias[lane] + sum_k W[k][lane] * act[k] as ONE k-ordered fma chain (acc = fma(w_k, a_k, acc), k = 0, 1, 2, ... from the
+// bias) -- rounding for rounding what the matrix cores compute when the layer is issued as v_mfma_f32_16x16x4_f32 steps
+// with the bias as C operand (measured on MI355X: profiles/r02_mfma_heads_ab.txt), so the wave-per-leaf kernel here and
+// the 16-leaf matrix-core towers of the single-launch vision search (smz_vision_search.hip) give bit-identical outputs.
+// The weights live in global memory / L2: the 16-byte loads of up to CH k-groups are issued back to back before the first
+// multiply-add, so a layer costs one or two L2 round trips instead of one per four k-groups.
+template <int CH>
+__device__ inline float dense_stream(const float *__restrict__ W, const float *__restrict__ bias, const float *act, int K4,
+                                     int OP, int lane) {
+    const float4 *w4 = reinterpret_cast<const float4 *>(W) + lane;
+    const float4 *a4 = reinterpret_cast<const float4 *>(act);
+    float acc = bias[lane];
+    const int n = K4 >> 2;
+    for (int q0 = 0; q0 < n; q0 += CH) {
+        float4 w[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) w[j] = w4[(size_t)min(q0 + j, n - 1) * OP];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            if (q0 + j < n) {
+                const float4 a = a4[q0 + j];
+                acc = fmaf(w[j].x, a.x, acc);
+                acc = fmaf(w[j].y, a.y, acc);
+                acc = fmaf(w[j].z, a.z, acc);
+                acc = fmaf(w[j].w, a.w, acc);
+            }
+        }
+    }
+    return acc;
+}
+
+// Linear(147,H) relu [Linear(H,H) relu] x L Linear(H,n_out): off[0..5] = W1,b1,Wm,bm,Wo,bo (float offsets)
+__device__ inline void tower(const float *weights, const int32_t *off, WaveLds &l, const smz_vision_desc &d, int lane,
+                             float (&acc)[1][1]) {
+    const int K4h = up4(d.H);
+    float y = dense_stream<19>(weights + off[0], weights + off[1], l.flat, kFlat4, d.OP, lane);
+    int cur = 0;
+    l.hid[0][lane] = lane < d.H ? fmaxf(y, 0.f) : 0.f;
+    lds_sync();
+    for (int i = 0; i < d.L; i++) {
+        y = dense_stream<16>(weights + off[2], weights + off[3], l.hid[cur], K4h, d.OP, lane);
+        cur ^= 1;
+        l.hid[cur][lane] = lane < d.H ? fmaxf(y, 0.f) : 0.f;
+        lds_sync();
+    }
+    acc[0][0] = dense_stream<16>(weights + off[4], weights + off[5], l.hid[cur], K4h, d.OP, lane);
+}
+
+// prediction / afterstate prediction on the hidden state in t (registers): policy (softmax) to dst_policy, returns value
+// `small`: where the convolution / batch-norm / 1x1 pieces are read from (the workgroup's LDS copy, or `weights`)
+__device__ inline float predict(const float *weights, const float *small, const smz_vision_desc &d,
+                                int net /*SMZ_V_PRE or SMZ_V_APR*/, WaveLds &l, int lane, int p, int pp, bool active,
+                                float (&t)[kC], float *dst_policy, bool want_value) {
+    const int32_t *o = d.off + SMZ_V_PRED_BASE + (net - SMZ_V_PRE) * SMZ_V_PRED_STRIDE;
+    const float *wa = uniform_ptr(small, o[SMZ_VP_RES_A]), *wb = uniform_ptr(small, o[SMZ_VP_RES_B]);
+    const float *bn = uniform_ptr(small, o[SMZ_VP_RES_BN]);
+    for (int i = 0; i < d.L; i++) residual_block(l.plane, pp, active, wa, wb, bn, t);
+    const float x[4] = {t[0], t[1], t[2], 0.f};
+    float acc[1][1];
+    float value = 0.f;
+    if (want_value) {
+        mix_to_flat<kC>(l.flat, p, active, x, uniform_ptr(small, o[SMZ_VP_VMIX_W]), uniform_ptr(small, o[SMZ_VP_VMIX_B]));
+        tower(weights, o + SMZ_VP_VTOWER, l, d, lane, acc);
+        value = decode_lanes<1>(acc[0], 0, d.S, lane);
+        lds_sync();
+    }
+    mix_to_flat<kC>(l.flat, p, active, x, uniform_ptr(small, o[SMZ_VP_PMIX_W]), uniform_ptr(small, o[SMZ_VP_PMIX_B]));
+    tower(weights, o + SMZ_VP_PTOWER, l, d, lane, acc);
+    softmax_lanes<1>(acc[0], d.A, lane, dst_policy);
+    return value;
+}
+
+__device__ inline void zero_wave_lds(WaveLds &l, int lane) {
+    for (int i = lane; i < kPad * kPad; i += smz_mlp::kWave) l.plane[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = lane; i < kFlat4; i += smz_mlp::kWave) l.flat[i] = 0.f;
+    lds_sync();
+}
+
+}  // namespace smz_vision

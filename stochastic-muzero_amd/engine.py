@@ -187,6 +187,24 @@ class SearchEngine:
                                                self._stream()))
         self._act_done = T
 
+    def search_vision(self, vision_desc, weights, hidden0, policy0, train=True, act_temperature=None):
+        """Whole search in one launch for `vision_model` heads (smz_search_vision): hidden0 [B,147] / policy0 [B,A] are
+        smz_vision_initial's outputs.  `act_temperature` as in search_mlp."""
+        hidden0 = self._f32(hidden0.reshape(self.B, -1), (self.B, self.S))
+        policy0 = self._f32(policy0, (self.B, self.A))
+        self._act_done = None
+        if act_temperature is None:
+            _lib.check(self.lib.smz_search_vision(self.h, C.byref(vision_desc), _ptr(weights), _ptr(hidden0), _ptr(policy0),
+                                                  int(bool(train)), self._stream()))
+            return
+        T = float(act_temperature)
+        tab = self._pow_table(T)
+        _lib.check(self.lib.smz_search_vision_act(self.h, C.byref(vision_desc), _ptr(weights), _ptr(hidden0), _ptr(policy0),
+                                                  int(bool(train)), T, None if tab is None else tab.ctypes.data_as(C.c_void_p),
+                                                  _ptr(self.action), _ptr(self.policy), _ptr(self.child_visits),
+                                                  _ptr(self.root_value), self._stream()))
+        self._act_done = T
+
     def root_stats(self):
         _lib.check(self.lib.smz_root_stats(self.h, _ptr(self.visits), _ptr(self.priors), _ptr(self.root_value),
                                            _ptr(self.child_reward), self._stream()))

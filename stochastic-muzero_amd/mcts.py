@@ -189,6 +189,24 @@ class BatchedMCTS(_Hyper):
                 self._single = False
                 warnings.warn("single-launch search does not fit in LDS for this batch geometry "
                               f"({self.num_trees} trees x {self.num_simulations} simulations): using the step-wise kernels")
+        # vision_model heads: representation per frame (its own launch), then the whole search in one launch
+        if (self.single_launch and isinstance(getattr(heads, "desc", None), _lib.VisionDesc) and self._single is not False
+                and self.num_trees <= self.single_launch_max_trees):
+            hidden, policy = heads.initial(observations)
+            eng = self._ensure_engine(policy.shape[1], hidden.shape[1])
+            if getattr(self, "_pending_seed", None) is not None:
+                eng.seed(self._pending_seed)
+                self._pending_seed = None
+            try:
+                eng.search_vision(heads.desc, heads.weights, hidden, policy, train=train, act_temperature=act_temperature)
+                self._single = True
+                return eng
+            except _lib.SmzError as err:
+                if err.code != _lib.SMZ_ERR_TOO_LARGE or self._single is True:
+                    raise
+                self._single = False
+                warnings.warn("single-launch vision search is outside its limits for this configuration "
+                              f"({err}): using the step-wise kernels")
         if not self.use_graph:
             self._search(observations, heads, train)
             return self.engine

@@ -642,3 +642,37 @@ def test_env_step_with_record_equals_step_then_pack():
     for a, b in zip(*out):
         assert np.array_equal(a, b)
     assert out[0][4][1].any() and not out[0][4][0].any() and out[0][3].any()
+
+
+@pytest.mark.parametrize("wname,B,sims", [("visionnet_L1_seed0", 1024, 50), ("visionnet_L1_seed0", 37, 12),
+                                          ("visionnet_L2_bn", 200, 16), ("visionnet_L1_seed0", 16, 0)])
+def test_vision_single_launch_search_equals_stepwise_search(wname, B, sims):
+    """smz_search_vision (whole vision search in one kernel: towers of 16 leaves on the matrix cores) against the
+    step-wise kernels (one wavefront per leaf, towers as k-ordered fma chains on the vector units): an f32-input MFMA is
+    that chain, so every tree, value and stream position must be identical -- two consecutive searches per engine."""
+    mcts_mod, model_mod, _, _ = _mods()
+    model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, wname + ".npz"))
+    heads = model.heads("cuda:0", backend="hip")
+    obs = torch.rand(B, 3, 98, 98, generator=torch.Generator().manual_seed(2)).cuda()
+    res = []
+    for single in (True, False):
+        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997,
+                                 root_exploration_fraction=0.25, use_graph=False, single_launch=single)
+        m.seed(np.arange(B, dtype=np.uint64) + 9)
+        for rep in range(2):
+            e = m.run(obs, heads, train=True, act_temperature=(1.0 if single and rep == 1 else None))
+        assert m._single is (True if single else None)
+        action, policy, cv, rv2 = (t.clone() for t in e.act(1.0))
+        visits, priors, rv, cr = e.root_stats()
+        torch.cuda.synchronize()
+        out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr, action, policy, cv)]
+        dumps = [e.dump_tree(i) for i in (0, B // 2, B - 1)]
+        states = [e.get_rng_state(i) for i in (0, B - 1)]
+        res.append((out, dumps, states))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for da, db in zip(res[0][1], res[1][1]):
+        for k in da:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+    for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
+        assert np.array_equal(ka, kb) and pa == pb
