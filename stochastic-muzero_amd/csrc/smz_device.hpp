@@ -8,8 +8,9 @@
 //
 // Data layout (HBM).  A tree is a header plus "child blocks"; a block holds the children of ONE node as a small
 // structure-of-arrays, so that one descent level touches one contiguous 64/128-byte block:
-//     root block   (A children): visit[A] | value_sum[A] | reward[A] | prior32[A] | child[A] | (pad) | prior64[A]
-//     expansion e  (K children): visit[K] | value_sum[K] | reward[K] | prior32[K] | child[K] | action[K]
+//     root block   (A children): (visit, value_sum)[A] | reward[A] | prior32[A] | child[A] | (pad) | prior64[A]
+//     expansion e  (K children): (visit, value_sum)[K] | reward[K] | prior32[K] | child[K] | action[K]
+// (the visit count and value sum of a child are adjacent: the backup updates both with ONE 8-byte store per level)
 // `child` = 1 + index of the expansion block holding that node's own children (0 = not expanded), so the block
 // just loaded already names the next block to load: one dependent memory round trip per level.  Node ids (used for
 // the hidden-state rows and by the debug dump) stay the creation-order ids of the reference-side goldens:
@@ -400,8 +401,8 @@ __device__ inline void root_init_tree(const Params &P, int tree, RNG &rng, const
     int32_t *vi = (int32_t *)rb;
     float *fs = (float *)rb;
     for (int a = 0; a < A; a++) {
-        vi[a] = 0;                 // visit
-        fs[A + a] = 0.f;           // value_sum
+        vi[2 * a] = 0;             // visit
+        fs[2 * a + 1] = 0.f;       // value_sum (interleaved with the visit count: one 8-byte store per backup level)
         fs[2 * A + a] = 0.f;       // reward
         fs[3 * A + a] = p[a];      // float32 prior
         vi[4 * A + a] = 0;         // child
@@ -456,8 +457,8 @@ __device__ inline void load_kids_dyn(const uint32_t *bp, int cnt, bool root, int
 #pragma unroll
     for (int j = 0; j < N; j++) {
         if (j < cnt) {
-            k.vis[j] = (int32_t)bp[j];
-            k.vsum[j] = __uint_as_float(bp[cnt + j]);
+            k.vis[j] = (int32_t)bp[2 * j];
+            k.vsum[j] = __uint_as_float(bp[2 * j + 1]);
             k.rew[j] = __uint_as_float(bp[2 * cnt + j]);
             k.pri[j] = __uint_as_float(bp[3 * cnt + j]);
             k.chd[j] = (int32_t)bp[4 * cnt + j];
@@ -481,8 +482,8 @@ __device__ inline void load_kids_static(const uint32_t *bp, Kids<N> &k) {
     }
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        k.vis[j] = (int32_t)w[j];
-        k.vsum[j] = __uint_as_float(w[N + j]);
+        k.vis[j] = (int32_t)w[2 * j];
+        k.vsum[j] = __uint_as_float(w[2 * j + 1]);
         k.rew[j] = __uint_as_float(w[2 * N + j]);
         k.pri[j] = __uint_as_float(w[3 * N + j]);
         k.chd[j] = (int32_t)w[4 * N + j];
@@ -691,8 +692,8 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, Tr
             nb4[2] = make_uint4(0u, 0u, (uint32_t)picks[0], (uint32_t)picks[1]);              // child, action
         } else {
             for (int j = 0; j < K; j++) {
-                nb[j] = 0u;                                  // visit
-                nb[K + j] = __float_as_uint(0.f);            // value_sum
+                nb[2 * j] = 0u;                              // visit
+                nb[2 * j + 1] = __float_as_uint(0.f);        // value_sum
                 nb[2 * K + j] = __float_as_uint(0.f);        // reward
                 float pj = 0.f;
                 for (int a = 0; a < A; a++) if (a == picks[j]) pj = p[a];
@@ -727,12 +728,11 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, Tr
                 const uint4 e4 = r4[q];
                 const int b = (int)e4.x >> 8, sl = (int)e4.x & 0xff;
                 const int cnt = (b == 0) ? A : K;
-                uint32_t *np = block_ptr(P, tb, b) + sl;
+                uint32_t *np = block_ptr(P, tb, b) + 2 * sl;
                 const float r = (i0 - q == len - 1) ? leaf_reward : __uint_as_float(e4.w);
                 const float nvs = __uint_as_float(e4.z) + v;
                 const int nvc = (int)e4.y + 1;
-                np[0] = (uint32_t)nvc;
-                np[cnt] = __float_as_uint(nvs);
+                *reinterpret_cast<uint2 *>(np) = make_uint2((uint32_t)nvc, __float_as_uint(nvs));     // (visit, value_sum)
                 const float qv = nvs / (float)nvc;
                 if (qv > mx) mx = qv;
                 if (qv < mn) mn = qv;
@@ -783,11 +783,10 @@ __device__ inline void backup_levels_lanes(const Params &P, int tree, int j, int
             const uint4 e4 = rec[i];
             const int b = (int)e4.x >> 8, sl = (int)e4.x & 0xff;
             const int cnt = (b == 0) ? A : K;
-            uint32_t *np = block_ptr(P, tb, b) + sl;
+            uint32_t *np = block_ptr(P, tb, b) + 2 * sl;
             const float nvs = __uint_as_float(e4.z) + vin;
             const int nvc = (int)e4.y + 1;
-            np[0] = (uint32_t)nvc;
-            np[cnt] = __float_as_uint(nvs);
+            *reinterpret_cast<uint2 *>(np) = make_uint2((uint32_t)nvc, __float_as_uint(nvs));         // (visit, value_sum)
             const float qv = nvs / (float)nvc;
             if (qv > mx) mx = qv;
             if (qv < mn) mn = qv;
@@ -813,7 +812,7 @@ __device__ inline void act_tree(const Params &P, int tree, RNG &rng, double temp
     const double *rp = (const double *)(rb + P.rp_off);
     double pol[MAXA], vis[MAXA], pri[MAXA];
     int32_t vc[MAXA];
-    for (int a = 0; a < A; a++) { vc[a] = (int32_t)rb[a]; vis[a] = (double)vc[a]; pri[a] = rp[a]; }
+    for (int a = 0; a < A; a++) { vc[a] = (int32_t)rb[2 * a]; vis[a] = (double)vc[a]; pri[a] = rp[a]; }
     const double vsum = np_sum<double, MAXA>(vis, A);
     const bool from_visits = !(vsum <= 1.0);
     for (int a = 0; a < A; a++) pol[a] = from_visits ? vis[a] : pri[a];

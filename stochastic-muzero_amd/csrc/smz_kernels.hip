@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits,
     const uint32_t *rb = tree_base(P, tree);
     const double *rp = (const double *)(rb + P.rp_off);
     for (int a = 0; a < P.A; a++) {
-        if (visits) visits[(size_t)tree * P.A + a] = (int32_t)rb[a];
+        if (visits) visits[(size_t)tree * P.A + a] = (int32_t)rb[2 * a];
         if (priors) priors[(size_t)tree * P.A + a] = rp[a];
         if (child_reward) child_reward[(size_t)tree * P.A + a] = __uint_as_float(rb[2 * P.A + a]);
     }
@@ -1828,7 +1828,7 @@ int smz_debug_dump_tree(smz_handle *h, int tree, smz_node_view *nodes, int cap, 
         for (int a = 0; a < A && 1 + a < cap; a++) {
             const uint32_t *rb = blob.data();
             const int c = (int)rb[4 * A + a];
-            nodes[1 + a] = smz_node_view{(int32_t)rb[a], f32(rb[A + a]), f32(rb[2 * A + a]), f32(rb[3 * A + a]),
+            nodes[1 + a] = smz_node_view{(int32_t)rb[2 * a], f32(rb[2 * a + 1]), f32(rb[2 * A + a]), f32(rb[3 * A + a]),
                                          c ? 1 + A + (c - 1) * K : 0, a};
         }
         for (int e = 0; e < hdr.n_exp; e++) {
@@ -1837,7 +1837,7 @@ int smz_debug_dump_tree(smz_handle *h, int tree, smz_node_view *nodes, int cap, 
                 const int id = 1 + A + e * K + j;
                 if (id >= cap) break;
                 const int c = (int)eb[4 * K + j];
-                nodes[id] = smz_node_view{(int32_t)eb[j], f32(eb[K + j]), f32(eb[2 * K + j]), f32(eb[3 * K + j]),
+                nodes[id] = smz_node_view{(int32_t)eb[2 * j], f32(eb[2 * j + 1]), f32(eb[2 * K + j]), f32(eb[3 * K + j]),
                                           c ? 1 + A + (c - 1) * K : 0, (int32_t)eb[5 * K + j]};
             }
         }
