@@ -369,14 +369,27 @@ def main():
         reps = max(1, min(args.steps, 8))
         if single:
             # dominant kernel = k_search_mlp (the whole search, one launch per env step): event pairs around each launch
+            # PER_PAIR back-to-back launches of that kernel ALONE between one pair (an event costs a barrier packet on
+            # each side, ~10 us; spread over PER_PAIR launches the mean agrees with rocprofv3's per-dispatch average).
+            PER_PAIR = 4
+            if wl["env"] == "image":
+                hidden0, policy0 = heads.initial(env.obs)          # the representation launch is not this kernel
+                def launch():
+                    eng.search_vision(heads.desc, heads.weights, hidden0, policy0, train=True, act_temperature=args.temperature)
+            else:
+                def launch():
+                    eng.search_mlp(heads.desc, heads.weights, env.obs, train=True, act_temperature=args.temperature)
             durs = []
             for _ in range(reps + 1):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda._sleep(2_000_000)      # the launch is queued behind this before e0 is reached
-                e0.record(); mcts.run(env.obs, heads, train=True); e1.record()
+                torch.cuda._sleep(2_000_000)      # the launches are queued behind this before e0 is reached
+                e0.record()
+                for _k in range(PER_PAIR):
+                    launch()
+                e1.record()
                 durs.append((e0, e1))
             torch.cuda.synchronize(dev)
-            ms = np.array([a.elapsed_time(b) for a, b in durs[1:]])
+            ms = np.array([a.elapsed_time(b) for a, b in durs[1:]]) / PER_PAIR
             mean_us = float(ms.mean() * 1e3)
             bytes_launch = (k2 + k5) * Bg * wl["sims"]
             kernel = ("k_search_vision<MAXA> (root expansion + num_simulations x [select, conv nets + MFMA towers, expand, backup] in one launch)"
@@ -429,14 +442,16 @@ def main():
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                            "bytes_per_launch": bytes_launch,
                            "mean_launch_us": mean_us, "median_launch_us": float(np.median(ms) * 1e3),
-                           "launches_timed": int(ms.size), "bytes_per_tree_select": k2,
+                           "launches_timed": int(ms.size) * (PER_PAIR if single else 1), "bytes_per_tree_select": k2,
                            "bytes_per_tree_expand_backup": k5, "mean_depth": depth,
                            "tree_kernel_alone": {"kernel": "k_expand_backup<MAXA,KS,true,AEX>", "mean_launch_us": tree_us,
                                                  "bytes_per_launch": tree_bytes,
                                                  "achieved": tree_bytes / (tree_us * 1e-6) / 1e9,
                                                  "frac": tree_bytes / (tree_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
-                           "method": "HIP event pairs on the launching (torch current) stream around each launch, "
-                                     "after the timed region; bytes = SURVEY 8d formula on this run's level histogram"}
+                           "method": "HIP event pairs on the launching (torch current) stream, after the timed region: "
+                                     "around 4 back-to-back launches of the search kernel alone (elapsed / 4), around each "
+                                     "launch for the step-wise tree kernel; bytes = SURVEY 8d formula on this run's level "
+                                     "histogram"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:                                # N=1 only (contract)
         out["cpu_baseline"] = cpu_baseline_vision(wl, model) if wl["env"] == "image" else cpu_baseline_mlp(wl, wpath)
     if rank == 0:

@@ -55,12 +55,29 @@ def mcts_kwargs(config, num_simulations=None):
                 custom_loop=m["custom_loop"])
 
 
-def make_env(name, num_envs, device, seed):
+def make_env(name, num_envs, device, seed, limit=0, on_end="continue"):
+    """The vectorised environment of a run: the built-in device-resident CartPole, or -- for any other name -- gymnasium
+    environments stepped on the host behind the pinned-memory adapter (envs.HostVecEnv; needs gymnasium installed)."""
     from importlib import import_module
     envs = import_module("stochastic-muzero_amd.envs")
     if name.startswith("CartPole"):
-        return envs.CartPoleVec(num_envs, device, seed=seed)
-    raise Exception(f"environment {name!r} needs gymnasium, which this engine does not bundle; built-in: CartPole-v1")
+        return envs.CartPoleVec(num_envs, device, seed=seed, on_end=on_end, limit=limit)
+    try:
+        import gymnasium as gym
+    except ImportError:
+        raise Exception(f"environment {name!r} needs gymnasium, which is not installed here; built-in: CartPole-v1 "
+                        "(host environments go through stochastic-muzero_amd.envs.HostVecEnv)")
+    made = [gym.make(name) for _ in range(num_envs)]
+    obs_dim = int(np_prod(made[0].observation_space.shape))
+    return envs.HostVecEnv(made, obs_dim, int(made[0].action_space.n), device, env_seed=seed, limit=limit,
+                           on_end="reset" if on_end == "continue" else on_end)
+
+
+def np_prod(shape):
+    n = 1
+    for v in shape:
+        n *= int(v)
+    return n
 
 
 def main(argv):
@@ -116,20 +133,24 @@ def main(argv):
                                      number_of_hidden_layer=mz["number_of_hidden_layer"], random_tag=lc["model_tag_number"])
         search = mcts_mod.BatchedMCTS(n_env, **mcts_kwargs(config))
         search.seed(np.arange(n_env, dtype=np.uint64) + np.uint64(config["random_seed"]["np_random_seed"]))
-        env = make_env(config["game"]["env"], n_env, device, config["random_seed"]["env_seed"])
-        steps = opts["steps"] or int(config["gameplay"]["limit_of_game_play"])
-        buffer, rewards = [], []
+        limit = int(config["gameplay"]["limit_of_game_play"])
+        steps = opts["steps"] or limit
+        # every env plays game after game inside an iteration's chunk (a finished game restarts at once)
+        env = make_env(config["game"]["env"], n_env, device, config["random_seed"]["env_seed"], limit=min(limit, steps),
+                       on_end="reset")
+        buffer = []
 
-        class _Sink:                          # stands where replay_buffer.save_game(g) is called (self_play.py:267-268)
+        class _Sink:                          # stands where the replay buffer is (self_play.py:267-268)
             def save_game(self, g):
                 buffer.append(g)
-        for ep in range(1, iters + 1):
-            T = sp.temperature_scheduler(lc["number_of_iteration"] + 1, ep, mode=lc["temperature_type"])
-            games, mean_reward = sp.self_play_iteration(env, model, search, T, steps, replay_buffer=_Sink())
-            rewards.append(mean_reward)
-            if lc["verbose"]:
-                print(f"EPOCH {ep} || selfplay reward: {mean_reward} || games in buffer: {len(buffer)}")
-        out["train"] = dict(iterations=iters, games=len(buffer), rewards=rewards)
+        model.save_model = lambda **k: None   # best-model gating writes checkpoints only when training is attached
+        epoch_pr, loss, reward, conf = sp.learning_cycle(
+            number_of_iteration=iters, number_of_self_play_before_training=lc["number_of_self_play_before_training"],
+            number_of_training_before_self_play=0, model_tag_number=lc["model_tag_number"], number_of_worker_selfplay="gpu",
+            temperature_type=lc["temperature_type"], verbose=bool(lc["verbose"]), muzero_model=model, gameplay=env,
+            monte_carlo_tree_search=search, replay_buffer=_Sink(), steps_per_iteration=steps,
+            model_directory=opts["checkpoint_dir"])
+        out["train"] = dict(iterations=iters, games=len(buffer), rewards=reward[1:])
     return out
 
 
