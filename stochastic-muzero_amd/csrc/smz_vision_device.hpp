@@ -169,52 +169,59 @@ __device__ inline void mix_to_flat(float *flat, int p, bool active, const float 
     lds_sync();
 }
 
-// acc = bias[lane] + sum_k W[k][lane] * act[k] as ONE k-ordered fma chain (acc = fma(w_k, a_k, acc), k = 0, 1, 2, ... from the
-// bias) -- rounding for rounding what the matrix cores compute when the layer is issued as v_mfma_f32_16x16x4_f32 steps
-// with the bias as C operand (measured on MI355X: profiles/r02_mfma_heads_ab.txt), so the wave-per-leaf kernel here and
-// the 16-leaf matrix-core towers of the single-launch vision search (smz_vision_search.hip) give bit-identical outputs.
-// The weights live in global memory / L2: the 16-byte loads of up to CH k-groups are issued back to back before the first
-// multiply-add, so a layer costs one or two L2 round trips instead of one per four k-groups.
+// acc = bias[lane] + sum_k W[k][lane] * act[k], summed as FOUR k-ordered fma chains over contiguous quarters of the inputs
+// (quarter length = the number of 4-input groups divided by four, rounded up: 10 + 10 + 10 + 7 groups for the 147-input
+// layer, 4 x 4 groups for a 64-wide one), chain 0 starting from the bias, the others from zero, combined as
+// (c0 + c1) + (c2 + c3).  This is rounding for rounding what the single-launch vision search (smz_vision_search.hip)
+// computes on the matrix cores -- one v_mfma_f32_4x4x1_16B_f32 per input and quarter, an f32-input MFMA being an fma with a
+// single rounding (measured on MI355X: tools/mfma4_probe.hip) -- so the wave-per-leaf kernel here and that kernel give
+// bit-identical outputs.  The weights live in global memory / L2: the 16-byte loads of CH groups of every quarter are
+// issued back to back before the first multiply-add, so a layer costs one or two L2 round trips.
 template <int CH>
 __device__ inline float dense_stream(const float *__restrict__ W, const float *__restrict__ bias, const float *act, int K4,
                                      int OP, int lane) {
     const float4 *w4 = reinterpret_cast<const float4 *>(W) + lane;
     const float4 *a4 = reinterpret_cast<const float4 *>(act);
-    float acc = bias[lane];
-    const int n = K4 >> 2;
-    for (int q0 = 0; q0 < n; q0 += CH) {
-        float4 w[CH];
+    const int n = K4 >> 2, pl = (n + 3) >> 2;
+    float c[4] = {bias[lane], 0.f, 0.f, 0.f};
+    for (int q0 = 0; q0 < pl; q0 += CH) {
+        float4 w[4][CH];
 #pragma unroll
-        for (int j = 0; j < CH; j++) w[j] = w4[(size_t)min(q0 + j, n - 1) * OP];
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < CH; j++) {
-            if (q0 + j < n) {
-                const float4 a = a4[q0 + j];
-                acc = fmaf(w[j].x, a.x, acc);
-                acc = fmaf(w[j].y, a.y, acc);
-                acc = fmaf(w[j].z, a.z, acc);
-                acc = fmaf(w[j].w, a.w, acc);
+            for (int j = 0; j < CH; j++) w[i][j] = w4[(size_t)min(i * pl + q0 + j, n - 1) * OP];
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int gk = i * pl + q0 + j;
+                if (q0 + j < pl && gk < n) {
+                    const float4 a = a4[gk];
+                    c[i] = fmaf(w[i][j].x, a.x, c[i]);
+                    c[i] = fmaf(w[i][j].y, a.y, c[i]);
+                    c[i] = fmaf(w[i][j].z, a.z, c[i]);
+                    c[i] = fmaf(w[i][j].w, a.w, c[i]);
+                }
             }
-        }
     }
-    return acc;
+    return (c[0] + c[1]) + (c[2] + c[3]);
 }
 
 // Linear(147,H) relu [Linear(H,H) relu] x L Linear(H,n_out): off[0..5] = W1,b1,Wm,bm,Wo,bo (float offsets)
 __device__ inline void tower(const float *weights, const int32_t *off, WaveLds &l, const smz_vision_desc &d, int lane,
                              float (&acc)[1][1]) {
     const int K4h = up4(d.H);
-    float y = dense_stream<19>(weights + off[0], weights + off[1], l.flat, kFlat4, d.OP, lane);
+    float y = dense_stream<5>(weights + off[0], weights + off[1], l.flat, kFlat4, d.OP, lane);
     int cur = 0;
     l.hid[0][lane] = lane < d.H ? fmaxf(y, 0.f) : 0.f;
     lds_sync();
     for (int i = 0; i < d.L; i++) {
-        y = dense_stream<16>(weights + off[2], weights + off[3], l.hid[cur], K4h, d.OP, lane);
+        y = dense_stream<4>(weights + off[2], weights + off[3], l.hid[cur], K4h, d.OP, lane);
         cur ^= 1;
         l.hid[cur][lane] = lane < d.H ? fmaxf(y, 0.f) : 0.f;
         lds_sync();
     }
-    acc[0][0] = dense_stream<16>(weights + off[4], weights + off[5], l.hid[cur], K4h, d.OP, lane);
+    acc[0][0] = dense_stream<4>(weights + off[4], weights + off[5], l.hid[cur], K4h, d.OP, lane);
 }
 
 // prediction / afterstate prediction on the hidden state in t (registers): policy (softmax) to dst_policy, returns value

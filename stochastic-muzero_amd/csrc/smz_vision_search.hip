@@ -3,21 +3,25 @@
 //
 // Why a second single-launch kernel: step-wise, a vision simulation round is two launches (k_vision_recurrent 20 us +
 // k_expand_backup 14 us at 1024 trees) and every leaf wavefront streams ~180 KB of tower weights out of L2 -- 180 MB per
-// round, the L2 running at 8.5 TB/s for weights that never change.  Here a workgroup of 8 wavefronts owns 16 trees for
-// the whole search:
+// round, the L2 running at 8.5 TB/s for weights that never change.  Here a workgroup of FOUR wavefronts owns four trees for
+// the whole search (1024 trees = one workgroup per CU, one wavefront per SIMD, 512 registers per lane):
 //   * tree phases (expand + backup, select) as in k_search_mlp: the tree's lane, path records and staged random words in LDS;
 //   * the convolutional part of a leaf's networks (3x7x7 hidden state, one pixel per lane) by the leaf's own wavefront,
 //     the code of the wave-per-leaf kernel (smz_vision_device.hpp);
 //   * the five 147 -> H -> [H ->] S/A towers (dynamics reward | prediction value, policy | afterstate-prediction value,
-//     policy) for all 16 leaves AT ONCE on the matrix cores: v_mfma_f32_16x16x4_f32 with A = 16 output neurons x 4 inputs
-//     of a weight matrix, B = 4 inputs x 16 leaves from a k-major LDS tile, C = bias.  The first-layer matrices (740 of
-//     the 1188 fragments: 111 VGPRs per wave) stay in REGISTERS for the whole search; the small second / output matrices
-//     are re-read from L2 once per round and workgroup (112 KB instead of 16 x 180 KB).  A tower no leaf of the workgroup
-//     needs this round (all leaves on one branch) is skipped.
-// f32 in, f32 accumulate: an f32-input MFMA is a k-ordered fma chain, exactly what dense_stream() of the wave-per-leaf
-// kernel computes -- the two paths give bit-identical searches (tests/test_gpu_end_to_end.py).
+//     policy) for the four leaves AT ONCE on the matrix cores with v_mfma_f32_4x4x1_16B_f32: sixteen 4x4 outer products per
+//     instruction, block = 4 output neurons (A operand: one weight per lane) x 4 leaves (B operand: one activation per
+//     lane), one input per instruction, accumulators = 4 registers per lane.  Every lane carries useful work (a
+//     16x16x4 tile would be three quarters empty with four leaves: measured 0.96 ms per search against 0.8 ms).
+//     A layer's inputs are cut into four contiguous quarters summed separately -- dense_stream() of the wave-per-leaf
+//     kernel does the same -- which turns a 64-neuron layer into four 64-lane rows; wave w owns tower w (rows = quarters,
+//     combined in-lane) and a quarter of tower 4's neurons (one row, quarters in the four 16-lane groups, combined with two
+//     cross-lane exchanges).  ALL weights of the wave's rows stay in REGISTERS for the whole search: 200 + 80 + 32 per lane.
+//     A tower no leaf of the workgroup needs this round (all leaves on one branch) is skipped.
+// f32 in, f32 accumulate, one rounding per multiply-add: the two paths give bit-identical searches
+// (tests/test_gpu_end_to_end.py).
 // Limits of this kernel (anything else runs step-wise): maxium_action_sample == 2, A <= 4, S <= 32, H <= 64,
-// SMZ_RNG_MT19937_NUMPY, LDS working set <= 160 KB (about 250 simulations).
+// SMZ_RNG_MT19937_NUMPY, LDS working set <= 160 KB.
 #define SMZ_PART 5
 #include "smz_kernels.hip"
 #include "smz_vision_device.hpp"
@@ -29,6 +33,7 @@ using smz_mlp::up4;
 using smz_vision::conv3x3;
 using smz_vision::kC;
 using smz_vision::kFlat;
+using smz_vision::kFlat4;
 using smz_vision::kN;
 using smz_vision::kPad;
 using smz_vision::kPix;
@@ -39,48 +44,33 @@ using smz_vision::uniform_ptr;
 
 namespace {
 
-constexpr int kVL = 16;                              // columns of an MFMA tile = leaf slots of a workgroup
+constexpr int kVW = 4;                               // wavefronts = trees = leaf slots of a workgroup
 constexpr int kTowers = 5;                           // 0 dyn reward | 1 pre value | 2 pre policy | 3 apr value | 4 apr policy
-constexpr int kFk = 148, kYS = 36;                   // flat inputs per tower (147 + pad); raw-output row stride (floats)
-constexpr int kJobs = 4 * kTowers;                   // (tower, output tile of 16 neurons) pairs of a 64-wide layer
-constexpr int kOutJobs = 8;                          // output-layer (tower, tile) pairs: (0,0) (0,1) (1,0) (1,1) (2,0) (3,0) (3,1) (4,0)
-#ifndef SMZ_VISION_ROLL
-#define SMZ_VISION_ROLL 1
-#endif
-constexpr bool kRollConv = SMZ_VISION_ROLL != 0;     // nine convolution taps as a rolled loop (register relief) or unrolled
-// Geometry: VW wavefronts x VT trees per workgroup (VW * VT <= 16 leaves; the other tile columns stay zero).
-//   <4, 1>: one wavefront per SIMD -> 512 VGPRs each: ALL tower fragments of the wave's jobs stay in registers for the whole
-//           search (5 first-layer + 5 hidden-layer + 2 output jobs = 297 VGPRs); 4 trees per workgroup, so 1024 trees fill
-//           the 256 CUs.  Three quarters of every tile's columns are empty -- the matrix pipe has nothing else to do.
-//   <8, 2>: 16 trees per workgroup, full tiles, 256 VGPRs per wave: one resident first-layer job, the rest re-read from L2.
-template <int VW> struct VGeo {
-    static constexpr int r1 = VW == 4 ? 5 : 1;       // resident first-layer jobs per wave
-    static constexpr int j1 = (kJobs + VW - 1) / VW; // first-layer (and hidden-layer) jobs per wave
-    static constexpr int rm = VW == 4 ? 5 : 0;       // resident hidden-layer jobs
-    static constexpr int jo = kOutJobs / VW;         // output jobs per wave
-    static constexpr int ro = VW == 4 ? 2 : 0;       // resident output jobs
-};
+constexpr int kP1 = 40;                              // inputs per quarter of the 147-input layer (10 groups of four)
+constexpr int kFS = 164;                             // floats per (input kind, leaf) row of the flat tile: 4 x 40 + bank spread
+constexpr int kHS = 68;                              // floats per (tower, leaf) row of a hidden tile: 64 + bank spread
+constexpr int kYS = 36;                              // floats per (tower, leaf) row of the raw outputs
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct VisLds {                                      // float offsets from the dynamic LDS base
     int small, pbc, wave, per_wave, plane, pv, rng, outs, F, H1, H2, Y, br, total;
 };
-__host__ __device__ inline VisLds vis_lds(const Params &P, int A, int VW, int VT) {
+__host__ __device__ inline VisLds vis_lds(const Params &P, int A) {
     VisLds m;
     m.small = 0;
     m.pbc = kSmallMax + 10 * 108;                                 // (+ tap-major copies of the ten 3x3 convolution pieces)
     m.wave = m.pbc + r4(2 * 2 * (P.sims + 2));
     m.plane = 0;                                                  // float4 plane[81] -> 324 floats
     m.pv = r4(kPad * kPad * 4);
-    m.rng = m.pv + VT * P.P * 4;
-    m.outs = m.rng + r4(VT * kRngStride);
-    m.per_wave = m.outs + r4(VT * (A + 2));
-    m.F = m.wave + VW * m.per_wave;
-    m.H1 = m.F + 3 * kFk * kVL;
-    m.H2 = m.H1 + kTowers * 64 * kVL;
-    m.Y = m.H2 + kTowers * 64 * kVL;
-    m.br = m.Y + kTowers * kVL * kYS + 64;                        // (+64: the tails read a full wave width of a row)
-    m.total = m.br + kVL;
+    m.rng = m.pv + P.P * 4;
+    m.outs = m.rng + r4(kRngStride);
+    m.per_wave = m.outs + r4(A + 2);
+    m.F = m.wave + kVW * m.per_wave;
+    m.H1 = m.F + 3 * kVW * kFS;
+    m.H2 = m.H1 + kTowers * kVW * kHS;
+    m.Y = m.H2 + kTowers * kVW * kHS;
+    m.br = m.Y + kTowers * kVW * kYS + 64;                        // (+64: the tails read a full wave width of a row)
+    m.total = m.br + kVW;
     return m;
 }
 
@@ -91,53 +81,80 @@ __device__ inline int tower_off(int t) {             // index of a tower's six o
 __device__ inline int tower_input(int t) { return t == 0 ? 0 : ((t == 1 || t == 3) ? 1 : 2); }   // which flat tile feeds it
 __device__ inline bool tower_dyn(int t) { return t < 3; }
 
-// element (k, o) of a packed tower matrix (4-way interleaved input-major, OP = 64); zero beyond its K rows
-__device__ inline float tw(const float *base, int k, int o, int K4) { return k < K4 ? base[((k >> 2) * kWave + o) * 4 + (k & 3)] : 0.f; }
-
-// NJ (1 or 2) (tower, tile) jobs of a layer at once: KSTEPS MFMA steps each over the k-major tiles bt[j] with A fragments
-// wf[j].  Two jobs give two independent accumulator chains (an f32 MFMA has a 40-cycle dependent latency against a 32-cycle
-// issue interval), and the B operands of chunk c + 1 are read from LDS before the products of chunk c are issued.
-template <int KSTEPS, int NJ>
-__device__ inline void tower_layers(const float *const (&wf)[NJ], const float *const (&bt)[NJ], v4f (&acc)[NJ], int g, int i) {
-    constexpr int CH = 8, NCH = (KSTEPS + CH - 1) / CH;
-    float b[2][NJ][CH];
+// Weights of one 64-lane row: inputs part * pl4 + (0 .. NS-1) of output neuron o of a packed tower matrix (4-way interleaved
+// input-major, 64 outputs wide, K4 input rows); zero beyond the quarter, beyond the matrix, and for a lane without work.
+template <int NS>
+__device__ inline void load_row(float (&w)[NS], const float *W, int o, int part, int pl4, int K4, bool on) {
 #pragma unroll
-    for (int j = 0; j < NJ; j++)
-#pragma unroll
-        for (int kk = 0; kk < CH; kk++) if (kk < KSTEPS) b[0][j][kk] = bt[j][(4 * kk + g) * kVL + i];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        if (c + 1 < NCH) {
-#pragma unroll
-            for (int j = 0; j < NJ; j++)
-#pragma unroll
-                for (int kk = 0; kk < CH; kk++)
-                    if ((c + 1) * CH + kk < KSTEPS) b[(c + 1) & 1][j][kk] = bt[j][(4 * ((c + 1) * CH + kk) + g) * kVL + i];
-        }
-#pragma unroll
-        for (int kk = 0; kk < CH; kk++)
-#pragma unroll
-            for (int j = 0; j < NJ; j++)
-                if (c * CH + kk < KSTEPS) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][c * CH + kk], b[c & 1][j][kk], acc[j], 0, 0, 0);
+    for (int s = 0; s < NS; s++) {
+        const int k = part * pl4 + s;
+        w[s] = (on && s < pl4 && k < K4) ? W[((k >> 2) * kWave + o) * 4 + (k & 3)] : 0.f;
     }
 }
-template <int KSTEPS>
-__device__ inline v4f tower_layer(const float (&wf)[KSTEPS], const float *bt, v4f acc, int g, int i) {
-    const float *const w[1] = {wf}, *const t[1] = {bt};
-    v4f a[1] = {acc};
-    tower_layers<KSTEPS, 1>(w, t, a, g, i);
-    return a[0];
-}
-// A fragments of one (tower, tile) job straight from the packed buffer in L2
-template <int KSTEPS>
-__device__ inline void load_frags(float (&wf)[KSTEPS], const float *W, int o, int g, int K4) {
+
+// NR rows at once, rows R0 .. R0 + NR - 1 of w / bx / acc: NS inputs each.  bx[r] = this lane's activations of row r in LDS
+// (its leaf's row of the tile, at the quarter's first input; 16-byte aligned).  One v_mfma_f32_4x4x1 per row and input; the
+// NR accumulator chains are independent (one wave issues one such MFMA per ~8.5 cycles from three chains on: mfma4_probe),
+// and the activations of the next four inputs are read before the products of the current four are issued.
+template <int NS, int NR, int R0, int NW>
+__device__ inline void rows_mfma(const float (&w)[NW][NS], const float *const (&bx)[NW], v4f (&acc)[NW]) {
+    constexpr int NC = NS / 4;
+    float4 b[2][NR];
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk++) wf[kk] = tw(W, 4 * kk + g, o, K4);
+    for (int r = 0; r < NR; r++) b[0][r] = *reinterpret_cast<const float4 *>(bx[R0 + r]);
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (c + 1 < NC) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) b[(c + 1) & 1][r] = *reinterpret_cast<const float4 *>(bx[R0 + r] + 4 * (c + 1));
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) acc[R0 + r] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[R0 + r][4 * c + 0], b[c & 1][r].x, acc[R0 + r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; r++) acc[R0 + r] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[R0 + r][4 * c + 1], b[c & 1][r].y, acc[R0 + r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; r++) acc[R0 + r] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[R0 + r][4 * c + 2], b[c & 1][r].z, acc[R0 + r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; r++) acc[R0 + r] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[R0 + r][4 * c + 3], b[c & 1][r].w, acc[R0 + r], 0, 0, 0);
+    }
+}
+__device__ inline v4f xadd(v4f v, int mask) {         // v + (v of lane ^ mask), the four registers
+    return v4f{v[0] + __shfl_xor(v[0], mask), v[1] + __shfl_xor(v[1], mask), v[2] + __shfl_xor(v[2], mask), v[3] + __shfl_xor(v[3], mask)};
+}
+__device__ inline v4f relu4(v4f v) { return v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+__device__ inline v4f bias4(const float *b, bool on) { return on ? v4f{b[0], b[1], b[2], b[3]} : v4f{0.f, 0.f, 0.f, 0.f}; }
+
+// A 64-neuron layer of the five towers for the workgroup's four leaves: this wave's five rows (see the file header).
+//   rows 0..3: tower `wave`, quarter = row, neuron = lane  -> combined in-lane, every lane stores four neurons of its leaf
+//   row 4:     tower 4, quarter = lane / 16, neuron = 16 * wave + lane % 16 -> combined across the 16-lane groups
+// in: per-(tower | input kind, leaf) rows of `stride` floats; out: rows of kHS floats, relu applied.
+template <int NS>
+__device__ inline void tower_layer64(const float (&w)[5][NS], const float *in, int stride, bool by_kind, int pl4, const float *bias_a,
+                                     const float *bias_b, float *out, int wave, int lane, bool need_a, bool need_b) {
+    const int blk = lane >> 2, lf = lane & 3, grp = lane >> 4;
+    const int ia = by_kind ? tower_input(wave) : wave, ib = by_kind ? tower_input(4) : 4;
+    const float *xa = in + (ia * kVW + lf) * stride, *xb = in + (ib * kVW + lf) * stride + grp * pl4;
+    const float *const bx[5] = {xa, xa + pl4, xa + 2 * pl4, xa + 3 * pl4, xb};
+    v4f acc[5];
+    acc[0] = bias4(bias_a + 4 * blk, true);
+    acc[1] = acc[2] = acc[3] = v4f{0.f, 0.f, 0.f, 0.f};
+    acc[4] = bias4(bias_b + 16 * wave + 4 * (blk & 3), grp == 0);
+    if (need_a && need_b) rows_mfma<NS, 5, 0>(w, bx, acc);            // (wave-uniform)
+    else if (need_a) rows_mfma<NS, 4, 0>(w, bx, acc);
+    else if (need_b) rows_mfma<NS, 1, 4>(w, bx, acc);
+    if (need_a) {
+        const v4f y = relu4((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        *reinterpret_cast<v4f *>(out + (wave * kVW + lf) * kHS + 4 * blk) = y;
+    }
+    if (need_b) {
+        const v4f y = relu4(xadd(xadd(acc[4], 16), 32));
+        if (grp == 0) *reinterpret_cast<v4f *>(out + (4 * kVW + lf) * kHS + 16 * wave + 4 * blk) = y;
+    }
 }
 
 __device__ inline void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // LDS hand-offs only
 
-// 1x1 convolution (with bias) of CIN channels -> column `leaf` of a k-major flat tile (torch's Flatten of [3,7,7])
+// 1x1 convolution (with bias) of CIN channels -> row `leaf` of a flat tile (torch's Flatten of [3,7,7])
 template <int CIN>
 __device__ inline void mix_to_tile(float *tile, int leaf, int p, bool active, const float (&x)[4], const float *__restrict__ w,
                                    const float *__restrict__ b) {
@@ -147,31 +164,25 @@ __device__ inline void mix_to_tile(float *tile, int leaf, int p, bool active, co
 #pragma unroll
         for (int ic = 0; ic < CIN; ic++) s = fmaf(w[oc * CIN + ic], x[ic], s);
         s += b[oc];
-        if (active) tile[(oc * kPix + p) * kVL + leaf] = s;
+        if (active) tile[leaf * kFS + oc * kPix + p] = s;
     }
 }
 
 extern __shared__ float4 smz_vsearch_lds4[];
 
-__device__ inline void out_job(int j, int &t, int &mt) {   // (tower, tile) of output job j
-    t = j < 2 ? 0 : (j < 4 ? 1 : (j == 4 ? 2 : (j < 7 ? 3 : 4)));
-    mt = (j == 1 || j == 3 || j == 6) ? 1 : 0;
-}
-
-template <int MAXA, int VW, int VT>
-__global__ void __launch_bounds__(VW *kWave) k_search_vision(Params Pin, smz_vision_desc d, const float *__restrict__ weights,
-                                                             const float *__restrict__ hidden0, const float *__restrict__ policy0,
-                                                             int train, ActOut act) {
-    constexpr int KS = 2;
-    using G = VGeo<VW>;
-    static_assert(VW * VT <= kVL && (VT == 1 || VT == 2), "workgroup geometry");
+template <int MAXA>
+__global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vision_desc d, const float *__restrict__ weights,
+                                                              const float *__restrict__ hidden0, const float *__restrict__ policy0,
+                                                              int train, ActOut act) {
+    constexpr int KS = 2, VT = 1;
     Params P = Pin;
     P.K = KS; P.tpw = VT;
     fix_layout(P, false, true);
     float *lds = reinterpret_cast<float *>(smz_vsearch_lds4);
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int A = P.A, S = d.S, K4h = up4(d.H);
-    const VisLds ml = vis_lds(P, A, VW, VT);
+    const int plh4 = 4 * (((K4h >> 2) + 3) >> 2);                     // inputs per quarter of an H-input layer (16 for H = 64)
+    const VisLds ml = vis_lds(P, A);
     // ---- one-time staging: small weights, pb_c table (+ reciprocals), zeroed tiles ---------------------------------------
     for (int i = threadIdx.x; i < d.small_floats / 4; i += blockDim.x)
         reinterpret_cast<float4 *>(lds + ml.small)[i] = reinterpret_cast<const float4 *>(weights)[i];
@@ -181,7 +192,7 @@ __global__ void __launch_bounds__(VW *kWave) k_search_vision(Params Pin, smz_vis
         pbc_lds[i] = P.pbc_sqrt[i];
         pbc_lds[n_pbc + i] = i > 0 ? 1.0 / (double)i : 0.0;
     }
-    for (int i = threadIdx.x + ml.wave; i < ml.total; i += blockDim.x) lds[i] = 0.f;     // planes' borders, pad rows / empty columns
+    for (int i = threadIdx.x + ml.wave; i < ml.total; i += blockDim.x) lds[i] = 0.f;     // planes' borders, pad inputs of the tiles
     // tap-major copies of the 3x3 convolutions: [net 0..1 transition: conv_in, res_a, res_b | net 0..1 prediction: res_a, res_b]
     float *tm = lds + kSmallMax;
     for (int n = 0; n < 2; n++) {
@@ -203,41 +214,41 @@ __global__ void __launch_bounds__(VW *kWave) k_search_vision(Params Pin, smz_vis
     float *F = lds + ml.F, *H1 = lds + ml.H1, *H2 = lds + ml.H2, *Y = lds + ml.Y;
     int *br = reinterpret_cast<int *>(lds + ml.br);
     const int slot = A + 2;
-    const int g = lane >> 4, li = lane & 15;
-    // ---- register-resident fragments of this wave's jobs (job q of a layer = pair number wave + VW * q) -------------------
-    float w1[G::r1][37], wmr[G::rm > 0 ? G::rm : 1][16], wor[G::ro > 0 ? G::ro : 1][16];
+    const int blk = lane >> 2, lf = lane & 3;
+    // ---- register-resident weights of this wave's rows ---------------------------------------------------------------------
+    const int32_t *offa = d.off + tower_off(wave), *offb = d.off + tower_off(4);
+    float w1[5][kP1], wm[5][16], wo[2][16];
 #pragma unroll
-    for (int q = 0; q < G::r1; q++) {
-        const int j = wave + VW * q;
-        load_frags<37>(w1[q], weights + d.off[tower_off(j >> 2)], 16 * (j & 3) + li, g, kFk);
-    }
+    for (int r = 0; r < 4; r++) load_row<kP1>(w1[r], weights + offa[0], lane, r, kP1, kFlat4, true);
+    load_row<kP1>(w1[4], weights + offb[0], 16 * wave + (lane & 15), lane >> 4, kP1, kFlat4, true);
 #pragma unroll
-    for (int q = 0; q < G::rm; q++) {
-        const int j = wave + VW * q;
-        load_frags<16>(wmr[q], weights + d.off[tower_off(j >> 2) + 2], 16 * (j & 3) + li, g, d.L > 0 ? K4h : 0);
-    }
-#pragma unroll
-    for (int q = 0; q < G::ro; q++) {
-        int t, mt;
-        out_job(wave + VW * q, t, mt);
-        load_frags<16>(wor[q], weights + d.off[tower_off(t) + 4], 16 * mt + li, g, K4h);
+    for (int r = 0; r < 4; r++) load_row<16>(wm[r], weights + offa[2], lane, r, plh4, d.L > 0 ? K4h : 0, true);
+    load_row<16>(wm[4], weights + offb[2], 16 * wave + (lane & 15), lane >> 4, plh4, d.L > 0 ? K4h : 0, true);
+    // output layer: waves 0..2 = the 32-wide outputs of towers 0 | 1 | 3 (row = quarters 0,1 | 2,3 in the two half-waves,
+    // neuron = lane % 32); wave 3 = the A-wide policy outputs of towers 2 (lanes 0..15) and 4 (lanes 16..31), quarter =
+    // (lane / 4) % 4, neuron = lane % 4
+    const int t_out = wave == 0 ? 0 : (wave == 1 ? 1 : 3);
+    const int32_t *offo = d.off + tower_off(wave < 3 ? t_out : ((lane & 16) ? 4 : 2));
+    if (wave < 3) {
+        load_row<16>(wo[0], weights + offo[4], lane & 31, lane >> 5, plh4, K4h, true);
+        load_row<16>(wo[1], weights + offo[4], lane & 31, 2 + (lane >> 5), plh4, K4h, true);
+    } else {
+        load_row<16>(wo[0], weights + offo[4], lane & 3, (lane >> 2) & 3, plh4, K4h, lane < 32);
+        load_row<16>(wo[1], weights + offo[4], 0, 0, plh4, K4h, false);
     }
     __syncthreads();
 
-    const int tree0 = (blockIdx.x * VW + wave) * VT;
+    const int tree0 = blockIdx.x * kVW + wave;
     const int tree = tree0 + lane;
     const bool valid = lane < VT && tree < P.B && tree_active(P, tree);
-    const bool live0 = __shfl((int)valid, 0) != 0, live1 = VT > 1 && __shfl((int)valid, 1) != 0;
+    const bool live0 = __shfl((int)valid, 0) != 0;
     const bool active = lane < kPix;
     const int p = active ? lane : kPix - 1, pp = (p / kN + 1) * kPad + (p % kN + 1);
 
     // ---- root: hidden state and policy come from smz_vision_initial (one workgroup per frame) ---------------------------
-#pragma unroll
-    for (int r = 0; r < VT; r++) {
-        if (!(r ? live1 : live0)) continue;                              // wave-uniform
-        const int row = tree0 + r;
-        for (int k = lane; k < kFlat; k += kWave) P.hidden[(size_t)row * P.N * P.hs + k] = hidden0[(size_t)row * kFlat + k];
-        if (lane < A) outs[r * slot + lane] = policy0[(size_t)row * A + lane];
+    if (live0) {                                                         // wave-uniform
+        for (int k = lane; k < kFlat; k += kWave) P.hidden[(size_t)tree0 * P.N * P.hs + k] = hidden0[(size_t)tree0 * kFlat + k];
+        if (lane < A) outs[lane] = policy0[(size_t)tree0 * A + lane];
     }
     lds_sync();
     int packed = wave_stage_rng<false>(P, tree, valid, rng_tile);
@@ -275,18 +286,14 @@ __global__ void __launch_bounds__(VW *kWave) k_search_vision(Params Pin, smz_vis
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         StagePre<VT> pre;
         stage_issue<VT, false>(P, tree, valid, packed, pre);
-        // ---- convolutional part, one leaf after the other: flat inputs of the leaf's towers into the k-major tiles ---------
-        const bool dyn0 = __builtin_amdgcn_readlane(L.branch, 0) != 0, dyn1 = VT > 1 && __builtin_amdgcn_readlane(L.branch, 1) != 0;
-#pragma unroll 1
-        for (int r = 0; r < VT; r++) {                                   // (rolled: one copy of the convolution code)
-            const int leaf = VT * wave + r;
-            const int parent = __shfl(L.parent_id, r), actn = __shfl(L.action, r);
-            const int leaf_id = __shfl(L.leaf_id, r);
-            const bool dyn = r ? dyn1 : dyn0, liv = r ? live1 : live0;
-            if (lane == 0) br[leaf] = liv ? (dyn ? 1 : 0) : -1;
-            if (!liv) continue;                                          // wave-uniform: the column stays zero
-            const int row = tree0 + r;
-            const float *hrow = P.hidden + ((size_t)row * P.N + parent) * P.hs;
+        // ---- convolutional part of this wave's leaf: flat inputs of its towers into the tiles ------------------------------
+        const bool dyn = __builtin_amdgcn_readlane(L.branch, 0) != 0;
+        const int leaf = wave;
+        if (lane == 0) br[leaf] = live0 ? (dyn ? 1 : 0) : -1;
+        if (live0) {                                                     // wave-uniform: a dead leaf's rows stay zero
+            const int parent = __shfl(L.parent_id, 0), actn = __shfl(L.action, 0);
+            const int leaf_id = __shfl(L.leaf_id, 0);
+            const float *hrow = P.hidden + ((size_t)tree0 * P.N + parent) * P.hs;
             const float a_plane = (float)(actn + 1) / (float)d.A;        // muzero_model.py:511-522
             float x[4] = {hrow[p], hrow[kPix + p], hrow[2 * kPix + p], a_plane};
             const int32_t *o = d.off + SMZ_V_TRANS_BASE + (dyn ? 0 : SMZ_V_TRANS_STRIDE);
@@ -311,7 +318,7 @@ __global__ void __launch_bounds__(VW *kWave) k_search_vision(Params Pin, smz_vis
             for (int c = 0; c < kC; c++) t[c] = fmaxf(t[c], 0.f);
             scale_channels(t);
             if (active) {
-                float *ho = P.hidden + ((size_t)row * P.N + leaf_id) * P.hs;
+                float *ho = P.hidden + ((size_t)tree0 * P.N + leaf_id) * P.hs;
                 ho[p] = t[0]; ho[kPix + p] = t[1]; ho[2 * kPix + p] = t[2];
             }
             const int32_t *q = d.off + SMZ_V_PRED_BASE + (dyn ? 0 : SMZ_V_PRED_STRIDE);
@@ -321,143 +328,55 @@ __global__ void __launch_bounds__(VW *kWave) k_search_vision(Params Pin, smz_vis
                 for (int i = 0; i < d.L; i++) smz_vision::residual_block_t(plane, pp, active, wa, wb, bn, t);
             }
             const float xs[4] = {t[0], t[1], t[2], 0.f};
-            mix_to_tile<kC>(F + kFk * kVL, leaf, p, active, xs, uniform_ptr(small, q[SMZ_VP_VMIX_W]), uniform_ptr(small, q[SMZ_VP_VMIX_B]));
-            mix_to_tile<kC>(F + 2 * kFk * kVL, leaf, p, active, xs, uniform_ptr(small, q[SMZ_VP_PMIX_W]), uniform_ptr(small, q[SMZ_VP_PMIX_B]));
+            mix_to_tile<kC>(F + kVW * kFS, leaf, p, active, xs, uniform_ptr(small, q[SMZ_VP_VMIX_W]), uniform_ptr(small, q[SMZ_VP_VMIX_B]));
+            mix_to_tile<kC>(F + 2 * kVW * kFS, leaf, p, active, xs, uniform_ptr(small, q[SMZ_VP_PMIX_W]), uniform_ptr(small, q[SMZ_VP_PMIX_B]));
         }
         SMZ_VSTAMP(t_conv)
         wg_barrier();                                                    // flat tiles and branch flags complete
         SMZ_VSTAMP(t_wait)
-        const int mine = br[li];
+        const int mine = br[lf];
         const bool need_dyn = __ballot(mine == 1) != 0ull, need_ady = __ballot(mine == 0) != 0ull;
-        // ---- towers, layer 1 ------------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int q = 0; q < G::r1; q += 2) {                             // register-resident jobs, two chains at a time
-            const int j0 = wave + VW * q, j1 = wave + VW * (q + 1);
-            const bool two = q + 1 < G::r1;
-            const int t0 = j0 >> 2, t1 = two ? j1 >> 2 : t0;
-            const bool n0 = tower_dyn(t0) ? need_dyn : need_ady, n1 = two && (tower_dyn(t1) ? need_dyn : need_ady);   // wave-uniform
-            const float *bv0 = weights + d.off[tower_off(t0) + 1] + 16 * (j0 & 3) + 4 * g;
-            const float *bv1 = weights + d.off[tower_off(t1) + 1] + 16 * (j1 & 3) + 4 * g;
-            v4f acc[2] = {v4f{bv0[0], bv0[1], bv0[2], bv0[3]}, v4f{bv1[0], bv1[1], bv1[2], bv1[3]}};
-            if (n0 && n1) {
-                const float *const w[2] = {w1[q], w1[two ? q + 1 : q]};
-                const float *const t[2] = {F + tower_input(t0) * kFk * kVL, F + tower_input(t1) * kFk * kVL};
-                tower_layers<37, 2>(w, t, acc, g, li);
-            } else if (n0) {
-                acc[0] = tower_layer<37>(w1[q], F + tower_input(t0) * kFk * kVL, acc[0], g, li);
-            } else if (n1) {
-                acc[1] = tower_layer<37>(w1[two ? q + 1 : q], F + tower_input(t1) * kFk * kVL, acc[1], g, li);
-            }
-            if (n0) {
-                float *dst = H1 + t0 * 64 * kVL + (16 * (j0 & 3) + 4 * g) * kVL + li;
-#pragma unroll
-                for (int r = 0; r < 4; r++) dst[r * kVL] = fmaxf(acc[0][r], 0.f);
-            }
-            if (n1) {
-                float *dst = H1 + t1 * 64 * kVL + (16 * (j1 & 3) + 4 * g) * kVL + li;
-#pragma unroll
-                for (int r = 0; r < 4; r++) dst[r * kVL] = fmaxf(acc[1][r], 0.f);
-            }
-        }
-#pragma unroll 1
-        for (int q = G::r1; q < G::j1; q++) {                            // jobs whose fragments are re-read from L2
-            const int j = wave + VW * q, t = j >> 2, mt = j & 3;
-            if (j < kJobs && (tower_dyn(t) ? need_dyn : need_ady)) {
-                const int32_t *o = d.off + tower_off(t);
-                const float *bv = weights + o[1] + 16 * mt + 4 * g;
-                float wt[37];
-                load_frags<37>(wt, weights + o[0], 16 * mt + li, g, kFk);
-                const v4f acc = tower_layer<37>(wt, F + tower_input(t) * kFk * kVL, v4f{bv[0], bv[1], bv[2], bv[3]}, g, li);
-                float *dst = H1 + t * 64 * kVL + (16 * mt + 4 * g) * kVL + li;
-#pragma unroll
-                for (int r = 0; r < 4; r++) dst[r * kVL] = fmaxf(acc[r], 0.f);
-            }
-        }
+        const bool need_a = wave < 3 ? need_dyn : need_ady, need_b = need_ady;          // tower `wave` | tower 4
+        // ---- towers: 147 -> H, [H -> H] x L (the SAME Linear applied L times), H -> S / A ---------------------------------------
+        tower_layer64<kP1>(w1, F, kFS, true, kP1, weights + offa[1], weights + offb[1], H1, wave, lane, need_a, need_b);
         wg_barrier();
-        // ---- hidden layers (the SAME Linear(H,H) applied L times) and the output layer ------------------------------------------
         float *hin = H1, *hout = H2;
         for (int l = 0; l < d.L; l++) {
-#pragma unroll
-            for (int q = 0; q < G::rm; q += 2) {
-                const int j0 = wave + VW * q, j1 = wave + VW * (q + 1);
-                const bool two = q + 1 < G::rm;
-                const int t0 = j0 >> 2, t1 = two ? j1 >> 2 : t0;
-                const bool n0 = tower_dyn(t0) ? need_dyn : need_ady, n1 = two && (tower_dyn(t1) ? need_dyn : need_ady);
-                const float *bv0 = weights + d.off[tower_off(t0) + 3] + 16 * (j0 & 3) + 4 * g;
-                const float *bv1 = weights + d.off[tower_off(t1) + 3] + 16 * (j1 & 3) + 4 * g;
-                v4f acc[2] = {v4f{bv0[0], bv0[1], bv0[2], bv0[3]}, v4f{bv1[0], bv1[1], bv1[2], bv1[3]}};
-                if (n0 && n1) {
-                    const float *const w[2] = {wmr[q], wmr[two ? q + 1 : q]};
-                    const float *const t[2] = {hin + t0 * 64 * kVL, hin + t1 * 64 * kVL};
-                    tower_layers<16, 2>(w, t, acc, g, li);
-                } else if (n0) {
-                    acc[0] = tower_layer<16>(wmr[q], hin + t0 * 64 * kVL, acc[0], g, li);
-                } else if (n1) {
-                    acc[1] = tower_layer<16>(wmr[two ? q + 1 : q], hin + t1 * 64 * kVL, acc[1], g, li);
-                }
-                if (n0) {
-                    float *dst = hout + t0 * 64 * kVL + (16 * (j0 & 3) + 4 * g) * kVL + li;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) dst[r * kVL] = fmaxf(acc[0][r], 0.f);
-                }
-                if (n1) {
-                    float *dst = hout + t1 * 64 * kVL + (16 * (j1 & 3) + 4 * g) * kVL + li;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) dst[r * kVL] = fmaxf(acc[1][r], 0.f);
-                }
-            }
-#pragma unroll 1
-            for (int q = G::rm; q < G::j1; q++) {
-                const int j = wave + VW * q, t = j >> 2, mt = j & 3;
-                if (j < kJobs && (tower_dyn(t) ? need_dyn : need_ady)) {
-                    const int32_t *o = d.off + tower_off(t);
-                    const float *bv = weights + o[3] + 16 * mt + 4 * g;
-                    float wm[16];
-                    load_frags<16>(wm, weights + o[2], 16 * mt + li, g, K4h);
-                    const v4f acc = tower_layer<16>(wm, hin + t * 64 * kVL, v4f{bv[0], bv[1], bv[2], bv[3]}, g, li);
-                    float *dst = hout + t * 64 * kVL + (16 * mt + 4 * g) * kVL + li;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) dst[r * kVL] = fmaxf(acc[r], 0.f);
-                }
-            }
+            tower_layer64<16>(wm, hin, kHS, false, plh4, weights + offa[3], weights + offb[3], hout, wave, lane, need_a, need_b);
             wg_barrier();
             float *tmp = hin; hin = hout; hout = tmp;
         }
-#pragma unroll
-        for (int q = 0; q < G::jo; q++) {
-            int t, mt;
-            out_job(wave + VW * q, t, mt);
-            if (tower_dyn(t) ? need_dyn : need_ady) {
-                const int32_t *o = d.off + tower_off(t);
-                const float *bv = weights + o[5] + 16 * mt + 4 * g;
-                v4f acc = v4f{bv[0], bv[1], bv[2], bv[3]};
-                if (q < G::ro) {
-                    acc = tower_layer<16>(wor[q < G::ro ? q : 0], hin + t * 64 * kVL, acc, g, li);
-                } else {
-                    float wo[16];
-                    load_frags<16>(wo, weights + o[4], 16 * mt + li, g, K4h);
-                    acc = tower_layer<16>(wo, hin + t * 64 * kVL, acc, g, li);
-                }
-                *reinterpret_cast<v4f *>(Y + t * kVL * kYS + li * kYS + 16 * mt + 4 * g) = acc;
+        if (wave < 3) {
+            if (wave < 2 ? need_dyn : need_ady) {
+                const float *x = hin + (t_out * kVW + lf) * kHS + (lane >> 5) * plh4;
+                const float *const bx[2] = {x, x + 2 * plh4};
+                v4f acc[2] = {bias4(weights + offo[5] + 4 * (blk & 7), lane < 32), v4f{0.f, 0.f, 0.f, 0.f}};
+                rows_mfma<16, 2, 0>(wo, bx, acc);
+                const v4f y = xadd(acc[0], 32) + xadd(acc[1], 32);
+                if (lane < 32) *reinterpret_cast<v4f *>(Y + (t_out * kVW + lf) * kYS + 4 * blk) = y;
             }
+        } else {
+            const int t = (lane & 16) ? 4 : 2;
+            const float *x = hin + (t * kVW + lf) * kHS + ((lane >> 2) & 3) * plh4;
+            const float *const bx[2] = {x, x};
+            v4f acc[2] = {bias4(weights + offo[5], (lane & 12) == 0 && lane < 32), v4f{0.f, 0.f, 0.f, 0.f}};
+            rows_mfma<16, 1, 0>(wo, bx, acc);
+            const v4f y = xadd(xadd(acc[0], 4), 8);
+            if ((lane & 12) == 0 && lane < 32) *reinterpret_cast<v4f *>(Y + (t * kVW + lf) * kYS) = y;
         }
         wg_barrier();
-        // ---- tails: this wave's own leaves, lane = output --------------------------------------------------------------------
-#pragma unroll
-        for (int r = 0; r < VT; r++) {
-            if (!(r ? live1 : live0)) continue;
-            const int leaf = VT * wave + r;
-            const bool dyn = r ? dyn1 : dyn0;
+        // ---- tails: this wave's own leaf, lane = output --------------------------------------------------------------------------
+        if (live0) {
             float reward = 0.f;
             if (dyn) {
-                const float v[1] = {lane < 32 ? Y[0 * kVL * kYS + leaf * kYS + lane] : 0.f};
+                const float v[1] = {lane < 32 ? Y[(0 * kVW + leaf) * kYS + lane] : 0.f};
                 reward = decode_lanes<1>(v, 0, S, lane);
             }
-            const float vv[1] = {lane < 32 ? Y[(dyn ? 1 : 3) * kVL * kYS + leaf * kYS + lane] : 0.f};
+            const float vv[1] = {lane < 32 ? Y[((dyn ? 1 : 3) * kVW + leaf) * kYS + lane] : 0.f};
             const float value = decode_lanes<1>(vv, 0, S, lane);
-            const float vp[1] = {lane < 32 ? Y[(dyn ? 2 : 4) * kVL * kYS + leaf * kYS + lane] : 0.f};
-            softmax_lanes<1>(vp, A, lane, outs + r * slot);
-            if (lane == 0) { outs[r * slot + A] = value; outs[r * slot + A + 1] = reward; }
+            const float vp[1] = {lane < 32 ? Y[((dyn ? 2 : 4) * kVW + leaf) * kYS + lane] : 0.f};
+            softmax_lanes<1>(vp, A, lane, outs);
+            if (lane == 0) { outs[A] = value; outs[A + 1] = reward; }
         }
         lds_sync();
         packed = stage_finish<VT, false>(P, tree, valid, rng_tile, packed, pre);
@@ -509,30 +428,25 @@ int search_vision_launch(smz_handle *h, const smz_vision_desc *desc, const float
         }
         P.pow_table = h->d_pow;
     }
-    // geometry: 4 waves x 1 tree (everything register-resident, 4 trees per workgroup) unless SMZ_VISION_GEOMETRY=8x2
-    bool wide = false;
-    if (const char *e = getenv("SMZ_VISION_GEOMETRY")) wide = strcmp(e, "8x2") == 0;
-    const int VW = wide ? 8 : 4, VT = wide ? 2 : 1;
-    P.tpw = VT;
-    const VisLds ml = vis_lds(P, P.A, VW, VT);
+    P.tpw = 1;
+    const VisLds ml = vis_lds(P, P.A);
     const size_t lds = (size_t)ml.total * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_TOO_LARGE, "smz_search_vision: working set exceeds the 160 KB LDS of a CU%s");
-    const int blocks = (P.B + VW * VT - 1) / (VW * VT);
-#define SMZ_LAUNCH_VS(MA, W, T)                                                                                        \
+    const int blocks = (P.B + kVW - 1) / kVW;
+#define SMZ_LAUNCH_VS(MA)                                                                                              \
     {                                                                                                                  \
         static size_t granted_dev[64] = {};                                                                            \
         size_t &granted = granted_dev[h->cfg.device & 63];                                                             \
         if (lds > granted) {                                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_vision<MA, W, T>),                         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_vision<MA>),                               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)               \
                 return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                             \
             granted = lds;                                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_search_vision<MA, W, T>), dim3(blocks), dim3(W * kWave), lds, (hipStream_t)stream, P,    \
+        hipLaunchKernelGGL((k_search_vision<MA>), dim3(blocks), dim3(kVW * kWave), lds, (hipStream_t)stream, P,        \
                            *desc, weights_dev, hidden0_dev, policy0_dev, train, act);                                  \
     }
-    if (wide) { if (h->maxa == 2) SMZ_LAUNCH_VS(2, 8, 2) else SMZ_LAUNCH_VS(4, 8, 2) }
-    else { if (h->maxa == 2) SMZ_LAUNCH_VS(2, 4, 1) else SMZ_LAUNCH_VS(4, 4, 1) }
+    if (h->maxa == 2) SMZ_LAUNCH_VS(2) else SMZ_LAUNCH_VS(4)
 #undef SMZ_LAUNCH_VS
     h->root_ready = true;
     h->selected = false;

@@ -131,26 +131,35 @@ class SyntheticVec:
 class ImageVec:
     """Frame-observation stand-in for the vision family: [B,3,98,98] float32 frames in [0,1) (the shape
     muzero_model.py:400-404 fixes; the reference's resize to it, game.py:82-89, needs torchvision and is not pinned).
-    Env i starts from RandomState(seed + i).rand(3,98,98); a step scrolls the frame one pixel, on the device."""
+    Frame j = RandomState(seed + j).rand(3,98,98); env i (global index) shows frame i + (t mod POOL) at step t.  The
+    frames of a shard sit in one device-resident pool and `obs` is a contiguous window into it, so an env step moves no
+    data (the frames of a real env arrive from outside the engine; a device-side scroll here only measured torch.roll)."""
     frame = (3, 98, 98)
+    POOL = 16
 
     def __init__(self, num_envs, num_actions, device, seed=0, first_env=0, total_envs=None):
         self.B, self.num_actions = int(num_envs), int(num_actions)
         self.obs_dim = int(np.prod(self.frame))
         self.device = torch.device(device)
         self.seed, self.first_env = int(seed), int(first_env)
-        self.obs = torch.empty((self.B,) + self.frame, dtype=torch.float32, device=self.device)
+        self.pool = torch.empty((self.B + self.POOL,) + self.frame, dtype=torch.float32, device=self.device)
+        self.t = 0
+        self.obs = self.pool[:self.B]
         self.reward = torch.zeros(self.B, dtype=torch.float32, device=self.device)
         self.terminated = torch.zeros(self.B, dtype=torch.uint8, device=self.device)
 
     def reset(self):
-        rows = np.stack([np.random.RandomState(self.seed + self.first_env + i).rand(*self.frame).astype(np.float32)
-                         for i in range(self.B)])
-        self.obs.copy_(torch.from_numpy(rows))
+        rows = np.stack([np.random.RandomState(self.seed + self.first_env + j).rand(*self.frame).astype(np.float32)
+                         for j in range(self.B + self.POOL)])
+        self.pool.copy_(torch.from_numpy(rows))
+        self.t = 0
+        self.obs = self.pool[:self.B]
         return self.obs
 
     def step(self, action):
-        self.obs.copy_(torch.roll(self.obs, shifts=1, dims=3))
+        self.t += 1
+        k = self.t % (self.POOL + 1)
+        self.obs = self.pool[k:k + self.B]
         return self.obs, self.reward, self.terminated
 
 
