@@ -1307,7 +1307,7 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     A_(dev_alloc(h, &h->d_seeds, (size_t)B));
     A_(dev_alloc(h, &h->d_pbc, (size_t)sims + 2));
     A_(dev_alloc(h, &h->d_pow, (size_t)sims + 1));
-    A_(dev_alloc(h, &h->d_stats, (size_t)8));
+    A_(dev_alloc(h, &h->d_stats, (size_t)16));
     A_(dev_alloc(h, &h->d_mt_backup, (size_t)B * kMtN));
     A_(dev_alloc(h, &h->d_pos_backup, (size_t)B));
     A_(dev_alloc(h, &h->d_block_backup, (size_t)B));
@@ -1326,7 +1326,7 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     // defined contents before first use
     hipError_t e = hipMemset(P.nodes, 0, (size_t)B * (size_t)P.tree_words * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(P.hdr, 0, (size_t)B * sizeof(TreeHdr));
-    if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(P.rng_pos, 0, (size_t)B * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(P.mt, 0, (size_t)B * kMtN * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(P.rng_block, 0, (size_t)B * sizeof(uint32_t));
@@ -1892,11 +1892,14 @@ int smz_read_stats(smz_handle *h, uint64_t levels_out[4], int reset) {
     if (!h || !levels_out) return fail(SMZ_ERR_INVALID, "smz_read_stats: null argument%s");
     DeviceGuard guard(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
-    unsigned long long v[8];
+    unsigned long long v[16];
     HIP_TRY(hipMemcpy(v, h->d_stats, sizeof(v), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) levels_out[i] = (uint64_t)v[i];
     if (getenv("SMZ_DEBUG_SKIP") && (atoi(getenv("SMZ_DEBUG_SKIP")) & 16))
         fprintf(stderr, "[smz phase cycles, summed over waves] stage %llu expand %llu select %llu mlp %llu  (k_search_vision: tree, conv, wait, towers+tails)\n", v[4], v[5], v[6], v[7]);
+    if (getenv("SMZ_DEBUG_SKIP") && (atoi(getenv("SMZ_DEBUG_SKIP")) & 16) && v[8])
+        fprintf(stderr, "[smz k_search_vision phases] tree %llu load %llu conv_transition %llu conv_prediction %llu wait %llu layer1 %llu hidden_out %llu tails_stage %llu\n",
+                v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
     if (reset) HIP_TRY(hipMemset(h->d_stats, 0, sizeof(v)));
     return SMZ_OK;
 }

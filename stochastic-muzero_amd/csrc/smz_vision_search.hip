@@ -53,18 +53,19 @@ constexpr int kYS = 36;                              // floats per (tower, leaf)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct VisLds {                                      // float offsets from the dynamic LDS base
-    int small, pbc, wave, per_wave, plane, pv, rng, outs, F, H1, H2, Y, br, total;
+    int small, pbc, wave, per_wave, plane, pv, rng, outs, prof, F, H1, H2, Y, br, total;
 };
 __host__ __device__ inline VisLds vis_lds(const Params &P, int A) {
     VisLds m;
     m.small = 0;
-    m.pbc = kSmallMax + 10 * 108;                                 // (+ tap-major copies of the ten 3x3 convolution pieces)
+    m.pbc = kSmallMax + 10 * smz_vision::kTapFloats;                                 // (+ tap-major copies of the ten 3x3 convolution pieces)
     m.wave = m.pbc + r4(2 * 2 * (P.sims + 2));
     m.plane = 0;                                                  // float4 plane[81] -> 324 floats
     m.pv = r4(kPad * kPad * 4);
     m.rng = m.pv + P.P * 4;
     m.outs = m.rng + r4(kRngStride);
-    m.per_wave = m.outs + r4(A + 2);
+    m.prof = m.outs + r4(A + 2);                                  // eight 64-bit phase counters (SMZ_DEBUG_SKIP=16)
+    m.per_wave = m.prof + 16;
     m.F = m.wave + kVW * m.per_wave;
     m.H1 = m.F + 3 * kVW * kFS;
     m.H2 = m.H1 + kTowers * kVW * kHS;
@@ -197,11 +198,11 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
     float *tm = lds + kSmallMax;
     for (int n = 0; n < 2; n++) {
         const int32_t *o = d.off + SMZ_V_TRANS_BASE + n * SMZ_V_TRANS_STRIDE, *q = d.off + SMZ_V_PRED_BASE + n * SMZ_V_PRED_STRIDE;
-        smz_vision::tap_major<4>(tm + (n * 3 + 0) * 108, weights + o[SMZ_VT_CONV_IN], threadIdx.x, blockDim.x);
-        smz_vision::tap_major<3>(tm + (n * 3 + 1) * 108, weights + o[SMZ_VT_RES_A], threadIdx.x, blockDim.x);
-        smz_vision::tap_major<3>(tm + (n * 3 + 2) * 108, weights + o[SMZ_VT_RES_B], threadIdx.x, blockDim.x);
-        smz_vision::tap_major<3>(tm + (6 + n * 2 + 0) * 108, weights + q[SMZ_VP_RES_A], threadIdx.x, blockDim.x);
-        smz_vision::tap_major<3>(tm + (6 + n * 2 + 1) * 108, weights + q[SMZ_VP_RES_B], threadIdx.x, blockDim.x);
+        smz_vision::tap_major<4>(tm + (n * 3 + 0) * smz_vision::kTapFloats, weights + o[SMZ_VT_CONV_IN], threadIdx.x, blockDim.x);
+        smz_vision::tap_major<3>(tm + (n * 3 + 1) * smz_vision::kTapFloats, weights + o[SMZ_VT_RES_A], threadIdx.x, blockDim.x);
+        smz_vision::tap_major<3>(tm + (n * 3 + 2) * smz_vision::kTapFloats, weights + o[SMZ_VT_RES_B], threadIdx.x, blockDim.x);
+        smz_vision::tap_major<3>(tm + (6 + n * 2 + 0) * smz_vision::kTapFloats, weights + q[SMZ_VP_RES_A], threadIdx.x, blockDim.x);
+        smz_vision::tap_major<3>(tm + (6 + n * 2 + 1) * smz_vision::kTapFloats, weights + q[SMZ_VP_RES_B], threadIdx.x, blockDim.x);
     }
     // convolution / batch-norm / 1x1 weights from the workgroup's LDS copy (as the wave-per-leaf kernel: through the scalar
     // cache a convolution measured 2x slower here too)
@@ -264,10 +265,14 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
     unsigned n_dec = 0, n_chance = 0, n_children = 0;
     if (P.sims > 0) packed = wave_stage_rng_from<4, false>(P, tree, valid, rng_tile, packed);
 
-    // (SMZ_DEBUG_SKIP=16 with statistics on: s_memtime phase accounting -> stats[4..7] = tree | conv | wait | towers + tails)
+    // (SMZ_DEBUG_SKIP=16 with statistics on: s_memtime phase accounting per wave in LDS -> stats[8..15] = tree | parent-row
+    //  load | transition convolutions | prediction convolutions | barrier wait | layer 1 | hidden + output layers | tails +
+    //  word staging; stats[4..7] = tree | conv | wait | towers + tails as sums of those)
     const bool prof = (P.dbg & 16) && P.stats;
-    unsigned long long t_tree = 0, t_conv = 0, t_wait = 0, t_tow = 0, t0 = 0, t1 = 0;
-#define SMZ_VSTAMP(acc) if (prof) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
+    unsigned long long *pc = reinterpret_cast<unsigned long long *>(wl + ml.prof);
+    unsigned long long t0 = 0;
+#define SMZ_VSTAMP(i) if (prof) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); if (lane == 0) pc[i] += t1 - t0; t0 = t1; }
+#define SMZ_VDRAIN() if (prof) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     // ---- simulations -----------------------------------------------------------------------------------------------------
     for (int s = 0; s < P.sims; s++) {
         if (prof) t0 = __builtin_amdgcn_s_memtime();
@@ -281,7 +286,7 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
             h.path_len = len;
             packed = rng.pack();
         }
-        SMZ_VSTAMP(t_tree)
+        SMZ_VSTAMP(0)
         // hidden rows written in earlier rounds (by this wave) may be this round's parent rows
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         StagePre<VT> pre;
@@ -296,13 +301,15 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
             const float *hrow = P.hidden + ((size_t)tree0 * P.N + parent) * P.hs;
             const float a_plane = (float)(actn + 1) / (float)d.A;        // muzero_model.py:511-522
             float x[4] = {hrow[p], hrow[kPix + p], hrow[2 * kPix + p], a_plane};
+            SMZ_VDRAIN()
+            SMZ_VSTAMP(1)
             const int32_t *o = d.off + SMZ_V_TRANS_BASE + (dyn ? 0 : SMZ_V_TRANS_STRIDE);
             if (dyn) mix_to_tile<4>(F, leaf, p, active, x, uniform_ptr(small, o[SMZ_VT_MIX_W]), uniform_ptr(small, o[SMZ_VT_MIX_B]));
             if (active) plane[pp] = make_float4(x[0], x[1], x[2], x[3]);
             lds_sync();
             float t[kC];
             const int ni = dyn ? 0 : 1;
-            smz_vision::conv3x3_t<4>(plane, pp, reinterpret_cast<const float4 *>(tm + (ni * 3 + 0) * 108), t);
+            smz_vision::conv3x3_t<4>(plane, pp, reinterpret_cast<const float4 *>(tm + (ni * 3 + 0) * smz_vision::kTapFloats), t);
             lds_sync();
             {
                 const float *bn = uniform_ptr(small, o[SMZ_VT_BN_IN]);
@@ -310,7 +317,7 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
                 for (int c = 0; c < kC; c++) t[c] = fmaxf(t[c] * bn[c] + bn[kC + c], 0.f);
             }
             {
-                const float4 *wa = reinterpret_cast<const float4 *>(tm + (ni * 3 + 1) * 108), *wb = reinterpret_cast<const float4 *>(tm + (ni * 3 + 2) * 108);
+                const float4 *wa = reinterpret_cast<const float4 *>(tm + (ni * 3 + 1) * smz_vision::kTapFloats), *wb = reinterpret_cast<const float4 *>(tm + (ni * 3 + 2) * smz_vision::kTapFloats);
                 const float *bn = uniform_ptr(small, o[SMZ_VT_RES_BN]);
                 for (int i = 0; i < d.L; i++) smz_vision::residual_block_t(plane, pp, active, wa, wb, bn, t);
             }
@@ -321,9 +328,11 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
                 float *ho = P.hidden + ((size_t)tree0 * P.N + leaf_id) * P.hs;
                 ho[p] = t[0]; ho[kPix + p] = t[1]; ho[2 * kPix + p] = t[2];
             }
+            SMZ_VDRAIN()
+            SMZ_VSTAMP(2)
             const int32_t *q = d.off + SMZ_V_PRED_BASE + (dyn ? 0 : SMZ_V_PRED_STRIDE);
             {
-                const float4 *wa = reinterpret_cast<const float4 *>(tm + (6 + ni * 2 + 0) * 108), *wb = reinterpret_cast<const float4 *>(tm + (6 + ni * 2 + 1) * 108);
+                const float4 *wa = reinterpret_cast<const float4 *>(tm + (6 + ni * 2 + 0) * smz_vision::kTapFloats), *wb = reinterpret_cast<const float4 *>(tm + (6 + ni * 2 + 1) * smz_vision::kTapFloats);
                 const float *bn = uniform_ptr(small, q[SMZ_VP_RES_BN]);
                 for (int i = 0; i < d.L; i++) smz_vision::residual_block_t(plane, pp, active, wa, wb, bn, t);
             }
@@ -331,15 +340,16 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
             mix_to_tile<kC>(F + kVW * kFS, leaf, p, active, xs, uniform_ptr(small, q[SMZ_VP_VMIX_W]), uniform_ptr(small, q[SMZ_VP_VMIX_B]));
             mix_to_tile<kC>(F + 2 * kVW * kFS, leaf, p, active, xs, uniform_ptr(small, q[SMZ_VP_PMIX_W]), uniform_ptr(small, q[SMZ_VP_PMIX_B]));
         }
-        SMZ_VSTAMP(t_conv)
+        SMZ_VSTAMP(3)
         wg_barrier();                                                    // flat tiles and branch flags complete
-        SMZ_VSTAMP(t_wait)
+        SMZ_VSTAMP(4)
         const int mine = br[lf];
         const bool need_dyn = __ballot(mine == 1) != 0ull, need_ady = __ballot(mine == 0) != 0ull;
         const bool need_a = wave < 3 ? need_dyn : need_ady, need_b = need_ady;          // tower `wave` | tower 4
         // ---- towers: 147 -> H, [H -> H] x L (the SAME Linear applied L times), H -> S / A ---------------------------------------
         tower_layer64<kP1>(w1, F, kFS, true, kP1, weights + offa[1], weights + offb[1], H1, wave, lane, need_a, need_b);
         wg_barrier();
+        SMZ_VSTAMP(5)
         float *hin = H1, *hout = H2;
         for (int l = 0; l < d.L; l++) {
             tower_layer64<16>(wm, hin, kHS, false, plh4, weights + offa[3], weights + offb[3], hout, wave, lane, need_a, need_b);
@@ -365,6 +375,7 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
             if ((lane & 12) == 0 && lane < 32) *reinterpret_cast<v4f *>(Y + (t * kVW + lf) * kYS) = y;
         }
         wg_barrier();
+        SMZ_VSTAMP(6)
         // ---- tails: this wave's own leaf, lane = output --------------------------------------------------------------------------
         if (live0) {
             float reward = 0.f;
@@ -380,12 +391,14 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
         }
         lds_sync();
         packed = stage_finish<VT, false>(P, tree, valid, rng_tile, packed, pre);
-        SMZ_VSTAMP(t_tow)
+        SMZ_VSTAMP(7)
     }
 #undef SMZ_VSTAMP
+#undef SMZ_VDRAIN
     if (prof && lane == 0) {
-        atomicAdd(&P.stats[4], t_tree); atomicAdd(&P.stats[5], t_conv);
-        atomicAdd(&P.stats[6], t_wait); atomicAdd(&P.stats[7], t_tow);
+        for (int i = 0; i < 8; i++) atomicAdd(&P.stats[8 + i], pc[i]);
+        atomicAdd(&P.stats[4], pc[0]); atomicAdd(&P.stats[5], pc[1] + pc[2] + pc[3]);
+        atomicAdd(&P.stats[6], pc[4]); atomicAdd(&P.stats[7], pc[5] + pc[6] + pc[7]);
     }
     if (valid) {
         if (P.sims > 0) {
