@@ -63,10 +63,12 @@ struct Params {
     uint32_t *rng_block;        // [B]  (philox) 624-word blocks consumed so far: word (block, idx) of a tree is component
                                 //      idx & 3 of philox(counter = block * 156 + idx / 4, key); rng_pos keeps idx
     const uint32_t *rng_key;    // [B][2] (philox)
+    int32_t tree0;              // index of the tree whose blocks `nodes` points at: 0, except in a kernel that keeps its workgroup's
+                                // trees in LDS for the search (k_search_vision) and points `nodes` there
 };
 __device__ inline bool tree_active(const Params &P, int tree) { return !P.active || P.active[tree] != 0; }
 
-__device__ inline uint32_t *tree_base(const Params &P, int tree) { return P.nodes + (size_t)tree * P.tree_words; }
+__device__ inline uint32_t *tree_base(const Params &P, int tree) { return P.nodes + (size_t)(tree - P.tree0) * P.tree_words; }
 __device__ inline uint32_t *block_ptr(const Params &P, uint32_t *tb, int blk) {
     return blk == 0 ? tb : tb + P.rb_words + (size_t)(blk - 1) * P.eb_words;
 }

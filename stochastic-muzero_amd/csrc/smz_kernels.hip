@@ -393,6 +393,7 @@ template <int MAXA, int KS, bool AEX>
 __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_hidden, int32_t *last_action,
                                                   uint8_t *branch, float *mlp_input) {
     Params P = Pin;
+    P.tree0 = 0;
     if (AEX) P.A = MAXA;
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);
@@ -425,6 +426,7 @@ __global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const fl
                                                          float *parent_hidden, int32_t *last_action, uint8_t *branch,
                                                          float *mlp_input) {
     Params P = Pin;
+    P.tree0 = 0;
     if (AEX) P.A = MAXA;
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);
@@ -510,6 +512,7 @@ template <int MAXA, int KS, int U, bool INSTR, bool AEX>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train, ActOut act) {
     Params P = Pin;
+    P.tree0 = 0;
     if (AEX) { P.A = MAXA; P.tpw = kFastTpw; d.A = MAXA; d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = smz_mlp::kWave; P.S = kFastS; }
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);

@@ -40,8 +40,16 @@ __device__ unsigned long long smz_vision_stamps[8];
         last_ = now_;                                                                                 \
     } while (0)
 #define SMZ_STAMP_INIT() unsigned long long last_ = __builtin_amdgcn_s_memtime()
+__device__ unsigned long long smz_rep_stamps[12];      // k_vision_initial: per stage, thread 0 of every workgroup
+#define SMZ_RSTAMP(i)                                                                                 \
+    do {                                                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                 \
+        if (threadIdx.x == 0) atomicAdd(&smz_rep_stamps[i], now_ - last_);                            \
+        last_ = now_;                                                                                 \
+    } while (0)
 #else
 #define SMZ_STAMP(i) do {} while (0)
+#define SMZ_RSTAMP(i) do {} while (0)
 #define SMZ_STAMP_INIT() do {} while (0)
 #endif
 
@@ -210,6 +218,7 @@ __global__ void __launch_bounds__(kRepThreads, 4) k_vision_initial(smz_vision_de
     const int row = blockIdx.x;
     const float *f = frames + (size_t)row * 3 * kFrame * kFrame;
     const int32_t *o = d.off + SMZ_V_REP_BASE;
+    SMZ_STAMP_INIT();
     // stem: conv3x3 stride 2 pad 1, 3 -> 1 channels, 98 -> 49, straight from global memory
     {
         const float *w = weights + o[SMZ_VR_STEM];
@@ -228,27 +237,35 @@ __global__ void __launch_bounds__(kRepThreads, 4) k_vision_initial(smz_vision_de
         }
         __syncthreads();
     }
+    SMZ_RSTAMP(0);
     {
         const float *wa = weights + o[SMZ_VR_NARROW_A], *wb = weights + o[SMZ_VR_NARROW_B], *bn = weights + o[SMZ_VR_NARROW_BN];
         residual_map<1>(l, 49, wa, wb, bn);
         residual_map<1>(l, 49, wa, wb, bn);
     }
+    SMZ_RSTAMP(1);
     // widen: conv3x3 stride 2, 1 -> 3 channels, 49 -> 25
     pad_store<1>(l.u, l.t, 49, nullptr);
     conv_map<1, 3>(l.v, l.u, 49, 25, 2, weights + o[SMZ_VR_WIDEN], nullptr);
     for (int i = threadIdx.x; i < 3 * 25 * 25; i += kRepThreads) l.t[i] = l.v[i];
     __syncthreads();
+    SMZ_RSTAMP(2);
     {
         const float *wa = weights + o[SMZ_VR_WIDE_A], *wb = weights + o[SMZ_VR_WIDE_B], *bn = weights + o[SMZ_VR_WIDE_BN];
         residual_map<3>(l, 25, wa, wb, bn);
         residual_map<3>(l, 25, wa, wb, bn);
+        SMZ_RSTAMP(3);
         pool_map<3>(l, 25, 13);
+        SMZ_RSTAMP(4);
         residual_map<3>(l, 13, wa, wb, bn);
         residual_map<3>(l, 13, wa, wb, bn);
         residual_map<3>(l, 13, wa, wb, bn);
+        SMZ_RSTAMP(5);
         pool_map<3>(l, 13, 7);
+        SMZ_RSTAMP(6);
     }
     residual_map<3>(l, 7, weights + o[SMZ_VR_LAST_A], weights + o[SMZ_VR_LAST_B], weights + o[SMZ_VR_LAST_BN]);
+    SMZ_RSTAMP(7);
     // wave 0: per-pixel scaling, hidden state out, root policy (the root value is discarded, mcts:319-321)
     if (threadIdx.x < kWave) {
         const int lane = threadIdx.x;
@@ -262,6 +279,7 @@ __global__ void __launch_bounds__(kRepThreads, 4) k_vision_initial(smz_vision_de
         }
         zero_wave_lds(l.head, lane);
         predict(weights, weights, d, SMZ_V_PRE, l.head, lane, p, pp, active, t, policy_out + (size_t)row * d.A, false);
+        SMZ_RSTAMP(8);
     }
 }
 

@@ -53,7 +53,7 @@ constexpr int kYS = 36;                              // floats per (tower, leaf)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct VisLds {                                      // float offsets from the dynamic LDS base
-    int small, pbc, wave, per_wave, plane, pv, rng, outs, prof, F, H1, H2, Y, br, total;
+    int small, pbc, wave, per_wave, plane, pv, rng, outs, prof, F, H1, H2, Y, br, trees, total;
 };
 __host__ __device__ inline VisLds vis_lds(const Params &P, int A) {
     VisLds m;
@@ -71,7 +71,8 @@ __host__ __device__ inline VisLds vis_lds(const Params &P, int A) {
     m.H2 = m.H1 + kTowers * kVW * kHS;
     m.Y = m.H2 + kTowers * kVW * kHS;
     m.br = m.Y + kTowers * kVW * kYS + 64;                        // (+64: the tails read a full wave width of a row)
-    m.total = m.br + kVW;
+    m.trees = (m.br + kVW + 15) & ~15;                                       // the four trees' child blocks (written back at the end)
+    m.total = m.trees + kVW * (int)P.tree_words;
     return m;
 }
 
@@ -216,6 +217,11 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
     int *br = reinterpret_cast<int *>(lds + ml.br);
     const int slot = A + 2;
     const int blk = lane >> 2, lf = lane & 3;
+    // the workgroup's four trees live in LDS for the search: a tree level is an LDS round trip instead of an L2 one
+    uint32_t *const nodes_global = P.nodes;
+    uint32_t *const nodes_lds = reinterpret_cast<uint32_t *>(lds + ml.trees);
+    P.nodes = nodes_lds;
+    P.tree0 = blockIdx.x * kVW;
     // ---- register-resident weights of this wave's rows ---------------------------------------------------------------------
     const int32_t *offa = d.off + tower_off(wave), *offb = d.off + tower_off(4);
     float w1[5][kP1], wm[5][16], wo[2][16];
@@ -414,6 +420,12 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
             packed = rng.pack();
         }
         P.rng_pos[tree] = packed;
+    }
+    lds_sync();
+    if (live0) {                                                         // the finished tree back to its place in global memory
+        const uint32_t *src = nodes_lds + (size_t)wave * P.tree_words;
+        uint32_t *dst = nodes_global + (size_t)tree0 * P.tree_words;
+        for (int i = lane; i < (int)P.tree_words; i += kWave) dst[i] = src[i];
     }
 }
 
