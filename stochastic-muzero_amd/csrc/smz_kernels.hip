@@ -1553,6 +1553,10 @@ int smz_internal_search_launch_narrow(smz_handle *h, const smz_mlp_desc *desc, c
                                       int train, SearchActArgs a, const double *pow_table_host, smz_stream stream);
 int smz_internal_search_launch_wide(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
                                     int train, SearchActArgs a, const double *pow_table_host, smz_stream stream);
+// smz_search_reg.hip: the register-resident / matrix-core kernel for the shipped network shape
+int smz_internal_search_launch_reg(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
+                                   int train, double temperature, int32_t *action, double *policy, double *child_visits,
+                                   float *root_value, const double *pow_table_host, smz_stream stream);
 int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
                       SearchActArgs a, const double *pow_table_host, smz_stream stream) {
     const ActOut act = {a.temperature, a.action, a.policy, a.child_visits, a.root_value};
@@ -1568,6 +1572,21 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     if (train && h->cfg.num_simulations > 0 && !(h->cfg.root_dirichlet_alpha > 0))
         return fail(SMZ_ERR_INVALID, "root_dirichlet_alpha must be > 0 to draw noise (numpy raises ValueError)%s");
     DeviceGuard guard(h->cfg.device);
+#if SMZ_PART == 2
+    {   // SMZ_SEARCH_REG=1: the experimental kernel of smz_search_reg.hip for the shipped shape (S 31, H 64, L 0; 2 or 4
+        // actions, two sampled children, MT19937 streams) -- four trees per wavefront, weights in registers, layers on the
+        // matrix cores.  Bit-identical to the kernel below; measured slower at 4096 trees (338 M vs 392 M simulations/s: one
+        // wavefront per SIMD cannot overlap its tree phases with another wave's network evaluation), hence opt-in.
+        const char *reg_env = getenv("SMZ_SEARCH_REG");
+        const bool reg_on = reg_env && atoi(reg_env) == 1;
+        const bool shape = h->K == 2 && (h->P.A == 2 || h->P.A == 4) && h->P.A == h->maxa && desc->S == kFastS &&
+                           desc->H == kFastH && desc->L == kFastL && !h->P.philox;
+        const bool plain = !(h->P.stats || h->P.dbg) || (h->P.dbg & 64) != 0;
+        if (reg_on && shape && plain)
+            return smz_internal_search_launch_reg(h, desc, weights_dev, obs_dev, train, a.temperature, a.action, a.policy,
+                                                  a.child_visits, a.root_value, pow_table_host, stream);
+    }
+#endif
     int kWaves = 8;
     if (const char *e = getenv("SMZ_SEARCH_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) kWaves = v; }
     Params P = h->P;
@@ -1900,6 +1919,8 @@ int smz_read_stats(smz_handle *h, uint64_t levels_out[4], int reset) {
     for (int i = 0; i < 4; i++) levels_out[i] = (uint64_t)v[i];
     if (getenv("SMZ_DEBUG_SKIP") && (atoi(getenv("SMZ_DEBUG_SKIP")) & 16))
         fprintf(stderr, "[smz phase cycles, summed over waves] stage %llu expand %llu select %llu mlp %llu  (k_search_vision: tree, conv, wait, towers+tails)\n", v[4], v[5], v[6], v[7]);
+    if (getenv("SMZ_DEBUG_SKIP") && (atoi(getenv("SMZ_DEBUG_SKIP")) & 64) && v[8])
+        fprintf(stderr, "[smz k_search_mlp_reg phases] tree %llu inputs %llu networks %llu staging %llu\n", v[8], v[9], v[10], v[11]);
     if (getenv("SMZ_DEBUG_SKIP") && (atoi(getenv("SMZ_DEBUG_SKIP")) & 16) && v[8])
         fprintf(stderr, "[smz k_search_vision phases] tree %llu load %llu conv_transition %llu conv_prediction %llu wait %llu layer1 %llu hidden_out %llu tails_stage %llu\n",
                 v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);

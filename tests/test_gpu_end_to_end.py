@@ -244,6 +244,41 @@ def test_single_launch_search_equals_stepwise_search(wname, B, sims, K):
         assert np.array_equal(ra.random_sample(700), rb.random_sample(700))
 
 
+@pytest.mark.parametrize("wname,B,sims", [("weights_ckpt421", 4096, 50), ("weights_lunar_L0", 1030, 20), ("weights_ckpt421", 37, 3)])
+def test_register_resident_search_kernel_equals_production_kernel(wname, B, sims, monkeypatch):
+    """SMZ_SEARCH_REG=1 selects k_search_mlp_reg (smz_search_reg.hip: four trees per wavefront, weights in registers,
+    layers as v_mfma_f32_4x4x1 chains, tails on the MFMA output layout).  Its arithmetic is arranged to round like the
+    vector-unit heads (even / odd accumulator chains, sums in wave_sum's association), so whole searches must agree bit for
+    bit with the production kernel: visits, priors, values, every dumped tree array, stream positions."""
+    mcts_mod, model_mod, _, _ = _mods()
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
+    heads = model.heads("cuda:0", backend="hip")
+    obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(3)).mul(0.3).cuda()
+    res = []
+    for reg in ("1", "0"):
+        monkeypatch.setenv("SMZ_SEARCH_REG", reg)
+        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997,
+                                 root_exploration_fraction=0.25, use_graph=False, single_launch=True)
+        m.seed(np.arange(B, dtype=np.uint64) + 11)
+        for rep in range(2):
+            e = m.run(obs, heads, train=True, act_temperature=1.0)
+        assert m._single is True
+        visits, priors, rv, cr = e.root_stats()
+        action, policy, cv, _ = e.act(1.0)
+        torch.cuda.synchronize()
+        out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr, action, policy, cv)]
+        dumps = [e.dump_tree(i) for i in (0, 1, 2, 3, B // 2, B - 1)]
+        states = [e.get_rng_state(i) for i in (0, B - 1)]
+        res.append((out, dumps, states))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for da, db in zip(res[0][1], res[1][1]):
+        for k in da:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+    for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
+        assert np.array_equal(ka, kb) and pa == pb
+
+
 def test_module_heads_with_image_shaped_hidden_states_and_action_planes():
     """The generic five-module path with a vision-shaped family: hidden state [B,3,7,7], action fed as a constant
     plane (a+1)/A (muzero_model.py:511-522).  Engine and per-tree oracle are fed the SAME module outputs, so every
