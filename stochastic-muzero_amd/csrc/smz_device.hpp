@@ -66,7 +66,11 @@ struct Params {
     int32_t tree0;              // index of the tree whose blocks `nodes` points at: 0, except in a kernel that keeps its workgroup's
                                 // trees in LDS for the search (k_search_vision) and points `nodes` there
 };
+#ifdef SMZ_NO_MASK
+__device__ inline bool tree_active(const Params &, int) { return true; }
+#else
 __device__ inline bool tree_active(const Params &P, int tree) { return !P.active || P.active[tree] != 0; }
+#endif
 
 __device__ inline uint32_t *tree_base(const Params &P, int tree) { return P.nodes + (size_t)(tree - P.tree0) * P.tree_words; }
 __device__ inline uint32_t *block_ptr(const Params &P, uint32_t *tb, int blk) {

@@ -508,7 +508,10 @@ struct ActOut {              // smz_search_mlp_act: Game.policy_step folded into
 };
 constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
 #if SMZ_PART == 0 || SMZ_PART == 2 || SMZ_PART == 4
-template <int MAXA, int KS, int U, bool INSTR, bool AEX>
+// MSK: the handle has a per-tree on / off array (smz_set_active).  Without one the validity of a tree slot is a comparison
+// that is recomputed where needed; with one it is state that stays live through the search loop -- in the specialised
+// instantiation that costs scalar registers it does not have (35 -> 45 spilled, -3 % measured), so it exists both ways.
+template <int MAXA, int KS, int U, bool INSTR, bool AEX, bool MSK = true>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train, ActOut act) {
     Params P = Pin;
@@ -540,16 +543,16 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
 
     const int tree0 = (blockIdx.x * waves + wave) * tpw;
     const int tree = tree0 + lane;
-    const bool valid = lane < tpw && tree < P.B && tree_active(P, tree);
+    const bool valid = lane < tpw && tree < P.B && (!MSK || tree_active(P, tree));
     // a wave none of whose trees is searched (beyond B, or switched off with smz_set_active) is done: there is no
     // workgroup barrier after the weight staging above
-    if (__ballot(valid) == 0ull) return;
+    if (MSK && __ballot(valid) == 0ull) return;
 
     // ---- root: representation + prediction per row, then root expansion per lane ---------------------------------
     for (int t = 0; t < tpw; t++) {
         const int row = tree0 + t;
         if (row >= P.B) break;                                   // wave-uniform
-        if (!__shfl((int)valid, t)) continue;                    // wave-uniform: the tree is switched off
+        if (MSK && !__shfl((int)valid, t)) continue;             // wave-uniform: the tree is switched off
         smz_mlp::initial_row<U>(lds, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * P.hs,
                                 nullptr, outs + t * slot);
     }
@@ -565,6 +568,10 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         packed = rng.pack();
     }
     unsigned n_dec = 0, n_chance = 0, n_children = 0, n_desc = 0;
+    // (wave-uniform, read once: inside the rounds a lane picks its tree slot's flag with a select, not a cross-lane read)
+    // (one scalar register: the kernel is short of them, and a wave-uniform bool costs a 64-bit lane mask)
+    const int vmask = MSK ? __builtin_amdgcn_readlane((int)valid, 0) | (__builtin_amdgcn_readlane((int)valid, 1) << 1) : 3;
+#define SMZ_SLOT_VALID(src) (MSK ? ((vmask >> (src)) & 1) != 0 : tree0 + (src) < P.B)
     const bool prof = INSTR && (P.dbg & 16) && P.stats;
     const int dbg = INSTR ? P.dbg : 0;
     unsigned long long t_stage = 0, t_expand = 0, t_select = 0, t_mlp = 0, t0 = 0, t1 = 0;
@@ -593,7 +600,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
                 const int src = lane & (kFastTpw - 1);
                 const int len = __shfl(h.path_len, src);
                 const float lrw = __shfl(leaf_rw, src);
-                if (lane < 8 * kFastTpw && tree0 + src < P.B && __shfl((int)valid, src)) {
+                if (lane < 8 * kFastTpw && SMZ_SLOT_VALID(src)) {
                     const bool own = lane < kFastTpw;
                     float mn = own ? h.mn : __builtin_inff(), mx = own ? h.mx : -__builtin_inff(), v_root = 0.f;
                     backup_levels_lanes<kFastTpw>(P, tree0 + src, lane / kFastTpw, len, outs[src * slot + A], lrw,
@@ -622,8 +629,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
 
             const float hmn = __shfl(h.mn, src), hmx = __shfl(h.mx, src);
             const int hrv = __shfl(h.root_visit, src);
-            const bool src_valid = __shfl((int)valid, src) != 0;
-            if (lane < 4 && tree0 + src < P.B && src_valid) {
+            if (lane < 4 && SMZ_SLOT_VALID(src)) {
                 TreeHdr hs = h;
                 if (lane >= 2) {
                     rng.load(P.mt + (size_t)(tree0 + src) * kMtN, pk, rng_tile + src * kRngStride, kRngStage);
@@ -670,12 +676,12 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
             if (tree0 + 1 < P.B) {
                 const float *xin[2] = {xall, xall + K4in};
                 const bool dyn[2] = {b0 != 0, b1 != 0};
-                const bool live[2] = {__builtin_amdgcn_readlane((int)valid, 0) != 0, __builtin_amdgcn_readlane((int)valid, 1) != 0};
                 float *dh[2], *dp[2] = {outs, outs + slot};
                 float reward[2], value[2];
 #pragma unroll
                 for (int r = 0; r < 2; r++)
                     dh[r] = P.hidden + ((size_t)(tree0 + r) * P.N + __builtin_amdgcn_readlane(L.leaf_id, r)) * P.hs;
+                const bool live[2] = {MSK ? (vmask & 1) != 0 : true, MSK ? (vmask & 2) != 0 : true};
                 if (b0 == b1) smz_mlp::recurrent_rows<U, 2, true>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
                 else smz_mlp::recurrent_rows<U, 2, false>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
                 if (lane == 0) {
@@ -696,7 +702,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
             for (int r = 0; r < R; r++) {
                 live[r] = (t + r < tpw) && (tree0 + t + r < P.B);
                 const int tt = live[r] ? t + r : t;
-                live[r] = live[r] && __shfl((int)valid, tt) != 0;
+                live[r] = live[r] && (!MSK || __shfl((int)valid, tt) != 0);
                 const int row = tree0 + tt;
                 const int leaf = __builtin_amdgcn_readlane(L.leaf_id, tt);
                 dyn[r] = __builtin_amdgcn_readlane(L.branch, tt) != 0;
@@ -716,6 +722,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         SMZ_STAMP(t_stage)
     }
 #undef SMZ_STAMP
+#undef SMZ_SLOT_VALID
     if (INSTR && prof && lane == 0) {
         atomicAdd(&P.stats[4], t_stage); atomicAdd(&P.stats[5], t_expand);
         atomicAdd(&P.stats[6], t_select); atomicAdd(&P.stats[7], t_mlp);
@@ -1611,17 +1618,17 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave) * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_TOO_LARGE, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
-#define SMZ_LAUNCH_SEARCH(UU, INSTR, AEX)                                                                              \
+#define SMZ_LAUNCH_SEARCH(UU, INSTR, AEX, MSK)                                                                         \
     SMZ_SEARCH_DISPATCH2(h->maxa, h->K, {                                                                              \
         static size_t granted_dev[64] = {}; /* per instantiation and device: the opt-in is a host-side call */           \
         size_t &granted = granted_dev[h->cfg.device & 63];                                                             \
         if (lds > granted) {                                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU, INSTR, AEX>),              \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU, INSTR, AEX, MSK>),         \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)               \
                 return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                            \
             granted = lds;                                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR, AEX>), dim3(blocks), dim3(kWaves * kWave), lds,            \
+        hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR, AEX, MSK>), dim3(blocks), dim3(kWaves * kWave), lds,       \
                            (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act);                           \
     })
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
@@ -1636,9 +1643,10 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
                            P, *desc, weights_dev, obs_dev, train, act);
     } else
 #endif
-    if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false); }
-    else if (fast) { SMZ_LAUNCH_SEARCH(1, false, true); }
-    else { SMZ_LAUNCH_SEARCH(1, false, false); }
+    if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false, true); }
+    else if (fast && !P.active) { SMZ_LAUNCH_SEARCH(1, false, true, false); }
+    else if (fast) { SMZ_LAUNCH_SEARCH(1, false, true, true); }
+    else { SMZ_LAUNCH_SEARCH(1, false, false, true); }
 #undef SMZ_LAUNCH_SEARCH
     h->root_ready = true;
     h->selected = false;
