@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 
 #include "../../include/smz.h"
@@ -77,6 +78,212 @@ __global__ void __launch_bounds__(512) k_mlp_initial(smz_mlp_desc d, const float
         if (row >= B) break;
         initial_row<U>(lds, d, lds, d, scratch, obs + (size_t)row * d.obs, hidden_out + (size_t)row * d.S, nullptr,
                        policy_out + (size_t)row * d.A);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// Large batches: the recurrent networks of the shipped shape (S 31, H 64, L 0) on the matrix cores, 16 leaves per wavefront.
+//
+// k_mlp_recurrent evaluates one or two leaves per wavefront pass and re-reads the weights from LDS for each: at 10^5 - 10^6
+// leaves per launch that is the bound (1.2 ms per million leaves, ~11 % of the f32 FMA peak).  Here a wavefront takes a
+// TILE of 16 leaves: a layer is v_mfma_f32_16x16x4_f32 steps with A = 16 output neurons x 4 inputs of the LDS weight
+// image and B = 4 inputs x 16 leaves, so every weight read serves 16 leaves.  To round exactly like smz_mlp::dense() --
+// even inputs in one accumulator (from the bias), odd inputs in another (from zero), added at the end -- an MFMA step
+// takes four EVEN inputs (8c, 8c+2, 8c+4, 8c+6) or four ODD ones; inside a step the matrix core adds its four products
+// in input order to the accumulator with one rounding each (an f32 MFMA is an fma chain: profiles/r02_mfma_heads_ab.txt).
+// Activations sit in LDS as [input pair][leaf][2], so one ds_read_b64 per lane yields the B operands of an even and an odd
+// step; the packed weight layout [input / 4][neuron][4] yields both A operands with one ds_read_b64 as well.
+// The tails work on the MFMA output layout (lane = (neuron group g, leaf j), registers = neurons 16t + 4g + r of the four
+// 16-neuron tiles t): sums in the association of smz_mlp::wave_sum -- registers, lanes ^ 16, ^ 32, then tiles.
+// Bit-identical to k_mlp_recurrent (tests/test_gpu_mlp_heads.py).
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int kTileLeaves = 16, kMfmaWaves = 8;
+constexpr int kXPairs = 20, kHPairs = 32;            // input pairs of the x / hidden tile (36 -> 40 inputs) and of the trunk tile
+constexpr int kTileFloats = kXPairs * 32 + kHPairs * 32;
+
+__device__ inline float lane_xor16(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(((threadIdx.x & 16) ? r[0] : r[1]));
+}
+__device__ inline float lane_xor32(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(((threadIdx.x & 32) ? r[0] : r[1]));
+}
+// sum over the 64 output positions o = 16 t + 4 g + r of a leaf, a[t][r] = the lane's values (zeros for non-members)
+__device__ inline float tile_sum(const float (&a)[4][4]) {
+    float s[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) s[t] = (a[t][0] + a[t][1]) + (a[t][2] + a[t][3]);
+#pragma unroll
+    for (int t = 0; t < 4; t++) s[t] = s[t] + lane_xor16(s[t]);
+#pragma unroll
+    for (int t = 0; t < 4; t++) s[t] = s[t] + lane_xor32(s[t]);
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+__device__ inline float tile_max(float m) { m = fmaxf(m, lane_xor16(m)); return fmaxf(m, lane_xor32(m)); }
+__device__ inline float tile_min(float m) { m = fminf(m, lane_xor16(m)); return fminf(m, lane_xor32(m)); }
+
+// y[t][r] = bias[16t + 4g + r] + sum_k W[k][16t + 4g + r] * x[k][leaf j]: K8 groups of eight inputs, W = LDS weight image
+// (4-way interleaved, 64 outputs wide), xp = activation tile [input pair][leaf][2]
+template <int K8>
+__device__ inline void tile_layer(const float *W, const float *bias, const float *xp, int lane, v4f (&y)[4]) {
+    const int g = lane >> 4, j = lane & 15;
+    v4f e[4], o[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float4 b = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * g);
+        e[t] = v4f{b.x, b.y, b.z, b.w};
+        o[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < K8; c++) {
+        // B operands: inputs 8c + 2g (even step) and 8c + 2g + 1 (odd step) of leaf j
+        const float2 xb = *reinterpret_cast<const float2 *>(xp + ((4 * c + g) * kTileLeaves + j) * 2);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            // A operands: the weights of inputs 8c + 2g, 8c + 2g + 1 for neuron 16t + j
+            const float2 wa = *reinterpret_cast<const float2 *>(W + ((2 * c + (g >> 1)) * kWave + 16 * t + j) * 4 + 2 * (g & 1));
+            e[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, xb.x, e[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, xb.y, o[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) y[t] = e[t] + o[t];
+}
+// ELU of a trunk layer's outputs into the trunk tile (neuron n = input n of the next layer)
+__device__ inline void store_trunk(float *hp, const v4f (&y)[4], int lane) {
+    const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int n = 16 * t + 4 * g;
+        *reinterpret_cast<float2 *>(hp + (((n >> 1) + 0) * kTileLeaves + j) * 2) = make_float2(elu(y[t][0]), elu(y[t][1]));
+        *reinterpret_cast<float2 *>(hp + (((n >> 1) + 1) * kTileLeaves + j) * 2) = make_float2(elu(y[t][2]), elu(y[t][3]));
+    }
+}
+
+template <int A>
+__global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_mlp_desc d, const float *__restrict__ weights,
+                                                                          const float *__restrict__ x, const uint8_t *__restrict__ branch,
+                                                                          float *__restrict__ hidden_out, float *__restrict__ reward_out,
+                                                                          float *__restrict__ policy_out, float *__restrict__ value_out,
+                                                                          int B, int n_tiles) {
+    float *lds = reinterpret_cast<float *>(smz_mlp_lds4);
+    stage_recurrent_weights(lds, weights, d);
+    d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = kWave; d.A = A;
+    constexpr int S = kFastS, half = S / 2, XW = S + A;
+    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int g = lane >> 4, j = lane & 15;
+    float *xp = lds + d.total_floats + wave * kTileFloats, *hp = xp + kXPairs * 32;
+    for (int tile = blockIdx.x * kMfmaWaves + wave; tile < n_tiles; tile += gridDim.x * kMfmaWaves) {
+        const int row0 = tile * kTileLeaves;
+        const int row = row0 + j < B ? row0 + j : B - 1;                     // (a ragged last tile repeats its last row)
+        const bool live = row0 + j < B;
+        const bool dyn = branch[row] != 0;
+        const bool need[2] = {__ballot(live && dyn) != 0ull, __ballot(live && !dyn) != 0ull};
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {                               // 0: dynamics + prediction, 1: the afterstate pair
+            if (!need[pass]) continue;                                       // wave-uniform
+            const bool mine = live && (dyn == (pass == 0));
+            // network inputs [hidden | one-hot] of the 16 leaves -> x tile (inputs 36..39: zero)
+            for (int i = lane; i < kTileLeaves * 40; i += kWave) {
+                const int lf = i / 40, k = i % 40;
+                const int rr = row0 + lf < B ? row0 + lf : B - 1;
+                xp[((k >> 1) * kTileLeaves + lf) * 2 + (k & 1)] = k < XW ? x[(size_t)rr * XW + k] : 0.f;
+            }
+            lds_sync();
+            v4f y[4];
+            const MatOff m_in = pick(d, pass == 0, M_DYN_IN, M_ADY_IN), m_out = pick(d, pass == 0, M_DYN_OUT, M_ADY_OUT);
+            const MatOff p_in = pick(d, pass == 0, M_PRE_IN, M_APR_IN), p_out = pick(d, pass == 0, M_PRE_OUT, M_APR_OUT);
+            tile_layer<5>(lds + m_in.w, lds + m_in.b, xp, lane, y);
+            store_trunk(hp, y, lane);
+            lds_sync();
+            tile_layer<8>(lds + m_out.w, lds + m_out.b, hp, lane, y);
+            // dynamics: [reward logits 0..S-1 | next state S..2S-1]; afterstate dynamics: next state 0..S-1
+            float reward = 0.f;
+            {
+                const int lo = pass == 0 ? S : 0;
+                float mr = -__builtin_inff(), mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int o = 16 * t + 4 * g + r;
+                        if (pass == 0 && o < S) mr = fmaxf(mr, y[t][r]);
+                        if (o >= lo && o < lo + S) { mn = fminf(mn, y[t][r]); mx = fmaxf(mx, y[t][r]); }
+                    }
+                mn = tile_min(mn); mx = tile_max(mx);
+                if (pass == 0) {
+                    mr = tile_max(mr);
+                    float de[4][4], nu[4][4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int o = 16 * t + 4 * g + r;
+                            const float ev = o < S ? smz_exp(y[t][r] - mr) : 0.f;
+                            de[t][r] = ev;
+                            nu[t][r] = o < S ? 0.f + (float)(o - half) * ev : 0.f;
+                        }
+                    const float den = tile_sum(de), num = tile_sum(nu);
+                    reward = support_to_scalar(num, den);
+                }
+                float sc = mx - mn;
+                if (sc < 1e-5f) sc += 1e-5f;
+                // the new hidden state: prediction input (x tile, inputs 0..S-1; input S..: zero) and, for this pass's leaves, out
+                lds_sync();
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int o = 16 * t + 4 * g + r, k = o - lo;
+                        if (k >= 0 && k < 32) {
+                            const float hv = k < S ? __fdividef(y[t][r] - mn, sc) : 0.f;
+                            xp[((k >> 1) * kTileLeaves + j) * 2 + (k & 1)] = hv;
+                            if (k < S && mine) hidden_out[(size_t)row * S + k] = hv;
+                        }
+                    }
+            }
+            lds_sync();
+            tile_layer<4>(lds + p_in.w, lds + p_in.b, xp, lane, y);
+            store_trunk(hp, y, lane);
+            lds_sync();
+            tile_layer<8>(lds + p_out.w, lds + p_out.b, hp, lane, y);
+            {   // [policy logits 0..A-1 | value logits A..A+S-1]
+                float mp = -__builtin_inff(), mv = -__builtin_inff();
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int o = 16 * t + 4 * g + r;
+                        if (o < A) mp = fmaxf(mp, y[t][r]);
+                        else if (o < A + S) mv = fmaxf(mv, y[t][r]);
+                    }
+                mp = tile_max(mp); mv = tile_max(mv);
+                float ep[4][4], ev[4][4], nv[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int o = 16 * t + 4 * g + r;
+                        const bool pol = o < A, val = !pol && o < A + S;
+                        const float e = (pol || val) ? smz_exp(y[t][r] - (pol ? mp : mv)) : 0.f;
+                        ep[t][r] = pol ? e : 0.f;
+                        ev[t][r] = val ? e : 0.f;
+                        nv[t][r] = val ? 0.f + (float)(o - A - half) * e : 0.f;
+                    }
+                const float dp = tile_sum(ep), dv = tile_sum(ev), nvs = tile_sum(nv);
+                const float value = support_to_scalar(nvs, dv);
+                if (mine && g == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (r < A) policy_out[(size_t)row * A + r] = __fdividef(ep[0][r], dp);
+                    value_out[row] = value;
+                    if (reward_out) reward_out[row] = reward;
+                }
+            }
+            lds_sync();
+        }
     }
 }
 
@@ -158,6 +365,27 @@ int smz_mlp_recurrent(const smz_mlp_desc *d, const float *weights_dev, const flo
     int blocks, rpw;
     mlp_geometry(B, blocks, rpw);
     const size_t lds = ((size_t)d->total_floats + (size_t)kWavesPerWg * scratch_floats(*d)) * sizeof(float);
+    if (d->S == kFastS && d->H == kFastH && d->L == kFastL && (d->A == 2 || d->A == 4)) {
+        // large batches: 16-leaf tiles on the matrix cores (bit-identical; SMZ_MLP_MFMA_MIN = smallest batch that takes it)
+        int min_rows = 16384;
+        if (const char *e = getenv("SMZ_MLP_MFMA_MIN")) min_rows = atoi(e);
+        const size_t lds2 = ((size_t)d->total_floats + (size_t)kMfmaWaves * kTileFloats) * sizeof(float);
+        if (min_rows >= 0 && B >= min_rows && lds2 <= (size_t)kLdsBytes) {
+            const int n_tiles = (B + kTileLeaves - 1) / kTileLeaves;
+            int wgs = (n_tiles + kMfmaWaves - 1) / kMfmaWaves;
+            if (wgs > 256) wgs = 256;
+            if (d->A == 2) {
+                if (allow_lds(k_mlp_recurrent_mfma<2>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
+                hipLaunchKernelGGL((k_mlp_recurrent_mfma<2>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
+                                   mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, n_tiles);
+            } else {
+                if (allow_lds(k_mlp_recurrent_mfma<4>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
+                hipLaunchKernelGGL((k_mlp_recurrent_mfma<4>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
+                                   mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, n_tiles);
+            }
+            return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
+        }
+    }
     if (d->S == kFastS && d->H == kFastH && d->L == kFastL) {
         if (allow_lds(k_mlp_recurrent<1, true>, lds) != SMZ_OK) return SMZ_ERR_HIP;
         hipLaunchKernelGGL((k_mlp_recurrent<1, true>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
