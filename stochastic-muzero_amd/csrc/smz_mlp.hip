@@ -98,8 +98,7 @@ __global__ void __launch_bounds__(512) k_mlp_initial(smz_mlp_desc d, const float
 // Bit-identical to k_mlp_recurrent (tests/test_gpu_mlp_heads.py).
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kTileLeaves = 16, kMfmaWaves = 8;
-constexpr int kXPairs = 20, kHPairs = 32;            // input pairs of the x / hidden tile (36 -> 40 inputs) and of the trunk tile
-constexpr int kTileFloats = kXPairs * 32 + kHPairs * 32;
+constexpr int kTileFloats = 32 * 32;                 // one activation tile per wavefront: [32 input pairs][16 leaves][2]
 
 __device__ inline float lane_xor16(float v) {
     const unsigned u = __float_as_uint(v);
@@ -163,115 +162,131 @@ __device__ inline void store_trunk(float *hp, const v4f (&y)[4], int lane) {
     }
 }
 
+// Leaves of the two branches need different networks, so a workgroup first sorts the rows of its chunk by branch (two index
+// lists in LDS, filled with LDS atomics: the order inside a list is arbitrary, a leaf's result does not depend on its tile
+// mates) and forms single-branch tiles; one 64 x 16 activation tile per wavefront serves every layer in turn (each layer's
+// inputs are dead once its MFMAs have been issued and its outputs sit in registers).
+constexpr int kMaxChunk = 2048;
 template <int A>
 __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_mlp_desc d, const float *__restrict__ weights,
                                                                           const float *__restrict__ x, const uint8_t *__restrict__ branch,
                                                                           float *__restrict__ hidden_out, float *__restrict__ reward_out,
                                                                           float *__restrict__ policy_out, float *__restrict__ value_out,
-                                                                          int B, int n_tiles) {
+                                                                          int B, int chunk) {
     float *lds = reinterpret_cast<float *>(smz_mlp_lds4);
-    stage_recurrent_weights(lds, weights, d);
     d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = kWave; d.A = A;
+    const smz_mlp_desc dl = lds_desc_without_rep(d);           // LDS image: everything but the representation matrices
+    stage_weights_without_rep(lds, weights, d);
     constexpr int S = kFastS, half = S / 2, XW = S + A;
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int g = lane >> 4, j = lane & 15;
-    float *xp = lds + d.total_floats + wave * kTileFloats, *hp = xp + kXPairs * 32;
-    for (int tile = blockIdx.x * kMfmaWaves + wave; tile < n_tiles; tile += gridDim.x * kMfmaWaves) {
-        const int row0 = tile * kTileLeaves;
-        const int row = row0 + j < B ? row0 + j : B - 1;                     // (a ragged last tile repeats its last row)
-        const bool live = row0 + j < B;
-        const bool dyn = branch[row] != 0;
-        const bool need[2] = {__ballot(live && dyn) != 0ull, __ballot(live && !dyn) != 0ull};
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++) {                               // 0: dynamics + prediction, 1: the afterstate pair
-            if (!need[pass]) continue;                                       // wave-uniform
-            const bool mine = live && (dyn == (pass == 0));
-            // network inputs [hidden | one-hot] of the 16 leaves -> x tile (inputs 36..39: zero)
+    float *tile = lds + dl.total_floats + wave * kTileFloats;
+    unsigned short *list = reinterpret_cast<unsigned short *>(lds + dl.total_floats + kMfmaWaves * kTileFloats);   // [2][kMaxChunk]
+    int *cnt = reinterpret_cast<int *>(list + 2 * kMaxChunk);
+    for (int base = blockIdx.x * chunk; base < B; base += gridDim.x * chunk) {
+        const int n = B - base < chunk ? B - base : chunk;
+        if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int w = branch[base + i] != 0 ? 0 : 1;
+            list[w * kMaxChunk + atomicAdd(&cnt[w], 1)] = (unsigned short)i;
+        }
+        __syncthreads();
+        const int n0 = cnt[0], n1 = cnt[1], t0 = (n0 + kTileLeaves - 1) / kTileLeaves, t1 = (n1 + kTileLeaves - 1) / kTileLeaves;
+        for (int t = wave; t < t0 + t1; t += kMfmaWaves) {
+            const bool ady = t >= t0;                                        // wave-uniform
+            const int tt = ady ? t - t0 : t, count = (ady ? n1 : n0) - tt * kTileLeaves;   // leaves in this tile (>= 1; may exceed 16)
+            const unsigned short *li = list + (ady ? kMaxChunk : 0) + tt * kTileLeaves;
+            const bool mine = j < count;
+            const int row = base + li[mine ? j : 0];                         // (a ragged tile repeats its first row)
+            // network inputs [hidden | one-hot] of the 16 leaves -> tile (inputs 36..39: zero)
             for (int i = lane; i < kTileLeaves * 40; i += kWave) {
                 const int lf = i / 40, k = i % 40;
-                const int rr = row0 + lf < B ? row0 + lf : B - 1;
-                xp[((k >> 1) * kTileLeaves + lf) * 2 + (k & 1)] = k < XW ? x[(size_t)rr * XW + k] : 0.f;
+                const int rr = base + li[lf < count ? lf : 0];
+                tile[((k >> 1) * kTileLeaves + lf) * 2 + (k & 1)] = k < XW ? x[(size_t)rr * XW + k] : 0.f;
             }
             lds_sync();
             v4f y[4];
-            const MatOff m_in = pick(d, pass == 0, M_DYN_IN, M_ADY_IN), m_out = pick(d, pass == 0, M_DYN_OUT, M_ADY_OUT);
-            const MatOff p_in = pick(d, pass == 0, M_PRE_IN, M_APR_IN), p_out = pick(d, pass == 0, M_PRE_OUT, M_APR_OUT);
-            tile_layer<5>(lds + m_in.w, lds + m_in.b, xp, lane, y);
-            store_trunk(hp, y, lane);
+            const MatOff m_in = pick(dl, !ady, M_DYN_IN, M_ADY_IN), m_out = pick(dl, !ady, M_DYN_OUT, M_ADY_OUT);
+            const MatOff p_in = pick(dl, !ady, M_PRE_IN, M_APR_IN), p_out = pick(dl, !ady, M_PRE_OUT, M_APR_OUT);
+            tile_layer<5>(lds + m_in.w, lds + m_in.b, tile, lane, y);
             lds_sync();
-            tile_layer<8>(lds + m_out.w, lds + m_out.b, hp, lane, y);
+            store_trunk(tile, y, lane);
+            lds_sync();
+            tile_layer<8>(lds + m_out.w, lds + m_out.b, tile, lane, y);
             // dynamics: [reward logits 0..S-1 | next state S..2S-1]; afterstate dynamics: next state 0..S-1
             float reward = 0.f;
             {
-                const int lo = pass == 0 ? S : 0;
+                const int lo = ady ? 0 : S;
                 float mr = -__builtin_inff(), mn = __builtin_inff(), mx = -__builtin_inff();
 #pragma unroll
-                for (int t = 0; t < 4; t++)
+                for (int t4 = 0; t4 < 4; t4++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int o = 16 * t + 4 * g + r;
-                        if (pass == 0 && o < S) mr = fmaxf(mr, y[t][r]);
-                        if (o >= lo && o < lo + S) { mn = fminf(mn, y[t][r]); mx = fmaxf(mx, y[t][r]); }
+                        const int o = 16 * t4 + 4 * g + r;
+                        if (!ady && o < S) mr = fmaxf(mr, y[t4][r]);
+                        if (o >= lo && o < lo + S) { mn = fminf(mn, y[t4][r]); mx = fmaxf(mx, y[t4][r]); }
                     }
                 mn = tile_min(mn); mx = tile_max(mx);
-                if (pass == 0) {
+                if (!ady) {
                     mr = tile_max(mr);
                     float de[4][4], nu[4][4];
 #pragma unroll
-                    for (int t = 0; t < 4; t++)
+                    for (int t4 = 0; t4 < 4; t4++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const int o = 16 * t + 4 * g + r;
-                            const float ev = o < S ? smz_exp(y[t][r] - mr) : 0.f;
-                            de[t][r] = ev;
-                            nu[t][r] = o < S ? 0.f + (float)(o - half) * ev : 0.f;
+                            const int o = 16 * t4 + 4 * g + r;
+                            const float ev = o < S ? smz_exp(y[t4][r] - mr) : 0.f;
+                            de[t4][r] = ev;
+                            nu[t4][r] = o < S ? 0.f + (float)(o - half) * ev : 0.f;
                         }
                     const float den = tile_sum(de), num = tile_sum(nu);
                     reward = support_to_scalar(num, den);
                 }
                 float sc = mx - mn;
                 if (sc < 1e-5f) sc += 1e-5f;
-                // the new hidden state: prediction input (x tile, inputs 0..S-1; input S..: zero) and, for this pass's leaves, out
+                // the new hidden state: prediction input (tile inputs 0..S-1; input S: zero) and, for the tile's leaves, out
                 lds_sync();
 #pragma unroll
-                for (int t = 0; t < 4; t++)
+                for (int t4 = 0; t4 < 4; t4++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int o = 16 * t + 4 * g + r, k = o - lo;
+                        const int o = 16 * t4 + 4 * g + r, k = o - lo;
                         if (k >= 0 && k < 32) {
-                            const float hv = k < S ? __fdividef(y[t][r] - mn, sc) : 0.f;
-                            xp[((k >> 1) * kTileLeaves + j) * 2 + (k & 1)] = hv;
+                            const float hv = k < S ? __fdividef(y[t4][r] - mn, sc) : 0.f;
+                            tile[((k >> 1) * kTileLeaves + j) * 2 + (k & 1)] = hv;
                             if (k < S && mine) hidden_out[(size_t)row * S + k] = hv;
                         }
                     }
             }
             lds_sync();
-            tile_layer<4>(lds + p_in.w, lds + p_in.b, xp, lane, y);
-            store_trunk(hp, y, lane);
+            tile_layer<4>(lds + p_in.w, lds + p_in.b, tile, lane, y);
             lds_sync();
-            tile_layer<8>(lds + p_out.w, lds + p_out.b, hp, lane, y);
+            store_trunk(tile, y, lane);
+            lds_sync();
+            tile_layer<8>(lds + p_out.w, lds + p_out.b, tile, lane, y);
             {   // [policy logits 0..A-1 | value logits A..A+S-1]
                 float mp = -__builtin_inff(), mv = -__builtin_inff();
 #pragma unroll
-                for (int t = 0; t < 4; t++)
+                for (int t4 = 0; t4 < 4; t4++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int o = 16 * t + 4 * g + r;
-                        if (o < A) mp = fmaxf(mp, y[t][r]);
-                        else if (o < A + S) mv = fmaxf(mv, y[t][r]);
+                        const int o = 16 * t4 + 4 * g + r;
+                        if (o < A) mp = fmaxf(mp, y[t4][r]);
+                        else if (o < A + S) mv = fmaxf(mv, y[t4][r]);
                     }
                 mp = tile_max(mp); mv = tile_max(mv);
                 float ep[4][4], ev[4][4], nv[4][4];
 #pragma unroll
-                for (int t = 0; t < 4; t++)
+                for (int t4 = 0; t4 < 4; t4++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int o = 16 * t + 4 * g + r;
+                        const int o = 16 * t4 + 4 * g + r;
                         const bool pol = o < A, val = !pol && o < A + S;
-                        const float e = (pol || val) ? smz_exp(y[t][r] - (pol ? mp : mv)) : 0.f;
-                        ep[t][r] = pol ? e : 0.f;
-                        ev[t][r] = val ? e : 0.f;
-                        nv[t][r] = val ? 0.f + (float)(o - A - half) * e : 0.f;
+                        const float e = (pol || val) ? smz_exp(y[t4][r] - (pol ? mp : mv)) : 0.f;
+                        ep[t4][r] = pol ? e : 0.f;
+                        ev[t4][r] = val ? e : 0.f;
+                        nv[t4][r] = val ? 0.f + (float)(o - A - half) * e : 0.f;
                     }
                 const float dp = tile_sum(ep), dv = tile_sum(ev), nvs = tile_sum(nv);
                 const float value = support_to_scalar(nvs, dv);
@@ -284,6 +299,7 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
             }
             lds_sync();
         }
+        __syncthreads();                                                     // the lists are refilled for the next chunk
     }
 }
 
@@ -369,19 +385,24 @@ int smz_mlp_recurrent(const smz_mlp_desc *d, const float *weights_dev, const flo
         // large batches: 16-leaf tiles on the matrix cores (bit-identical; SMZ_MLP_MFMA_MIN = smallest batch that takes it)
         int min_rows = 16384;
         if (const char *e = getenv("SMZ_MLP_MFMA_MIN")) min_rows = atoi(e);
-        const size_t lds2 = ((size_t)d->total_floats + (size_t)kMfmaWaves * kTileFloats) * sizeof(float);
+        const size_t lds2 = ((size_t)(d->total_floats - rep_floats(*d)) + (size_t)kMfmaWaves * kTileFloats) * sizeof(float) +
+                            2 * kMaxChunk * sizeof(unsigned short) + 16;
+        if (min_rows == 0 && lds2 > (size_t)kLdsBytes) return SMZ_ERR_TOO_LARGE;     // (forced: say so instead of falling back)
         if (min_rows >= 0 && B >= min_rows && lds2 <= (size_t)kLdsBytes) {
-            const int n_tiles = (B + kTileLeaves - 1) / kTileLeaves;
-            int wgs = (n_tiles + kMfmaWaves - 1) / kMfmaWaves;
+            // rows per workgroup pass: enough chunks for 256 workgroups, a multiple of 128, at most kMaxChunk
+            int chunk = ((B + 255) / 256 + 127) / 128 * 128;
+            if (chunk < 256) chunk = 256;
+            if (chunk > kMaxChunk) chunk = kMaxChunk;
+            int wgs = (B + chunk - 1) / chunk;
             if (wgs > 256) wgs = 256;
             if (d->A == 2) {
                 if (allow_lds(k_mlp_recurrent_mfma<2>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
                 hipLaunchKernelGGL((k_mlp_recurrent_mfma<2>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
-                                   mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, n_tiles);
+                                   mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, chunk);
             } else {
                 if (allow_lds(k_mlp_recurrent_mfma<4>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
                 hipLaunchKernelGGL((k_mlp_recurrent_mfma<4>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
-                                   mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, n_tiles);
+                                   mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, chunk);
             }
             return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
         }
