@@ -238,3 +238,60 @@ def test_philox_mode_equals_the_oracle_drawing_from_the_same_counter_stream(wnam
     # a second search continues every stream (no re-seeding): still the oracle's
     m.run(torch.from_numpy(obs).cuda(), heads, train=True)
     torch.cuda.synchronize()
+
+
+def test_vision_search_kernel_equals_oracle_on_every_tree():
+    """The same chain for the `vision_model` family at the size bench.py times (1024 trees x 50 simulations, 98x98x3
+    frames, hidden state 3x7x7): the step-wise kernels with the hand-written vision heads (smz_vision_initial /
+    smz_vision_recurrent) record a net-output tape, the oracle replays it on 1024 trees of its own -- same leaf, parent,
+    action, branch and parent hidden row at every simulation, same final trees and stream positions -- and the
+    single-launch kernel (smz_search_vision_act: conv nets per wavefront, towers as v_mfma_f32_4x4x1 chains, trees in LDS)
+    must equal both, with the action selection of its tail.  neural_network_vision_model.py:41-515, mcts:311-349."""
+    import orc
+    import stochastic_muzero_amd as smz
+    mcts_mod, model_mod = _mods()
+    model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L1_seed0.npz"))
+    heads = model.heads("cuda:0")
+    B, sims, K, T, A, S = 1024, 50, 2, 1.0, heads.A, 147
+    frames = torch.rand(B, 3, 98, 98, generator=torch.Generator().manual_seed(2)).cuda()
+    seeds = np.arange(B, dtype=np.uint64) + 77
+    eng = smz.SearchEngine(B, A, S, num_simulations=sims, maxium_action_sample=K, discount=DISCOUNT,
+                           root_dirichlet_alpha=ALPHA, root_exploration_fraction=FRAC)
+    eng.seed(seeds)
+    hidden, policy = heads.initial(frames)
+    torch.cuda.synchronize()
+    root_hidden, root_policy = hidden.reshape(B, -1).cpu().numpy().copy(), policy.cpu().numpy().copy()
+    cfg = orc.make_cfg(A, K, S, sims, discount=DISCOUNT, alpha=ALPHA, frac=FRAC)
+    trees, noise = [], np.zeros((B, A), np.float64)
+    for i in range(B):
+        t = orc.Tree(cfg); t.seed(int(seeds[i]))
+        noise[i] = t.root_init(root_policy[i], hidden=root_hidden[i], train=True)
+        trees.append(t)
+    eng.root_init(hidden.reshape(B, -1), policy, train=True, noise_override=torch.from_numpy(noise).cuda())
+    tape = []
+    for s in range(sims):
+        eng.select(want_mlp_input=False, want_parent_hidden=True)
+        h2, rw, pol, val = heads.recurrent(eng)
+        torch.cuda.synchronize()
+        tape.append(dict(action=eng.last_action.cpu().numpy().copy(), branch=eng.branch.cpu().numpy().copy(),
+                         parent_hidden=eng.parent_hidden.cpu().numpy()[:, :S].copy(), hidden=h2.reshape(B, -1).cpu().numpy().copy(),
+                         reward=rw.cpu().numpy().copy(), policy=pol.cpu().numpy().copy(), value=val.cpu().numpy().copy()))
+        eng.expand_backup(h2.reshape(B, -1), rw, pol, val)
+    torch.cuda.synchronize()
+    oracle_replay(trees, tape)
+    assert_engine_equals_oracle(eng, trees, sims, prior_rtol=0)
+    eng.close()
+    m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=K, discount=DISCOUNT, root_dirichlet_alpha=ALPHA,
+                             root_exploration_fraction=FRAC, use_graph=False, single_launch=True)
+    m.seed(seeds)
+    e = m.run(frames, heads, train=True, act_temperature=T)
+    assert m._single is True and e._act_done == T
+    action, pol_out, child_visits, root_value = (t.clone() for t in e.act(T))
+    torch.cuda.synchronize()
+    oa = [trees[i].act(T) for i in range(B)]
+    n_exact = assert_engine_equals_oracle_after_act(e, trees, sims)
+    assert np.array_equal(action.cpu().numpy(), np.array([a[0] for a in oa], np.int32))
+    assert np.array_equal(pol_out.cpu().numpy(), np.stack([a[1] for a in oa]))
+    assert np.array_equal(child_visits.cpu().numpy(), np.stack([a[2] for a in oa]))
+    assert np.array_equal(root_value.cpu().numpy(), np.array([a[3] for a in oa], np.float32))
+    print(f"[vision 1024x50] single-launch == oracle on all {B} trees; f64 root priors bit-identical with device-drawn noise: {n_exact}/{B}")
