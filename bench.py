@@ -402,18 +402,18 @@ def main():
         # kernel in front of every repetition lets the host enqueue the whole search before the GPU starts on it, so an
         # event pair brackets the kernel alone (an idle queue would stamp e0 early and add the host's launch latency).
         hidden, policy = heads.initial(env.obs)
+        want = (heads.bind_engine(eng) if hasattr(heads, "bind_engine") else
+                dict(want_mlp_input=getattr(heads, "wants_mlp_input", True), want_parent_hidden=getattr(heads, "wants_parent_hidden", False)))
         tdurs = []
         for _ in range(min(reps, 4)):
             eng.root_init(hidden, policy, train=True)
-            eng.select(want_mlp_input=getattr(heads, "wants_mlp_input", True),
-                       want_parent_hidden=getattr(heads, "wants_parent_hidden", False))
+            eng.select(**want)
             torch.cuda._sleep(2_000_000)
             for s in range(wl["sims"] - 1):
                 o = heads.recurrent(eng)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                eng.expand_backup_select(*o, want_mlp_input=getattr(heads, "wants_mlp_input", True),
-                                         want_parent_hidden=getattr(heads, "wants_parent_hidden", False))
+                eng.expand_backup_select(*o, **want)
                 e1.record()
                 tdurs.append((e0, e1))
             eng.expand_backup(*heads.recurrent(eng))

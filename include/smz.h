@@ -124,6 +124,16 @@ int smz_rng_restore(smz_handle *h, smz_stream stream);
  * (self_play.py:79): a finished game stops consuming simulations.  The array is read when the kernels run, so the
  * env-step kernel may clear entries on the same stream (smz_cartpole_step_ctl). */
 int smz_set_active(smz_handle *h, const uint8_t *active_dev);
+/* Large batches: the row moves of a simulation round can be left to the network kernel.  When ids_dev is set, every
+ * selection (smz_select, smz_expand_backup_select) also writes, per tree, the node ids of the selected leaf and of its
+ * parent to ids_dev [B][2] i32 ({-1, -1} for a tree switched off with smz_set_active); a network kernel then reads the
+ * parent's hidden row from the handle's storage and writes the leaf's row into it (smz_mlp_recurrent_rows), and the tree
+ * entry points are called with NULL for their row arguments (parent_hidden / mlp_input outputs, hidden input).  NULL
+ * switches it off.  ids_dev is read by later launches: it must stay alive.  mcts:270-286 (leaf I/O of the nets). */
+int smz_set_leaf_ids_out(smz_handle *h, int32_t *ids_dev);
+/* Hidden-state storage of the handle: the row of node n of tree t starts at hidden + ((size_t)t * nodes_per_tree + n) *
+ * row_stride floats (hidden_size floats used). */
+int smz_get_hidden_layout(smz_handle *h, float **hidden_dev_out, int *nodes_per_tree_out, int *row_stride_out);
 
 /* ---- the search (one call per phase of Monte_carlo_tree_search.run, mcts:311-349) ----------------------------- */
 /* Root: resets the trees and MinMaxStats, stores the root hidden state, normalises the root policy, creates all A
@@ -309,6 +319,15 @@ int smz_search_vision_act(smz_handle *h, const smz_vision_desc *desc, const floa
                           const float *policy0_dev, int train, double temperature, const double *pow_table_host,
                           int32_t *action_dev, double *policy_dev, double *child_visits_dev, float *root_value_dev,
                           smz_stream stream);
+
+/* smz_mlp_recurrent on rows that live in a handle's hidden-state storage (smz_get_hidden_layout): leaf i's network input
+ * is the hidden row of node ids_dev[2i+1] of tree i plus the one-hot of last_action_dev[i], its new hidden row is written
+ * to node ids_dev[2i] of tree i; rows with ids < 0 are skipped.  Matrix-core kernel of the shipped network shape
+ * (state_space_dimensions 31, hidden_layer_dimensions 64, number_of_hidden_layer 0, 2 or 4 actions): SMZ_ERR_TOO_LARGE for
+ * any other shape -- use smz_mlp_recurrent then.  Same outputs, bit for bit.  muzero_model.py:844-909. */
+int smz_mlp_recurrent_rows(const smz_mlp_desc *desc, const float *weights_dev, float *hidden_dev, int nodes_per_tree,
+                           int row_stride, const int32_t *ids_dev, const int32_t *last_action_dev, const uint8_t *branch_dev,
+                           float *reward_out_dev, float *policy_out_dev, float *value_out_dev, int B, smz_stream stream);
 
 /* ---- synthetic environment + trajectory record (self_play.py:63-98 loop body around the search) -------------- */
 /* CartPole-v1 shaped Euler step on device (float64 state, float32 observation), used for the synthetic

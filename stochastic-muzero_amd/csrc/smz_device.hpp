@@ -63,6 +63,8 @@ struct Params {
     uint32_t *rng_block;        // [B]  (philox) 624-word blocks consumed so far: word (block, idx) of a tree is component
                                 //      idx & 3 of philox(counter = block * 156 + idx / 4, key); rng_pos keeps idx
     const uint32_t *rng_key;    // [B][2] (philox)
+    int32_t *ids_out;           // [B][2] or nullptr: every selection also writes (leaf node id, parent node id) per tree
+                                // ({-1, -1} for a switched-off tree): smz_set_leaf_ids_out
     int32_t tree0;              // index of the tree whose blocks `nodes` points at: 0, except in a kernel that keeps its workgroup's
                                 // trees in LDS for the search (k_search_vision) and points `nodes` there
 };

@@ -375,6 +375,10 @@ __device__ inline void select_phase(const Params &P, int tree, bool valid, RNG &
         if (last_action) last_action[tree] = L.action;
         if (branch) branch[tree] = (uint8_t)L.branch;
     }
+    if (P.ids_out && (int)threadIdx.x < P.tpw && tree < P.B) {
+        P.ids_out[2 * (size_t)tree] = valid ? L.leaf_id : -1;
+        P.ids_out[2 * (size_t)tree + 1] = valid ? L.parent_id : -1;
+    }
     if (P.S > 0 && (parent_hidden || mlp_input))
         wave_gather_inputs(P, tree, valid, L.parent_id, L.action, parent_hidden, mlp_input);
     wave_add_stats(P.stats, n_dec, n_chance, valid ? 1u : 0u, n_children);
@@ -1798,6 +1802,20 @@ int smz_synthetic_obs(float *obs_dev, int B, int obs_dim, uint64_t seed, int64_t
 int smz_set_active(smz_handle *h, const uint8_t *active_dev) {
     if (!h) return fail(SMZ_ERR_INVALID, "smz_set_active: null handle%s");
     h->P.active = active_dev;
+    return SMZ_OK;
+}
+
+int smz_set_leaf_ids_out(smz_handle *h, int32_t *ids_dev) {
+    if (!h) return fail(SMZ_ERR_INVALID, "smz_set_leaf_ids_out: null handle%s");
+    h->P.ids_out = ids_dev;
+    return SMZ_OK;
+}
+
+int smz_get_hidden_layout(smz_handle *h, float **hidden_dev_out, int *nodes_per_tree_out, int *row_stride_out) {
+    if (!h || !hidden_dev_out || !nodes_per_tree_out || !row_stride_out) return fail(SMZ_ERR_INVALID, "smz_get_hidden_layout: null argument%s");
+    *hidden_dev_out = h->P.hidden;
+    *nodes_per_tree_out = h->P.N;
+    *row_stride_out = h->P.hs;
     return SMZ_OK;
 }
 

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(512) k_mlp_initial(smz_mlp_desc d, const float
 // 16-neuron tiles t): sums in the association of smz_mlp::wave_sum -- registers, lanes ^ 16, ^ 32, then tiles.
 // Bit-identical to k_mlp_recurrent (tests/test_gpu_mlp_heads.py).
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kTileLeaves = 16, kMfmaWaves = 8;
+constexpr int kTileLeaves = 16, kMfmaWaves = 12;
 constexpr int kTileFloats = 32 * 32;                 // one activation tile per wavefront: [32 input pairs][16 leaves][2]
 
 __device__ inline float lane_xor16(float v) {
@@ -167,12 +167,19 @@ __device__ inline void store_trunk(float *hp, const v4f (&y)[4], int lane) {
 // mates) and forms single-branch tiles; one 64 x 16 activation tile per wavefront serves every layer in turn (each layer's
 // inputs are dead once its MFMAs have been issued and its outputs sit in registers).
 constexpr int kMaxChunk = 2048;
-template <int A>
+// ROWS: network inputs and new hidden rows live in a search handle's hidden-state storage (smz_mlp_recurrent_rows): row of
+// node n of tree t = tree_hidden + (t * tree_n + n) * tree_hs; ids [B][2] = (leaf node, parent node) per tree, < 0: skip.
+struct TreeRows {
+    float *hidden;
+    const int32_t *ids, *last_action;
+    int n, hs;
+};
+template <int A, bool ROWS>
 __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_mlp_desc d, const float *__restrict__ weights,
                                                                           const float *__restrict__ x, const uint8_t *__restrict__ branch,
                                                                           float *__restrict__ hidden_out, float *__restrict__ reward_out,
                                                                           float *__restrict__ policy_out, float *__restrict__ value_out,
-                                                                          int B, int chunk) {
+                                                                          int B, int chunk, TreeRows tr) {
     float *lds = reinterpret_cast<float *>(smz_mlp_lds4);
     d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = kWave; d.A = A;
     const smz_mlp_desc dl = lds_desc_without_rep(d);           // LDS image: everything but the representation matrices
@@ -188,23 +195,46 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
         if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            if (ROWS && tr.ids[2 * (size_t)(base + i)] < 0) continue;        // a tree that is switched off
             const int w = branch[base + i] != 0 ? 0 : 1;
             list[w * kMaxChunk + atomicAdd(&cnt[w], 1)] = (unsigned short)i;
         }
         __syncthreads();
         const int n0 = cnt[0], n1 = cnt[1], t0 = (n0 + kTileLeaves - 1) / kTileLeaves, t1 = (n1 + kTileLeaves - 1) / kTileLeaves;
+        // network inputs of a tile: 16 leaves x 40 inputs = 10 values per lane, fetched one tile ahead (the rows of a tile are
+        // scattered over the batch -- or, ROWS, over the trees' hidden-state storage: a DRAM round trip the MFMAs of the
+        // current tile hide)
+        auto fetch = [&](int t, float (&v)[10]) {
+            const bool ady = t >= t0;
+            const int tt = ady ? t - t0 : t, count = (ady ? n1 : n0) - tt * kTileLeaves;
+            const unsigned short *li = list + (ady ? kMaxChunk : 0) + tt * kTileLeaves;
+#pragma unroll
+            for (int u = 0; u < 10; u++) {
+                const int i = lane + kWave * u, lf = i / 40, k = i % 40;
+                const int rr = base + li[lf < count ? lf : 0];
+                float val = 0.f;
+                if (ROWS) {
+                    if (k < S) val = tr.hidden[((size_t)rr * tr.n + tr.ids[2 * (size_t)rr + 1]) * tr.hs + k];
+                    else if (k < XW) val = (k - S) == tr.last_action[rr] ? 1.f : 0.f;
+                } else if (k < XW) val = x[(size_t)rr * XW + k];
+                v[u] = val;
+            }
+        };
+        float xin[10];
+        if (wave < t0 + t1) fetch(wave, xin);
         for (int t = wave; t < t0 + t1; t += kMfmaWaves) {
             const bool ady = t >= t0;                                        // wave-uniform
             const int tt = ady ? t - t0 : t, count = (ady ? n1 : n0) - tt * kTileLeaves;   // leaves in this tile (>= 1; may exceed 16)
             const unsigned short *li = list + (ady ? kMaxChunk : 0) + tt * kTileLeaves;
             const bool mine = j < count;
             const int row = base + li[mine ? j : 0];                         // (a ragged tile repeats its first row)
-            // network inputs [hidden | one-hot] of the 16 leaves -> tile (inputs 36..39: zero)
-            for (int i = lane; i < kTileLeaves * 40; i += kWave) {
-                const int lf = i / 40, k = i % 40;
-                const int rr = base + li[lf < count ? lf : 0];
-                tile[((k >> 1) * kTileLeaves + lf) * 2 + (k & 1)] = k < XW ? x[(size_t)rr * XW + k] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 10; u++) {
+                const int i = lane + kWave * u, lf = i / 40, k = i % 40;
+                tile[((k >> 1) * kTileLeaves + lf) * 2 + (k & 1)] = xin[u];
             }
+            if (t + kMfmaWaves < t0 + t1) fetch(t + kMfmaWaves, xin);      // (in flight during this tile's layers)
+            float *hrow = ROWS ? tr.hidden + ((size_t)row * tr.n + tr.ids[2 * (size_t)row]) * tr.hs : hidden_out + (size_t)row * S;
             lds_sync();
             v4f y[4];
             const MatOff m_in = pick(dl, !ady, M_DYN_IN, M_ADY_IN), m_out = pick(dl, !ady, M_DYN_OUT, M_ADY_OUT);
@@ -255,7 +285,7 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
                         if (k >= 0 && k < 32) {
                             const float hv = k < S ? __fdividef(y[t4][r] - mn, sc) : 0.f;
                             tile[((k >> 1) * kTileLeaves + j) * 2 + (k & 1)] = hv;
-                            if (k < S && mine) hidden_out[(size_t)row * S + k] = hv;
+                            if (k < S && mine) hrow[k] = hv;
                         }
                     }
             }
@@ -396,13 +426,13 @@ int smz_mlp_recurrent(const smz_mlp_desc *d, const float *weights_dev, const flo
             int wgs = (B + chunk - 1) / chunk;
             if (wgs > 256) wgs = 256;
             if (d->A == 2) {
-                if (allow_lds(k_mlp_recurrent_mfma<2>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
-                hipLaunchKernelGGL((k_mlp_recurrent_mfma<2>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
-                                   mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, chunk);
+                if (allow_lds(k_mlp_recurrent_mfma<2, false>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
+                hipLaunchKernelGGL((k_mlp_recurrent_mfma<2, false>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
+                                   mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, chunk, TreeRows{});
             } else {
-                if (allow_lds(k_mlp_recurrent_mfma<4>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
-                hipLaunchKernelGGL((k_mlp_recurrent_mfma<4>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
-                                   mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, chunk);
+                if (allow_lds(k_mlp_recurrent_mfma<4, false>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
+                hipLaunchKernelGGL((k_mlp_recurrent_mfma<4, false>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
+                                   mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, chunk, TreeRows{});
             }
             return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
         }
@@ -417,6 +447,34 @@ int smz_mlp_recurrent(const smz_mlp_desc *d, const float *weights_dev, const flo
         hipLaunchKernelGGL((k_mlp_recurrent<1, false>), dim3(blocks), dim3(kWavesPerWg * kWave), lds, (hipStream_t)stream, *d,
                            weights_dev, mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev,
                            value_out_dev, B, rpw);
+    }
+    return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
+}
+
+int smz_mlp_recurrent_rows(const smz_mlp_desc *d, const float *weights_dev, float *hidden_dev, int nodes_per_tree,
+                           int row_stride, const int32_t *ids_dev, const int32_t *last_action_dev, const uint8_t *branch_dev,
+                           float *reward_out_dev, float *policy_out_dev, float *value_out_dev, int B, smz_stream stream) {
+    if (mlp_check(d, weights_dev) != SMZ_OK || !hidden_dev || !ids_dev || !last_action_dev || !branch_dev || !policy_out_dev ||
+        !value_out_dev || B < 1 || nodes_per_tree < 1 || row_stride < d->S)
+        return SMZ_ERR_INVALID;
+    const size_t lds2 = ((size_t)(d->total_floats - rep_floats(*d)) + (size_t)kMfmaWaves * kTileFloats) * sizeof(float) +
+                        2 * kMaxChunk * sizeof(unsigned short) + 16;
+    if (!(d->S == kFastS && d->H == kFastH && d->L == kFastL && (d->A == 2 || d->A == 4)) || lds2 > (size_t)kLdsBytes)
+        return SMZ_ERR_TOO_LARGE;
+    int chunk = ((B + 255) / 256 + 127) / 128 * 128;
+    if (chunk < 256) chunk = 256;
+    if (chunk > kMaxChunk) chunk = kMaxChunk;
+    int wgs = (B + chunk - 1) / chunk;
+    if (wgs > 256) wgs = 256;
+    const TreeRows tr = {hidden_dev, ids_dev, last_action_dev, nodes_per_tree, row_stride};
+    if (d->A == 2) {
+        if (allow_lds(k_mlp_recurrent_mfma<2, true>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
+        hipLaunchKernelGGL((k_mlp_recurrent_mfma<2, true>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
+                           nullptr, branch_dev, nullptr, reward_out_dev, policy_out_dev, value_out_dev, B, chunk, tr);
+    } else {
+        if (allow_lds(k_mlp_recurrent_mfma<4, true>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
+        hipLaunchKernelGGL((k_mlp_recurrent_mfma<4, true>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
+                           nullptr, branch_dev, nullptr, reward_out_dev, policy_out_dev, value_out_dev, B, chunk, tr);
     }
     return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
 }

@@ -93,6 +93,22 @@ class SearchEngine:
         self._active = active
         _lib.check(self.lib.smz_set_active(self.h, _ptr(active)))
 
+    def enable_leaf_ids(self, on=True):
+        """smz_set_leaf_ids_out: every selection also writes (leaf node id, parent node id) per tree to `self.leaf_ids`
+        [B,2] int32, so that a network kernel can take and put its rows in the tree's own hidden-state storage
+        (heads.HipMlpHeads at large batches) and the tree kernels move no rows."""
+        if on and getattr(self, "leaf_ids", None) is None:
+            self.leaf_ids = torch.full((self.B, 2), -1, dtype=torch.int32, device=self.device)
+        if not on:
+            self.leaf_ids = None
+        _lib.check(self.lib.smz_set_leaf_ids_out(self.h, _ptr(self.leaf_ids if on else None)))
+
+    def hidden_layout(self):
+        """(device address of the hidden-state storage, nodes per tree, floats between rows): smz_get_hidden_layout."""
+        base, n, hs = C.c_void_p(), C.c_int(), C.c_int()
+        _lib.check(self.lib.smz_get_hidden_layout(self.h, C.byref(base), C.byref(n), C.byref(hs)))
+        return base, n.value, hs.value
+
     # ---- random streams ------------------------------------------------------------------------------------------
     def seed(self, seeds):
         """numpy `seed(int)` per tree; a scalar s seeds tree i with s + i."""
@@ -147,13 +163,14 @@ class SearchEngine:
         return self.parent_hidden, self.last_action, self.branch, self.mlp_input
 
     def expand_backup(self, hidden, reward, policy, value):
-        hidden = self._f32(hidden.reshape(self.B, -1), (self.B, self.S)) if self.S > 0 else None
+        # (hidden None: the leaf rows are in the tree already -- smz_mlp_recurrent_rows wrote them)
+        hidden = self._f32(hidden.reshape(self.B, -1), (self.B, self.S)) if (self.S > 0 and hidden is not None) else None
         _lib.check(self.lib.smz_expand_backup(self.h, _ptr(hidden), _ptr(None if reward is None else self._f32(reward, (self.B,))),
                                               _ptr(self._f32(policy, (self.B, self.A))), _ptr(self._f32(value, (self.B,))),
                                               self._stream()))
 
     def expand_backup_select(self, hidden, reward, policy, value, want_mlp_input=True, want_parent_hidden=True):
-        hidden = self._f32(hidden.reshape(self.B, -1), (self.B, self.S)) if self.S > 0 else None
+        hidden = self._f32(hidden.reshape(self.B, -1), (self.B, self.S)) if (self.S > 0 and hidden is not None) else None
         _lib.check(self.lib.smz_expand_backup_select(
             self.h, _ptr(hidden), _ptr(None if reward is None else self._f32(reward, (self.B,))),
             _ptr(self._f32(policy, (self.B, self.A))), _ptr(self._f32(value, (self.B,))),

@@ -150,6 +150,7 @@ class HipMlpHeads:
     weights packed once into the LDS layout described in include/smz.h, no library GEMMs, no torch ops.
     Raises ValueError when the networks do not fit a CU's LDS (use FusedMlpHeads then)."""
     wants_mlp_input, wants_parent_hidden = True, False
+    IN_PLACE_MIN = 16384      # from this many trees on (shipped network shape) the rows stay in the tree: see bind_engine
     # off[] order of smz_mlp_desc: (name of the input-major matrix, [names of the output heads concatenated])
     _MATS = [("dyn_in", ["dyn_in"]), ("ady_in", ["ady_in"]), ("dyn_mid", ["dyn_mid"]), ("ady_mid", ["ady_mid"]),
              ("dyn_out", ["dyn_rw", "dyn_st"]), ("ady_out", ["ady_st"]), ("pre_in", ["pre_in"]), ("apr_in", ["apr_in"]),
@@ -197,11 +198,30 @@ class HipMlpHeads:
                                             B, _stream(self.device)))
         return hidden, policy
 
+    def bind_engine(self, engine):
+        """Called by the step-wise search before its first selection.  Large batches of the shipped network shape
+        (S 31, H 64, L 0; 2 or 4 actions): the matrix-core kernel reads each leaf's parent row from the tree's
+        hidden-state storage and writes the new row into it (smz_mlp_recurrent_rows), so the tree kernels gather and
+        scatter no rows -- a quarter of their memory traffic at 10^6 trees.  Returns the row arguments of the tree calls."""
+        import os
+        lim = int(os.environ.get("SMZ_MLP_IN_PLACE_MIN", self.IN_PLACE_MIN))
+        shape_ok = self.S == 31 and self.H == 64 and self.L == 0 and self.A in (2, 4)
+        in_place = shape_ok and lim >= 0 and engine.B >= lim and hasattr(self.lib, "smz_mlp_recurrent_rows")
+        engine.enable_leaf_ids(in_place)
+        self._in_place = engine if in_place else None
+        return dict(want_mlp_input=not in_place, want_parent_hidden=False)
+
     def recurrent(self, engine):
+        B = engine.B
+        reward, policy, value = self._out("r", (B,)), self._out("p", (B, self.A)), self._out("v", (B,))
+        if getattr(self, "_in_place", None) is engine:
+            base, n, hs = engine.hidden_layout()
+            _lib.check(self.lib.smz_mlp_recurrent_rows(C.byref(self.desc), _ptr(self.weights), base, n, hs, _ptr(engine.leaf_ids),
+                                                       _ptr(engine.last_action), _ptr(engine.branch), _ptr(reward), _ptr(policy),
+                                                       _ptr(value), B, _stream(self.device)))
+            return None, reward, policy, value
         x, branch = engine.mlp_input, engine.branch
-        B = x.shape[0]
-        hidden, reward = self._out("h", (B, self.S)), self._out("r", (B,))
-        policy, value = self._out("p", (B, self.A)), self._out("v", (B,))
+        hidden = self._out("h", (B, self.S))
         _lib.check(self.lib.smz_mlp_recurrent(C.byref(self.desc), _ptr(self.weights), _ptr(x), _ptr(branch), _ptr(hidden),
                                               _ptr(reward), _ptr(policy), _ptr(value), B, _stream(self.device)))
         return hidden, reward, policy, value

@@ -128,8 +128,11 @@ class BatchedMCTS(_Hyper):
             eng.seed(self._pending_seed)
             self._pending_seed = None
         eng.root_init(hidden, policy, train=train)
-        want = dict(want_mlp_input=getattr(heads, "wants_mlp_input", True),
-                    want_parent_hidden=getattr(heads, "wants_parent_hidden", True))
+        if hasattr(heads, "bind_engine"):            # heads that may leave the rows in the tree (large batches)
+            want = heads.bind_engine(eng)
+        else:
+            want = dict(want_mlp_input=getattr(heads, "wants_mlp_input", True),
+                        want_parent_hidden=getattr(heads, "wants_parent_hidden", True))
         if self.num_simulations > 0:
             eng.select(**want)
         for s in range(self.num_simulations):

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 class _Eng:
     def __init__(self, x, branch):
-        self.mlp_input, self.branch = x, branch
+        self.mlp_input, self.branch, self.B = x, branch, x.shape[0]
 
 
 @pytest.mark.parametrize("wname,B,branches", [("weights_ckpt421", 20000, "mixed"), ("weights_lunar_L0", 16391, "mixed"),
@@ -49,3 +49,43 @@ def test_matrix_core_recurrent_heads_equal_vector_unit_heads(wname, B, branches,
     for name, a, b in zip(("hidden", "reward", "policy", "value"), outs[0], outs[1]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
     assert np.all(outs[0][1][(br == 0).cpu().numpy()] == 0.0)          # afterstate branch: reward 0
+
+
+@pytest.mark.parametrize("wname,B,sims,masked", [("weights_ckpt421", 20000, 12, False), ("weights_lunar_L0", 16500, 9, True)])
+def test_rows_left_in_the_tree_give_the_same_search(wname, B, sims, masked, monkeypatch):
+    """Step-wise search at a large batch with the network kernel taking / putting its rows in the tree's own hidden-state
+    storage (smz_set_leaf_ids_out + smz_mlp_recurrent_rows; the tree kernels move no rows) against the same search with
+    the rows copied through the mlp_input / hidden staging arrays: identical trees, hidden rows, statistics and streams.
+    With some trees switched off (smz_set_active) those must stay untouched."""
+    mcts_mod = import_module("stochastic-muzero_amd.mcts")
+    model_mod = import_module("stochastic-muzero_amd.model")
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
+    heads = model.heads("cuda:0", backend="hip")
+    obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(4)).mul(0.3).cuda()
+    active = None
+    if masked:
+        active = (torch.arange(B) % 5 != 0).to(torch.uint8).cuda()
+    res = []
+    for lim in ("0", "-1"):
+        monkeypatch.setenv("SMZ_MLP_IN_PLACE_MIN", lim)
+        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997, root_exploration_fraction=0.25,
+                                 use_graph=False, single_launch=False)
+        m.seed(np.arange(B, dtype=np.uint64) + 3)
+        e = m.run(obs, heads, train=True)
+        if masked:
+            m.set_active(active)
+            e = m.run(obs, heads, train=True)
+        assert (heads._in_place is e) == (lim == "0")
+        visits, priors, rv, cr = e.root_stats()
+        torch.cuda.synchronize()
+        out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr)]
+        dumps = [e.dump_tree(i) for i in (0, 1, 5, 6, B // 2, B - 1)]
+        states = [e.get_rng_state(i) for i in (0, 1, B - 1)]
+        res.append((out, dumps, states))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for da, db in zip(res[0][1], res[1][1]):
+        for k in da:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+    for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
+        assert np.array_equal(ka, kb) and pa == pb
