@@ -426,7 +426,10 @@ def main():
                   "argmax", int(tms.argmax()), file=sys.stderr)
         tms = tms[tms <= 3.0 * np.median(tms)]     # a host hiccup while the queue is short shows up as a 10-60 ms pair
         tree_us = float(tms.mean() * 1e3)
-        tree_bytes = (k2 + k5) * Bg
+        # rows left in the tree (large batches, heads.bind_engine): the tree kernel neither gathers the parent's hidden row
+        # (4 S bytes of K2) nor scatters the new one (4 S bytes of K5) -- the network kernel does; they are not its bytes
+        in_place = getattr(heads, "_in_place", None) is eng
+        tree_bytes = (k2 + k5 - (8 * S if in_place else 0)) * Bg
         if not single:
             ms, mean_us, bytes_launch = tms, tree_us, tree_bytes
         achieved = bytes_launch / (mean_us * 1e-6) / 1e9
@@ -444,7 +447,8 @@ def main():
                            "mean_launch_us": mean_us, "median_launch_us": float(np.median(ms) * 1e3),
                            "launches_timed": int(ms.size) * (PER_PAIR if single else 1), "bytes_per_tree_select": k2,
                            "bytes_per_tree_expand_backup": k5, "mean_depth": depth,
-                           "tree_kernel_alone": {"kernel": "k_expand_backup<MAXA,KS,true,AEX>", "mean_launch_us": tree_us,
+                           "tree_kernel_alone": {"kernel": "k_expand_backup<MAXA,KS,true,AEX>" + (" (hidden rows moved by the network kernel: 8 S bytes per tree less)" if in_place else ""),
+                                                 "mean_launch_us": tree_us,
                                                  "bytes_per_launch": tree_bytes,
                                                  "achieved": tree_bytes / (tree_us * 1e-6) / 1e9,
                                                  "frac": tree_bytes / (tree_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
