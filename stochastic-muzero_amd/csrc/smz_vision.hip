@@ -137,8 +137,9 @@ constexpr int kMaxPad = 51 * 51;                 // same, zero bordered (3 x 27 
 
 struct RepLds {
     float t[kMaxMap];      // residual stream  [C][N][N]
-    float v[kMaxMap];      // convolution output
-    float u[kMaxPad];      // zero-bordered input of the next convolution [C][N+2][N+2]
+    float u[kMaxPad];      // zero-bordered input of a convolution [C][N+2][N+2]
+    float v[kMaxPad];      // second zero-bordered buffer: a convolution writes relu(bn(.)) of its output straight into the
+                           // interior of the next convolution's input (no separate padding pass, one barrier less)
     WaveLds head;          // root prediction (wave 0)
 };
 
@@ -157,14 +158,36 @@ __device__ inline void pad_store(float *u, const float *src, int N, const float 
     }
     __syncthreads();
 }
+// zero border of a [C][N+2][N+2] buffer whose interior a convolution is about to fill
+template <int C>
+__device__ inline void zero_border(float *u, int N) {
+    const int P = N + 2;
+    for (int i = threadIdx.x; i < C * 4 * P; i += kRepThreads) {
+        const int c = i / (4 * P), r = i % (4 * P), side = r / P, k = r % P;
+        const int y = side == 0 ? 0 : (side == 1 ? P - 1 : k), x = side < 2 ? k : (side == 2 ? 0 : P - 1);
+        u[(c * P + y) * P + x] = 0.f;
+    }
+}
 
-// dst[oc][y][x] = sum w[oc][ic][ky][kx] * u[ic][y*stride + ky][x*stride + kx]  (+ res[oc][y][x] if res)
+// acc[oc] = sum w[oc][ic][ky][kx] * u[ic][y*stride + ky][x*stride + kx] for one output pixel (input channels outermost, taps
+// inside: the order of the wave-per-leaf convolutions is per tap -- the two kernels never meet on the same tensor)
 template <int CIN, int COUT>
-__device__ inline void conv_map(float *dst, const float *u, int Nin, int Nout, int stride, const float *w, const float *res) {
-    const int P = Nin + 2;
-    for (int i = threadIdx.x; i < Nout * Nout; i += kRepThreads) {
-        const int y = i / Nout, x = i % Nout;
-        float acc[COUT];
+__device__ inline void conv_pixel(const float *u, int P, int y, int x, int stride, const float *w, float (&acc)[COUT]) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    if constexpr (COUT == 3) {      // outputs 0 and 1 advance in one v_pk_fma_f32, output 2 in a v_fma_f32
+        v2f a01 = {0.f, 0.f};
+        float a2 = 0.f;
+#pragma unroll
+        for (int ic = 0; ic < CIN; ic++)
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const float val = u[(ic * P + y * stride + t / 3) * P + x * stride + t % 3];
+                const v2f wp = {w[(0 * CIN + ic) * 9 + t], w[(1 * CIN + ic) * 9 + t]}, vv = {val, val};
+                a01 = __builtin_elementwise_fma(wp, vv, a01);
+                a2 = fmaf(w[(2 * CIN + ic) * 9 + t], val, a2);
+            }
+        acc[0] = a01.x; acc[1] = a01.y; acc[2] = a2;
+    } else {
 #pragma unroll
         for (int oc = 0; oc < COUT; oc++) acc[oc] = 0.f;
 #pragma unroll
@@ -175,6 +198,16 @@ __device__ inline void conv_map(float *dst, const float *u, int Nin, int Nout, i
 #pragma unroll
                 for (int oc = 0; oc < COUT; oc++) acc[oc] = fmaf(w[(oc * CIN + ic) * 9 + t], val, acc[oc]);
             }
+    }
+}
+// dst[oc][y][x] = conv (+ res[oc][y][x] if res)
+template <int CIN, int COUT>
+__device__ inline void conv_map(float *dst, const float *u, int Nin, int Nout, int stride, const float *w, const float *res) {
+    const int P = Nin + 2;
+    for (int i = threadIdx.x; i < Nout * Nout; i += kRepThreads) {
+        const int y = i / Nout, x = i % Nout;
+        float acc[COUT];
+        conv_pixel<CIN, COUT>(u, P, y, x, stride, w, acc);
 #pragma unroll
         for (int oc = 0; oc < COUT; oc++) {
             const int j = (oc * Nout + y) * Nout + x;
@@ -183,15 +216,29 @@ __device__ inline void conv_map(float *dst, const float *u, int Nin, int Nout, i
     }
     __syncthreads();
 }
-
+// the same convolution writing relu(bn(conv)) into the interior of the zero-bordered buffer `un` (same size, stride 1)
 template <int C>
-__device__ inline void residual_map(RepLds &l, int N, const float *wa, const float *wb, const float *bn) {
-    pad_store<C>(l.u, l.t, N, bn);
-    conv_map<C, C>(l.v, l.u, N, N, 1, wa, nullptr);
-    pad_store<C>(l.u, l.v, N, bn);
-    conv_map<C, C>(l.v, l.u, N, N, 1, wb, nullptr);
-    pad_store<C>(l.u, l.v, N, bn);
-    conv_map<C, C>(l.t, l.u, N, N, 1, wa, l.t);       // each thread reads and writes only its own pixels of t
+__device__ inline void conv_bn_pad(float *un, const float *u, int N, const float *w, const float *bn) {
+    const int P = N + 2;
+    for (int i = threadIdx.x; i < N * N; i += kRepThreads) {
+        const int y = i / N, x = i % N;
+        float acc[C];
+        conv_pixel<C, C>(u, P, y, x, 1, w, acc);
+#pragma unroll
+        for (int oc = 0; oc < C; oc++) un[(oc * P + y + 1) * P + x + 1] = fmaxf(acc[oc] * bn[oc] + bn[C + oc], 0.f);
+    }
+    __syncthreads();
+}
+
+// v2 residual block on a map: t += convA(f(convB(f(convA(f(t)))))), f = relu(bn(.)) with ONE batch-norm
+// (neural_network_vision_model.py:41-79).  `fresh`: the borders of l.v are not known to be zero for this N yet.
+template <int C>
+__device__ inline void residual_map(RepLds &l, int N, const float *wa, const float *wb, const float *bn, bool fresh) {
+    if (fresh) zero_border<C>(l.v, N);
+    pad_store<C>(l.u, l.t, N, bn);                     // (its barrier also covers the border zeroing)
+    conv_bn_pad<C>(l.v, l.u, N, wa, bn);
+    conv_bn_pad<C>(l.u, l.v, N, wb, bn);               // l.u's borders are zero from pad_store
+    conv_map<C, C>(l.t, l.u, N, N, 1, wa, l.t);        // each thread reads and writes only its own pixels of t
 }
 
 // AvgPool2d(3, stride 2, padding 1), count_include_pad: sum of the zero-padded window / 9
@@ -222,7 +269,7 @@ __global__ void __launch_bounds__(kRepThreads, 4) k_vision_initial(smz_vision_de
     // stem: conv3x3 stride 2 pad 1, 3 -> 1 channels, 98 -> 49, straight from global memory
     {
         const float *w = weights + o[SMZ_VR_STEM];
-        for (int i = threadIdx.x; i < 49 * 49; i += kRepThreads) {
+        for (int i = threadIdx.x; i < 49 * 49; i += kRepThreads) {       // (two pixels per trip measured slower: 60.7 k vs 54.8 k cycles)
             const int y = i / 49, x = i % 49;
             float acc = 0.f;
 #pragma unroll
@@ -240,31 +287,29 @@ __global__ void __launch_bounds__(kRepThreads, 4) k_vision_initial(smz_vision_de
     SMZ_RSTAMP(0);
     {
         const float *wa = weights + o[SMZ_VR_NARROW_A], *wb = weights + o[SMZ_VR_NARROW_B], *bn = weights + o[SMZ_VR_NARROW_BN];
-        residual_map<1>(l, 49, wa, wb, bn);
-        residual_map<1>(l, 49, wa, wb, bn);
+        residual_map<1>(l, 49, wa, wb, bn, true);
+        residual_map<1>(l, 49, wa, wb, bn, false);
     }
     SMZ_RSTAMP(1);
     // widen: conv3x3 stride 2, 1 -> 3 channels, 49 -> 25
     pad_store<1>(l.u, l.t, 49, nullptr);
-    conv_map<1, 3>(l.v, l.u, 49, 25, 2, weights + o[SMZ_VR_WIDEN], nullptr);
-    for (int i = threadIdx.x; i < 3 * 25 * 25; i += kRepThreads) l.t[i] = l.v[i];
-    __syncthreads();
+    conv_map<1, 3>(l.t, l.u, 49, 25, 2, weights + o[SMZ_VR_WIDEN], nullptr);     // (reads l.u only: l.t can take the result)
     SMZ_RSTAMP(2);
     {
         const float *wa = weights + o[SMZ_VR_WIDE_A], *wb = weights + o[SMZ_VR_WIDE_B], *bn = weights + o[SMZ_VR_WIDE_BN];
-        residual_map<3>(l, 25, wa, wb, bn);
-        residual_map<3>(l, 25, wa, wb, bn);
+        residual_map<3>(l, 25, wa, wb, bn, true);
+        residual_map<3>(l, 25, wa, wb, bn, false);
         SMZ_RSTAMP(3);
         pool_map<3>(l, 25, 13);
         SMZ_RSTAMP(4);
-        residual_map<3>(l, 13, wa, wb, bn);
-        residual_map<3>(l, 13, wa, wb, bn);
-        residual_map<3>(l, 13, wa, wb, bn);
+        residual_map<3>(l, 13, wa, wb, bn, true);
+        residual_map<3>(l, 13, wa, wb, bn, false);
+        residual_map<3>(l, 13, wa, wb, bn, false);
         SMZ_RSTAMP(5);
         pool_map<3>(l, 13, 7);
         SMZ_RSTAMP(6);
     }
-    residual_map<3>(l, 7, weights + o[SMZ_VR_LAST_A], weights + o[SMZ_VR_LAST_B], weights + o[SMZ_VR_LAST_BN]);
+    residual_map<3>(l, 7, weights + o[SMZ_VR_LAST_A], weights + o[SMZ_VR_LAST_B], weights + o[SMZ_VR_LAST_BN], true);
     SMZ_RSTAMP(7);
     // wave 0: per-pixel scaling, hidden state out, root policy (the root value is discarded, mcts:319-321)
     if (threadIdx.x < kWave) {
