@@ -81,6 +81,14 @@ __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds)
 }
 #endif
 
+// Value of lane 0 or lane 1 (src = 0 / 1, may differ per lane): two v_readlane and a select instead of a ds_bpermute round
+// trip (~120 cycles in the middle of the tree phases' dependent chains).
+__device__ inline int pick_lane01(int v, int src) {
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 1);
+    return src ? b : a;
+}
+__device__ inline float pick_lane01(float v, int src) { return __int_as_float(pick_lane01(__float_as_int(v), src)); }
+
 // Random-word staging: for each of the wave's 64 trees, all 64 lanes cooperate on that tree's NEXT 64 words --
 // lane j owns word (idx + j) mod 624; words not yet twisted (j >= ready) are twisted in place (every lane reads
 // its three source words before any lane stores, which is exactly the sequential in-place order because the
@@ -184,8 +192,8 @@ __device__ inline void stage_issue(const Params &P, int tree, bool valid, int pa
     if (PHC && P.philox) return;                            // nothing to load: stage_finish computes the words
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const int pk = __shfl(packed, u);
-        const bool vt = u < P.tpw && __shfl((int)valid, u) != 0;          // wave-uniform
+        const int pk = __builtin_amdgcn_readlane(packed, u);              // (u is a constant after unrolling)
+        const bool vt = u < P.tpw && __builtin_amdgcn_readlane((int)valid, u) != 0;          // wave-uniform
         const int idx = pk & 0xffff, ready = pk >> 16;
         const uint32_t *mt = P.mt + (size_t)(tree0 + u) * kMtN;
         int p = idx + lane;
@@ -214,8 +222,8 @@ __device__ inline int stage_finish(const Params &P, int tree, bool valid, uint32
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const int pk = __shfl(packed, u);
-        const bool vt = u < P.tpw && __shfl((int)valid, u) != 0;
+        const int pk = __builtin_amdgcn_readlane(packed, u);
+        const bool vt = u < P.tpw && __builtin_amdgcn_readlane((int)valid, u) != 0;
         const int idx = pk & 0xffff, ready = pk >> 16;
         int p = idx + lane;
         if (p >= kMtN) p -= kMtN;
@@ -602,8 +610,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         if constexpr (LBKP) {
             if (s > 0) {
                 const int src = lane & (kFastTpw - 1);
-                const int len = __shfl(h.path_len, src);
-                const float lrw = __shfl(leaf_rw, src);
+                const int len = pick_lane01(h.path_len, src);
+                const float lrw = pick_lane01(leaf_rw, src);
                 if (lane < 8 * kFastTpw && SMZ_SLOT_VALID(src)) {
                     const bool own = lane < kFastTpw;
                     float mn = own ? h.mn : __builtin_inff(), mx = own ? h.mx : -__builtin_inff(), v_root = 0.f;
@@ -629,10 +637,10 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         constexpr bool PAIR = AEX && MAXA == 2 && KS == 2 && !INSTR;
         if constexpr (PAIR) {
             const int src = lane & 1;
-            const int pk = __shfl(valid ? rng.pack() : 0, src), us = __shfl(valid ? rng.used : 0, src);
+            const int pk = pick_lane01(valid ? rng.pack() : 0, src), us = pick_lane01(valid ? rng.used : 0, src);
 
-            const float hmn = __shfl(h.mn, src), hmx = __shfl(h.mx, src);
-            const int hrv = __shfl(h.root_visit, src);
+            const float hmn = pick_lane01(h.mn, src), hmx = pick_lane01(h.mx, src);
+            const int hrv = pick_lane01(h.root_visit, src);
             if (lane < 4 && SMZ_SLOT_VALID(src)) {
                 TreeHdr hs = h;
                 if (lane >= 2) {
