@@ -768,6 +768,13 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, Tr
 // every lane repeats; the per-level work (visit / value_sum stores, the MinMax quotient) is the same arithmetic as in
 // the one-lane loop, so the tree and the bounds come out bit-identical; min / max are order-free.  Called by lanes
 // [0, 8 TPW); returns the tree's new MinMax bounds and the value arriving at the root in the lanes j == 0.
+template <int SH>
+__device__ inline void minmax_shl(float &mn, float &mx) {      // mn = min(mn, mn of lane + SH), mx likewise (same 16-lane row)
+    const float smn = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(mn), __float_as_int(mn), 0x100 + SH, 0xf, 0xf, false));
+    const float smx = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(mx), __float_as_int(mx), 0x100 + SH, 0xf, 0xf, false));
+    mn = fminf(mn, smn);
+    mx = fmaxf(mx, smx);
+}
 template <int TPW>
 __device__ inline void backup_levels_lanes(const Params &P, int tree, int j, int len, float value, float leaf_reward,
                                            const uint4 *rec, float &mn, float &mx, float &v_root) {
@@ -802,11 +809,11 @@ __device__ inline void backup_levels_lanes(const Params &P, int tree, int j, int
     }
     v_root = v;
     // min / max over the tree's eight lanes (stride TPW inside one 16-lane row): shift-left reductions bring them to j == 0
-#pragma unroll
-    for (int sh = TPW; sh < 8 * TPW; sh <<= 1) {
-        mn = fminf(mn, __shfl_down(mn, sh));
-        mx = fmaxf(mx, __shfl_down(mx, sh));
-    }
+    // (on the DPP crossbar: row_shl by a constant inside the 16-lane row, a lane without a source keeps its own value)
+    static_assert(8 * TPW <= 16, "the tree's eight lanes must sit in one DPP row");
+    minmax_shl<TPW>(mn, mx);
+    minmax_shl<2 * TPW>(mn, mx);
+    minmax_shl<4 * TPW>(mn, mx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
