@@ -120,8 +120,28 @@ __device__ inline void rows_mfma(const float (&w)[NW][NS], const float *const (&
         for (int r = 0; r < NR; r++) acc[R0 + r] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[R0 + r][4 * c + 3], b[c & 1][r].w, acc[R0 + r], 0, 0, 0);
     }
 }
-__device__ inline v4f xadd(v4f v, int mask) {         // v + (v of lane ^ mask), the four registers
-    return v4f{v[0] + __shfl_xor(v[0], mask), v[1] + __shfl_xor(v[1], mask), v[2] + __shfl_xor(v[2], mask), v[3] + __shfl_xor(v[3], mask)};
+// value of lane ^ MASK without an LDS-crossbar round trip: rows (^16) and halves (^32) through gfx950's permlane swaps,
+// 4-lane groups (^4, ^8) through DPP row shifts selected per group with bank masks
+template <int MASK>
+__device__ inline float lane_xor(float v) {
+    const unsigned u = __float_as_uint(v);
+    const int lane = threadIdx.x & 63;
+    if constexpr (MASK == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);     // r[0] = rows (0,0,2,2), r[1] = rows (1,1,3,3)
+        return __uint_as_float((lane & 16) ? r[0] : r[1]);
+    } else if constexpr (MASK == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = halves (lo,lo), r[1] = halves (hi,hi)
+        return __uint_as_float((lane & 32) ? r[0] : r[1]);
+    } else {
+        static_assert(MASK == 4 || MASK == 8, "lane_xor");
+        // row_shr:MASK reaches the upper group of each pair, row_shl:MASK the lower one
+        const int up = __builtin_amdgcn_update_dpp((int)u, (int)u, 0x110 + MASK, 0xf, MASK == 4 ? 0xa : 0xc, false);
+        return __int_as_float(__builtin_amdgcn_update_dpp(up, (int)u, 0x100 + MASK, 0xf, MASK == 4 ? 0x5 : 0x3, false));
+    }
+}
+template <int MASK>
+__device__ inline v4f xadd(v4f v) {                   // v + (v of lane ^ MASK), the four registers
+    return v4f{v[0] + lane_xor<MASK>(v[0]), v[1] + lane_xor<MASK>(v[1]), v[2] + lane_xor<MASK>(v[2]), v[3] + lane_xor<MASK>(v[3])};
 }
 __device__ inline v4f relu4(v4f v) { return v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
 __device__ inline v4f bias4(const float *b, bool on) { return on ? v4f{b[0], b[1], b[2], b[3]} : v4f{0.f, 0.f, 0.f, 0.f}; }
@@ -149,7 +169,7 @@ __device__ inline void tower_layer64(const float (&w)[5][NS], const float *in, i
         *reinterpret_cast<v4f *>(out + (wave * kVW + lf) * kHS + 4 * blk) = y;
     }
     if (need_b) {
-        const v4f y = relu4(xadd(xadd(acc[4], 16), 32));
+        const v4f y = relu4(xadd<32>(xadd<16>(acc[4])));
         if (grp == 0) *reinterpret_cast<v4f *>(out + (4 * kVW + lf) * kHS + 16 * wave + 4 * blk) = y;
     }
 }
@@ -248,7 +268,7 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
     const int tree0 = blockIdx.x * kVW + wave;
     const int tree = tree0 + lane;
     const bool valid = lane < VT && tree < P.B && tree_active(P, tree);
-    const bool live0 = __shfl((int)valid, 0) != 0;
+    const bool live0 = __builtin_amdgcn_readlane((int)valid, 0) != 0;
     const bool active = lane < kPix;
     const int p = active ? lane : kPix - 1, pp = (p / kN + 1) * kPad + (p % kN + 1);
 
@@ -302,8 +322,8 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
         const int leaf = wave;
         if (lane == 0) br[leaf] = live0 ? (dyn ? 1 : 0) : -1;
         if (live0) {                                                     // wave-uniform: a dead leaf's rows stay zero
-            const int parent = __shfl(L.parent_id, 0), actn = __shfl(L.action, 0);
-            const int leaf_id = __shfl(L.leaf_id, 0);
+            const int parent = __builtin_amdgcn_readlane(L.parent_id, 0), actn = __builtin_amdgcn_readlane(L.action, 0);
+            const int leaf_id = __builtin_amdgcn_readlane(L.leaf_id, 0);
             const float *hrow = P.hidden + ((size_t)tree0 * P.N + parent) * P.hs;
             const float a_plane = (float)(actn + 1) / (float)d.A;        // muzero_model.py:511-522
             float x[4] = {hrow[p], hrow[kPix + p], hrow[2 * kPix + p], a_plane};
@@ -368,7 +388,7 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
                 const float *const bx[2] = {x, x + 2 * plh4};
                 v4f acc[2] = {bias4(weights + offo[5] + 4 * (blk & 7), lane < 32), v4f{0.f, 0.f, 0.f, 0.f}};
                 rows_mfma<16, 2, 0>(wo, bx, acc);
-                const v4f y = xadd(acc[0], 32) + xadd(acc[1], 32);
+                const v4f y = xadd<32>(acc[0]) + xadd<32>(acc[1]);
                 if (lane < 32) *reinterpret_cast<v4f *>(Y + (t_out * kVW + lf) * kYS + 4 * blk) = y;
             }
         } else {
@@ -377,7 +397,7 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
             const float *const bx[2] = {x, x};
             v4f acc[2] = {bias4(weights + offo[5], (lane & 12) == 0 && lane < 32), v4f{0.f, 0.f, 0.f, 0.f}};
             rows_mfma<16, 1, 0>(wo, bx, acc);
-            const v4f y = xadd(xadd(acc[0], 4), 8);
+            const v4f y = xadd<8>(xadd<4>(acc[0]));
             if ((lane & 12) == 0 && lane < 32) *reinterpret_cast<v4f *>(Y + (t * kVW + lf) * kYS) = y;
         }
         wg_barrier();
