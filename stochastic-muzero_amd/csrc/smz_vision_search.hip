@@ -303,10 +303,56 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
     for (int s = 0; s < P.sims; s++) {
         if (prof) t0 = __builtin_amdgcn_s_memtime();
         Leaf L = {0, 0, 0, 0};
+        // The tree phases use the spare lanes as k_search_mlp's specialised instantiation does: the backup runs one lane per
+        // path level (lanes 0..7, backup_levels_lanes), the descent of a two-action tree scores one child per lane (lanes 0
+        // and 2, pick_decision_pair; the helper works on a copy of the stream position and of the MinMax bounds).
+        float leaf_rw = 0.f;
         if (valid) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            if (s > 0) expand_backup_tree<MAXA, KS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
-                                                    outs[lane * slot + A], pvals + lane * P.P);
+            if (s > 0) expand_backup_tree<MAXA, KS, true>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
+                                                          outs[lane * slot + A], pvals + lane * P.P, &leaf_rw);
+        }
+        if (s > 0 && live0) {
+            const int len = __builtin_amdgcn_readlane(h.path_len, 0);
+            const float lrw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(leaf_rw), 0));
+            if (lane < 8) {
+                float mn = lane == 0 ? h.mn : __builtin_inff(), mx = lane == 0 ? h.mx : -__builtin_inff(), v_root = 0.f;
+                backup_levels_lanes<1>(P, tree0, lane, len, outs[A], lrw, pvals, mn, mx, v_root);
+                if (lane == 0) {   // the root itself (reward 0)
+                    const float nvs = h.root_value_sum + v_root;
+                    const int nvc = h.root_visit + 1;
+                    h.root_value_sum = nvs;
+                    h.root_visit = nvc;
+                    const float qv = nvs / (float)nvc;
+                    if (qv > mx) mx = qv;
+                    if (qv < mn) mn = qv;
+                    h.mn = mn;
+                    h.mx = mx;
+                }
+            }
+        }
+        if constexpr (MAXA == 2) {
+            const int pk = __builtin_amdgcn_readlane(valid ? rng.pack() : 0, 0), us = __builtin_amdgcn_readlane(valid ? rng.used : 0, 0);
+            const float hmn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.mn), 0));
+            const float hmx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.mx), 0));
+            const int hrv = __builtin_amdgcn_readlane(h.root_visit, 0);
+            if ((lane == 0 || lane == 2) && live0) {
+                TreeHdr hs = h;
+                if (lane == 2) {
+                    rng.load(P.mt + (size_t)tree0 * kMtN, pk, rng_tile, kRngStage);
+                    rng.used = us;
+                    hs.mn = hmn; hs.mx = hmx; hs.root_visit = hrv;
+                }
+                int len = 0;
+                const Leaf Lp = select_tree<MAXA, KS, false, true, true>(P, tree0, rng, hs, pbc_lds, len, n_dec, n_chance, n_children,
+                                                                        pvals, lane >> 1);
+                if (lane == 0) {
+                    L = Lp;
+                    h.path_len = len;
+                    packed = rng.pack();
+                }
+            }
+        } else if (valid) {
             int len = 0;
             L = select_tree<MAXA, KS, false, true>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
             h.path_len = len;
