@@ -212,9 +212,10 @@ class HipMlpHeads:
         return dict(want_mlp_input=not in_place, want_parent_hidden=False)
 
     def recurrent(self, engine):
-        B = engine.B
+        in_place = getattr(self, "_in_place", None) is engine
+        B = engine.B if in_place else engine.mlp_input.shape[0]
         reward, policy, value = self._out("r", (B,)), self._out("p", (B, self.A)), self._out("v", (B,))
-        if getattr(self, "_in_place", None) is engine:
+        if in_place:
             base, n, hs = engine.hidden_layout()
             _lib.check(self.lib.smz_mlp_recurrent_rows(C.byref(self.desc), _ptr(self.weights), base, n, hs, _ptr(engine.leaf_ids),
                                                        _ptr(engine.last_action), _ptr(engine.branch), _ptr(reward), _ptr(policy),
