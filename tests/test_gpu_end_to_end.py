@@ -711,3 +711,40 @@ def test_vision_single_launch_search_equals_stepwise_search(wname, B, sims):
             assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
     for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
         assert np.array_equal(ka, kb) and pa == pb
+
+
+@pytest.mark.parametrize("A,L,B,sims", [(4, 1, 130, 14), (3, 0, 64, 9)])
+def test_vision_single_launch_search_with_more_actions_equals_stepwise(A, L, B, sims):
+    """k_search_vision<4> (3 or 4 actions: plain one-lane descent, no paired scoring) and a tower without hidden layers
+    (number_of_hidden_layer 0), on freshly constructed vision models: single launch == step-wise, bit for bit."""
+    mcts_mod, model_mod, _, _ = _mods()
+    torch.manual_seed(11)
+    model = model_mod.Muzero(model_structure="vision_model", observation_space_dimensions=(98, 98, 3), action_space_dimensions=A,
+                             state_space_dimensions=31, hidden_layer_dimensions=64, number_of_hidden_layer=L, random_tag=1)
+    for mod in (model.representation_function, model.dynamics_function, model.afterstate_dynamics_function,
+                model.prediction_function, model.afterstate_prediction_function):
+        mod.eval()
+    heads = model.heads("cuda:0", backend="hip")
+    assert type(heads).__name__ == "HipVisionHeads" and heads.A == A
+    obs = torch.rand(B, 3, 98, 98, generator=torch.Generator().manual_seed(5)).cuda()
+    res = []
+    for single in (True, False):
+        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997,
+                                 root_exploration_fraction=0.25, use_graph=False, single_launch=single)
+        m.seed(np.arange(B, dtype=np.uint64) + 21)
+        e = m.run(obs, heads, train=True)
+        assert m._single is (True if single else None)
+        visits, priors, rv, cr = e.root_stats()
+        action, policy, cv, _ = e.act(0.5)
+        torch.cuda.synchronize()
+        out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr, action, policy, cv)]
+        dumps = [e.dump_tree(i) for i in (0, B // 2, B - 1)]
+        res.append((out, dumps, [e.get_rng_state(i) for i in (0, B - 1)]))
+    assert (res[0][0][0].sum(1) == sims).all()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for da, db in zip(res[0][1], res[1][1]):
+        for k in da:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+    for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
+        assert np.array_equal(ka, kb) and pa == pb
