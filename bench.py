@@ -184,9 +184,10 @@ def main():
     ap.add_argument("--rng", default="mt19937", choices=["mt19937", "philox"],
                     help="mt19937: per-tree numpy-legacy streams (parity mode, the headline); philox: counter-based "
                          "streams (throughput mode: same distributions, different numbers) -- reported as its own workload")
-    ap.add_argument("--host-env", action="store_true",
-                    help="cartpole workloads: step the envs on the HOST (envs.HostVecEnv over numpy CartPoles): the "
-                         "PCIe-inclusive rate of the boundary's host-buffer variant")
+    ap.add_argument("--host-env", nargs="?", const="python", default=None, choices=["python", "native"],
+                    help="cartpole workloads: step the envs on the HOST -- the PCIe-inclusive rate of the boundary's "
+                         "host-buffer variant: 'python' = envs.HostVecEnv over Python CartPoles (measures the Python), 'native' = "
+                         "envs.HostCartPoleVec (compiled host step, smz_host_cartpole_step)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -243,7 +244,9 @@ def main():
     groups = []
     for gi in range(G):
         glo = lo + gi * Bg
-        if wl["env"] == "cartpole" and args.host_env:
+        if wl["env"] == "cartpole" and args.host_env == "native":
+            env = envs_mod.HostCartPoleVec(Bg, dev, seed=0, first_env=glo)
+        elif wl["env"] == "cartpole" and args.host_env:
             env = envs_mod.HostVecEnv([envs_mod.HostCartPole() for _ in range(Bg)], 4, 2, dev, env_seed=0, limit=0,
                                       on_end="reset", first_env=glo)
         elif wl["env"] == "cartpole":
@@ -326,7 +329,8 @@ def main():
                          "one launch per env step (smz_search_mlp_act)") if single else
                         ("step-wise kernels" + ("" if args.no_graph else ", one HIP graph per env step")),
               "stream_groups": G, "heads": type(groups[0].heads).__name__,
-              "env": "host (envs.HostVecEnv, pinned-memory action download + observation upload per step)" if args.host_env else "device",
+              "env": ("host, compiled step (envs.HostCartPoleVec: pinned-memory action download + observation upload per step)" if args.host_env == "native"
+                      else "host, Python envs (envs.HostVecEnv, pinned-memory action download + observation upload per step)" if args.host_env else "device"),
               "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}
     if world > 1:
         config["collective_backend"] = "nccl (RCCL)" if backend == "nccl" else f"{backend} ({world} ranks share {n_dev} GPU(s))"

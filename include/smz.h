@@ -372,6 +372,13 @@ int smz_cartpole_step_ctl(double *state_dev, const int32_t *action_dev, float *o
                           smz_stream stream);
 /* Host evaluation of the reset state smz_cartpole_step_ctl gives env `env` for its game number `episode` (>= 1). */
 int smz_cartpole_reset_state(uint64_t reset_seed, int64_t env, int64_t episode, double state_out[4]);
+/* The same CartPole-v1 Euler step for environments that live on the HOST (plain C loop, no GPU call): the compiled counterpart
+ * of a gymnasium vector env behind the host-buffer variant of the boundary (envs.HostCartPoleVec: actions down and
+ * observations up through pinned memory every env step).  state_host [B,4] f64 in/out; flag 0 running | 1 terminated | 2
+ * stopped by `limit` (<= 0: none; needs step_count_host [B] i32 in/out); any output may be NULL.  gymnasium's
+ * cartpole.py (dependency of game.py:123-131). */
+int smz_host_cartpole_step(double *state_host, const int32_t *action_host, float *obs_out_host, float *reward_out_host,
+                           uint8_t *flag_out_host, int32_t *step_count_host, int32_t limit, int B);
 /* Observation-only stand-in env (LunarLander-shaped benchmark workload; Box2D / gymnasium are not part of this build):
  * obs_dev [B][obs_dim] f32 ~ N(0,1), element (env, k) of step t a pure function of (seed, first_env + env, t, k). */
 int smz_synthetic_obs(float *obs_dev, int B, int obs_dim, uint64_t seed, int64_t first_env, int64_t t, smz_stream stream);

@@ -94,6 +94,7 @@ SIGNATURES = {
     "smz_synthetic_obs": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int64, _P]),
     "smz_set_active": (C.c_int, [_P, _P]),
     "smz_set_leaf_ids_out": (C.c_int, [_P, _P]),
+    "smz_host_cartpole_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int]),
     "smz_get_hidden_layout": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "smz_mlp_recurrent_rows": (C.c_int, [C.POINTER(MlpDesc), _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_traj_floats": (C.c_int, [C.c_int, C.c_int]),

@@ -1799,6 +1799,36 @@ int smz_cartpole_reset_state(uint64_t reset_seed, int64_t env, int64_t episode, 
     return SMZ_OK;
 }
 
+int smz_host_cartpole_step(double *state_host, const int32_t *action_host, float *obs_out_host, float *reward_out_host,
+                           uint8_t *flag_out_host, int32_t *step_count_host, int32_t limit, int B) {
+    if (!state_host || !action_host || B < 1) return fail(SMZ_ERR_INVALID, "smz_host_cartpole_step: bad argument%s");
+    const double g = 9.8, mc = 1.0, mp = 0.1, tm = mc + mp, len = 0.5, pml = mp * len, fm = 10.0, tau = 0.02;
+    for (int e = 0; e < B; e++) {
+        double *st = state_host + (size_t)e * 4;
+        const double x = st[0], xd = st[1], th = st[2], thd = st[3];
+        const double force = action_host[e] == 1 ? fm : -fm;
+        const double ct = cos(th), sn = sin(th);
+        const double temp = (force + pml * thd * thd * sn) / tm;
+        const double tha = (g * sn - ct * temp) / (len * (4.0 / 3.0 - mp * ct * ct / tm));
+        const double xa = temp - pml * tha * ct / tm;
+        const double nx = x + tau * xd, nxd = xd + tau * xa, nth = th + tau * thd, nthd = thd + tau * tha;
+        st[0] = nx; st[1] = nxd; st[2] = nth; st[3] = nthd;
+        if (obs_out_host) {
+            float *o = obs_out_host + (size_t)e * 4;
+            o[0] = (float)nx; o[1] = (float)nxd; o[2] = (float)nth; o[3] = (float)nthd;
+        }
+        if (reward_out_host) reward_out_host[e] = 1.0f;
+        const bool term = fabs(nx) > 2.4 || fabs(nth) > 12.0 * 2.0 * 3.14159265358979323846 / 360.0;
+        int flag = term ? 1 : 0;
+        if (step_count_host) {
+            const int count = ++step_count_host[e];
+            if (limit > 0 && count == limit) flag = 2;
+        }
+        if (flag_out_host) flag_out_host[e] = (uint8_t)flag;
+    }
+    return SMZ_OK;
+}
+
 int smz_synthetic_obs(float *obs_dev, int B, int obs_dim, uint64_t seed, int64_t first_env, int64_t t, smz_stream stream) {
     if (!obs_dev || B < 1 || obs_dim < 1) return fail(SMZ_ERR_INVALID, "smz_synthetic_obs: bad argument%s");
     const size_t n = (size_t)B * obs_dim;

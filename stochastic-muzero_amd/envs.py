@@ -302,3 +302,54 @@ class HostVecEnv:
     def close(self):
         for e in self.envs:
             e.close()
+
+
+class HostCartPoleVec:
+    """B CartPole-v1 shaped environments stepped on the HOST by compiled code (smz_host_cartpole_step), behind the same
+    interface as the device envs: per env step the B actions come down and the B observations / rewards / flags go up
+    through pinned memory on the engine's stream, and the host waits once, for the actions.  This is the boundary's
+    host-buffer variant at its best -- what a compiled vector env costs -- where HostVecEnv over Python envs measures
+    the Python.  Fixed-length episodes as CartPoleVec(on_end="continue")."""
+    obs_dim, num_actions = 4, 2
+
+    def __init__(self, num_envs, device, seed=0, first_env=0, limit=0):
+        self.lib = _lib.load()
+        self.B, self.device = int(num_envs), torch.device(device)
+        self.seed, self.first_env, self.limit = int(seed), int(first_env), int(limit)
+        pin = dict(pin_memory=torch.cuda.is_available())
+        B = self.B
+        self._state = torch.zeros(B, 4, dtype=torch.float64, **pin)
+        self._h_obs = torch.zeros(B, 4, dtype=torch.float32, **pin)
+        self._h_reward = torch.zeros(B, dtype=torch.float32, **pin)
+        self._h_flag = torch.zeros(B, dtype=torch.uint8, **pin)
+        self._h_action = torch.zeros(B, dtype=torch.int32, **pin)
+        self._count = torch.zeros(B, dtype=torch.int32)
+        self.obs = torch.zeros(B, 4, dtype=torch.float32, device=self.device)
+        self.reward = torch.zeros(B, dtype=torch.float32, device=self.device)
+        self.terminated = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        self.transfer_seconds = 0.0
+
+    def reset(self):
+        rows = np.stack([np.random.RandomState(self.seed + self.first_env + i).uniform(-0.05, 0.05, 4) for i in range(self.B)])
+        self._state.copy_(torch.from_numpy(rows))
+        self._h_obs.copy_(self._state.to(torch.float32))
+        self._count.zero_()
+        self.obs.copy_(self._h_obs, non_blocking=True)
+        return self.obs
+
+    def step(self, action):
+        import time
+        stream = torch.cuda.current_stream(self.device)
+        self._h_action.copy_(action, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        t0 = time.perf_counter()
+        ev.synchronize()                                  # the search of this step has to finish before the env can move
+        self.transfer_seconds += time.perf_counter() - t0
+        P = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(self.lib.smz_host_cartpole_step(P(self._state), P(self._h_action), P(self._h_obs), P(self._h_reward),
+                                                   P(self._h_flag), P(self._count), self.limit, self.B))
+        self.obs.copy_(self._h_obs, non_blocking=True)
+        self.reward.copy_(self._h_reward, non_blocking=True)
+        self.terminated.copy_(self._h_flag, non_blocking=True)
+        return self.obs, self.reward, self.terminated

@@ -208,3 +208,31 @@ def test_cli_argv_and_config_surface():
     kw = muzero_cli.mcts_kwargs(config)
     _pkg("mcts").Monte_carlo_tree_search(**kw)
     assert muzero_cli.mcts_kwargs(config, 2)["num_simulations"] == 2
+
+
+def test_compiled_host_cartpole_step_equals_the_python_env():
+    """smz_host_cartpole_step (plain C on the host, no GPU) against envs.HostCartPole: same float64 Euler arithmetic,
+    observation for observation; flags 1 (terminated) and 2 (stopped by the step limit)."""
+    import ctypes as C
+    import stochastic_muzero_amd as smz
+    from importlib import import_module
+    envs = import_module("stochastic-muzero_amd.envs")
+    lib = smz._lib.load()
+    B, T, limit = 6, 60, 40
+    py = [envs.HostCartPole() for _ in range(B)]
+    state = np.stack([e.reset(seed=100 + i)[0].astype(np.float64) * 0 + e.state for i, e in enumerate(py)])
+    state = np.ascontiguousarray(state)
+    obs = np.zeros((B, 4), np.float32); rew = np.zeros(B, np.float32); flag = np.zeros(B, np.uint8); cnt = np.zeros(B, np.int32)
+    rs = np.random.RandomState(3)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    seen = set()
+    for t in range(T):
+        act = rs.randint(0, 2, B).astype(np.int32)
+        assert lib.smz_host_cartpole_step(P(state), P(act), P(obs), P(rew), P(flag), P(cnt), limit, B) == 0
+        for i, e in enumerate(py):
+            o, r, term = e.step(int(act[i]))[:3]
+            assert np.array_equal(o, obs[i]) and r == rew[i] == 1.0
+            want = 2 if t + 1 == limit else (1 if term else 0)
+            assert flag[i] == want, (t, i, flag[i], want)
+            seen.add(int(flag[i]))
+    assert seen == {0, 1, 2} and (cnt == T).all()
