@@ -93,7 +93,9 @@ class BatchedMCTS(_Hyper):
         self._graph = None
         self._graph_key = None
         self._single = None
-        self.single_launch_max_trees = 32768
+        # beyond ~30 k trees the step-wise kernels (64 trees per wavefront, networks as 16-leaf tiles on the matrix cores, rows
+        # left in the tree) overtake the single launch: measured 425 vs 446 M simulations/s at 32 768 trees, 426 vs 374 at 24 576
+        self.single_launch_max_trees = 28672
 
     def _ensure_engine(self, num_actions, hidden_size):
         if self.engine is None or (self.engine.A, self.engine.S) != (num_actions, hidden_size):
@@ -173,7 +175,7 @@ class BatchedMCTS(_Hyper):
         enqueued on the current stream (read results with engine.root_stats() / engine.act()).
         With HipMlpHeads the whole search is ONE kernel launch (smz_search_mlp) when it fits in LDS; otherwise the
         step-wise kernels run, captured in a HIP graph unless use_graph is off."""
-        # beyond ~32k trees the step-wise kernels (64 trees per wavefront, every lane busy) overtake the single launch
+        # (single_launch_max_trees: where the step-wise kernels overtake the single launch)
         if (self.single_launch and isinstance(getattr(heads, "desc", None), _lib.MlpDesc) and self._single is not False
                 and self.num_trees <= self.single_launch_max_trees):
             eng = self._ensure_engine(heads.A, heads.S)
