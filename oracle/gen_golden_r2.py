@@ -8,7 +8,11 @@ only).  TEST INFRASTRUCTURE.  oracle/gen_golden.py and its fixtures are untouche
   reanalyse421_sims10_T1.npz  the reference's own play_game on its REANALYSE branch (self_play.py:70-81, game.py:112-115,
   reanalyse421_sims10_T0.npz  254-257): a game it has just played is the stored game; per-step tapes + the resulting lists;
   game_illegal_moves.npz      the reference's Game over an env whose step() raises for some actions: the illegal-move
-                              reward rule of game.py:123-131, through the reference's own play_game.
+                              reward rule of game.py:123-131, through the reference's own play_game;
+  weights_cfg434shape.npz     a random-init mlp_model of the OTHER network shape the reference's configs ship
+  cfg434shape_sims11.npz      (config/experiment_434_config.json: state_space_dimensions 61, hidden_layer_dimensions 126,
+                              number_of_hidden_layer 0, CartPole, num_simulations 11) and the reference's searches on it --
+                              too wide for the LDS-resident kernels: the torch-GEMM heads + step-wise tree kernels serve it.
 """
 import os
 import random
@@ -162,6 +166,9 @@ def gen_illegal(ref):
 def main():
     ref = R.import_reference()
     torch.set_num_threads(1)
+    if "--only-cfg434" in sys.argv:
+        gen_cfg434(ref)
+        return
     net = G.fresh_mlp(ref, 4, 2, S=7, H=8, L=1, seed=7)
     G.export_state_dicts(net, os.path.join(OUT, "mlpnet_seed7.npz"), model_structure="mlp_model", A=2, S=7, H=8, L=1, obs=4,
                          torch_seed=7)
@@ -169,6 +176,16 @@ def main():
     gen_reanalyse(ref, mz, "reanalyse421_sims10_T1", temperature=1.0, limit=20, seed=4)
     gen_reanalyse(ref, mz, "reanalyse421_sims10_T0", temperature=0.0, limit=12, seed=6)
     gen_illegal(ref)
+    gen_cfg434(ref)
+
+
+def gen_cfg434(ref):
+    wide = G.fresh_mlp(ref, 4, 2, S=61, H=126, L=0, seed=3)
+    G.export_mlp_weights(wide, os.path.join(OUT, "weights_cfg434shape.npz"))
+    kw = dict(KW, num_simulations=11)
+    cases = [G.run_case(ref, wide, torch.tensor(np.random.RandomState(4340 + s).uniform(-0.05, 0.05, (1, 4)).astype(np.float32)), s, kw)
+             for s in range(8)]
+    G.save("cfg434shape_sims11", {k: v for k, v in kw.items() if v is not None}, cases)
 
 
 if __name__ == "__main__":

@@ -748,3 +748,41 @@ def test_vision_single_launch_search_with_more_actions_equals_stepwise(A, L, B, 
             assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
     for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
         assert np.array_equal(ka, kb) and pa == pb
+
+
+def test_config434_network_shape_runs_on_the_gemm_heads():
+    """The other network shape among the reference's configs (config/experiment_434_config.json: state_space_dimensions
+    61, hidden_layer_dimensions 126) does not fit the LDS-resident kernels: model.heads() must hand out the torch-GEMM
+    heads by itself (no silent LDS overflow), those must reproduce the reference's recorded head outputs, and a batched
+    search over the fixture's observations must reproduce the reference's visit counts on every case (goldens
+    cfg434shape_sims11 + weights_cfg434shape, written by the reference: oracle/gen_golden_r2.py)."""
+    mcts_mod, model_mod, _, _ = _mods()
+    cfg, data = gu.load("cfg434shape_sims11")
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_cfg434shape.npz"))
+    with pytest.raises(ValueError):
+        model.heads("cuda:0", backend="hip")
+    heads = model.heads("cuda:0")
+    assert type(heads).__name__ == "FusedMlpHeads" and heads.S == 61
+    ncase, sims = data["tape_branch"].shape
+    hid, pol = heads.initial(torch.from_numpy(data["obs"]).cuda())
+    torch.testing.assert_close(hid.cpu(), torch.from_numpy(data["root_hidden"]), rtol=0, atol=2e-6)
+    torch.testing.assert_close(pol.cpu(), torch.from_numpy(data["root_policy"]), rtol=0, atol=1e-6)
+    fe = _FakeEngine()
+    hin = torch.from_numpy(data["tape_hidden_in"].reshape(ncase * sims, -1))
+    onehot = torch.eye(2)[torch.from_numpy(data["tape_action"].reshape(-1)).long()]
+    fe.mlp_input = torch.cat([hin, onehot], 1).cuda().contiguous()
+    fe.branch = torch.from_numpy(data["tape_branch"].reshape(-1).astype(np.uint8)).cuda()
+    h2, rw, p2, v2 = heads.recurrent(fe)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(ncase * sims, -1)), rtol=0, atol=2e-6)
+    torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1)), rtol=0, atol=1e-6)
+    torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=3e-5, atol=2e-4)
+    # whole batched search (step-wise kernels + GEMM heads in one HIP graph) from the fixture's seeds
+    m = mcts_mod.BatchedMCTS(ncase, num_simulations=int(cfg["num_simulations"]), maxium_action_sample=2,
+                             discount=float(cfg["discount"]), root_dirichlet_alpha=float(cfg["root_dirichlet_alpha"]),
+                             root_exploration_fraction=float(cfg["root_exploration_fraction"]), use_graph=True)
+    m.seed(np.asarray(data["seed"], np.uint64))
+    e = m.run(torch.from_numpy(data["obs"]).cuda(), heads, train=True)
+    visits = e.root_stats()[0]
+    torch.cuda.synchronize()
+    assert np.array_equal(visits.cpu().numpy(), data["root_visits"])
