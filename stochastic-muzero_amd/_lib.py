@@ -80,6 +80,8 @@ SIGNATURES = {
     "smz_mlp_layout": (C.c_int, [C.POINTER(MlpDesc)]),
     "smz_mlp_initial": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, C.c_int, _P]),
     "smz_mlp_recurrent": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "smz_mlp_layout_wide": (C.c_int, [C.POINTER(MlpDesc)]),
+    "smz_mlp_recurrent_wide": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_vision_layout": (C.c_int, [C.POINTER(VisionDesc)]),
     "smz_vision_initial": (C.c_int, [C.POINTER(VisionDesc), _P, _P, _P, _P, C.c_int, _P]),
     "smz_vision_recurrent": (C.c_int, [C.POINTER(VisionDesc), _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),

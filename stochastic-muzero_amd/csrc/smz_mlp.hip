@@ -333,6 +333,199 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// Networks too wide for LDS residency (the reference's config/experiment_434_config.json: state_space_dimensions 61,
+// hidden_layer_dimensions 126; any number_of_hidden_layer 0 shape with H <= 128, 2 S <= 128, A + S <= 128): the same
+// 16-leaf tiles with the weights streamed from L2 -- A operands as 8-byte global loads of a 128-wide packed image
+// (smz_mlp_layout_wide), prefetched one input group ahead of the MFMAs that consume them; layers are 8 tiles of 16
+// neurons, dimensions are run-time values.  Outputs agree with the torch-GEMM heads / the reference's tapes within the
+// measured float tolerances (no bit-identity partner exists for these shapes).
+constexpr int kWideOP = 128, kWideTiles = 8, kWideWaves = 8;
+constexpr int kWideTileFloats = 64 * 32;              // [64 input pairs][16 leaves][2]
+
+__device__ inline void wide_layer(const float *__restrict__ W, const float *__restrict__ bias, const float *xp, int K8, int lane, v4f (&y)[kWideTiles]) {
+    const int g = lane >> 4, j = lane & 15;
+    v4f e[kWideTiles], o[kWideTiles];
+    float2 wa[2][kWideTiles];
+#pragma unroll
+    for (int t = 0; t < kWideTiles; t++) {
+        const float4 b = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * g);
+        e[t] = v4f{b.x, b.y, b.z, b.w};
+        o[t] = v4f{0.f, 0.f, 0.f, 0.f};
+        wa[0][t] = *reinterpret_cast<const float2 *>(W + ((size_t)(g >> 1) * kWideOP + 16 * t + j) * 4 + 2 * (g & 1));
+    }
+    for (int c = 0; c < K8; c += 2) {                       // two input groups per trip: static indices into wa[]
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int cc = c + h;
+            if (cc < K8) {                                  // wave-uniform
+                const float2 xb = *reinterpret_cast<const float2 *>(xp + ((4 * cc + g) * kTileLeaves + j) * 2);
+                if (cc + 1 < K8) {
+#pragma unroll
+                    for (int t = 0; t < kWideTiles; t++)
+                        wa[(h + 1) & 1][t] = *reinterpret_cast<const float2 *>(W + ((size_t)(2 * (cc + 1) + (g >> 1)) * kWideOP + 16 * t + j) * 4 + 2 * (g & 1));
+                }
+#pragma unroll
+                for (int t = 0; t < kWideTiles; t++) {
+                    e[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[h][t].x, xb.x, e[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[h][t].y, xb.y, o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kWideTiles; t++) y[t] = e[t] + o[t];
+}
+__device__ inline float wide_sum(float s) { s = s + lane_xor16(s); return s + lane_xor32(s); }
+
+__global__ void __launch_bounds__(kWideWaves *kWave) k_mlp_recurrent_wide(smz_mlp_desc d, const float *__restrict__ weights,
+                                                                          const float *__restrict__ x, const uint8_t *__restrict__ branch,
+                                                                          float *__restrict__ hidden_out, float *__restrict__ reward_out,
+                                                                          float *__restrict__ policy_out, float *__restrict__ value_out,
+                                                                          int B, int chunk) {
+    float *lds = reinterpret_cast<float *>(smz_mlp_lds4);
+    const int S = d.S, A = d.A, H = d.H, half = S / 2, XW = S + A;
+    const int K8x = (XW + 7) >> 3, K8h = (H + 7) >> 3, K8s = (S + 7) >> 3;
+    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int g = lane >> 4, j = lane & 15;
+    const int waves = blockDim.x / kWave;                 // 2 .. kWideWaves: small batches spread their tiles over more workgroups
+    float *tile = lds + wave * kWideTileFloats;
+    unsigned short *list = reinterpret_cast<unsigned short *>(lds + waves * kWideTileFloats);   // [2][kMaxChunk]
+    int *cnt = reinterpret_cast<int *>(list + 2 * kMaxChunk);
+    for (int base = blockIdx.x * chunk; base < B; base += gridDim.x * chunk) {
+        const int n = B - base < chunk ? B - base : chunk;
+        if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int w = branch[base + i] != 0 ? 0 : 1;
+            list[w * kMaxChunk + atomicAdd(&cnt[w], 1)] = (unsigned short)i;
+        }
+        __syncthreads();
+        const int n0 = cnt[0], n1 = cnt[1], t0 = (n0 + kTileLeaves - 1) / kTileLeaves, t1 = (n1 + kTileLeaves - 1) / kTileLeaves;
+        for (int tl = wave; tl < t0 + t1; tl += waves) {
+            const bool ady = tl >= t0;                                       // wave-uniform
+            const int tt = ady ? tl - t0 : tl, count = (ady ? n1 : n0) - tt * kTileLeaves;
+            const unsigned short *li = list + (ady ? kMaxChunk : 0) + tt * kTileLeaves;
+            const bool mine = j < count;
+            const int row = base + li[mine ? j : 0];
+            // network inputs [hidden | one-hot] -> tile, zero beyond them up to the layer's 8-input groups
+            for (int i = lane; i < kTileLeaves * 8 * K8x; i += kWave) {
+                const int lf = i / (8 * K8x), k = i % (8 * K8x);
+                const int rr = base + li[lf < count ? lf : 0];
+                tile[((k >> 1) * kTileLeaves + lf) * 2 + (k & 1)] = k < XW ? x[(size_t)rr * XW + k] : 0.f;
+            }
+            lds_sync();
+            // (selects between constant-index descriptor entries: a run-time index would put the table in scratch)
+            const int w_in = ady ? d.off[M_ADY_IN] : d.off[M_DYN_IN], b_in = ady ? d.off[M_COUNT + M_ADY_IN] : d.off[M_COUNT + M_DYN_IN];
+            const int w_out = ady ? d.off[M_ADY_OUT] : d.off[M_DYN_OUT], b_out = ady ? d.off[M_COUNT + M_ADY_OUT] : d.off[M_COUNT + M_DYN_OUT];
+            const int wp_in = ady ? d.off[M_APR_IN] : d.off[M_PRE_IN], bp_in = ady ? d.off[M_COUNT + M_APR_IN] : d.off[M_COUNT + M_PRE_IN];
+            const int wp_out = ady ? d.off[M_APR_OUT] : d.off[M_PRE_OUT], bp_out = ady ? d.off[M_COUNT + M_APR_OUT] : d.off[M_COUNT + M_PRE_OUT];
+            v4f y[kWideTiles];
+            auto trunk_store = [&]() {
+#pragma unroll
+                for (int t = 0; t < kWideTiles; t++) {
+                    const int nn = 16 * t + 4 * g;
+                    *reinterpret_cast<float2 *>(tile + (((nn >> 1) + 0) * kTileLeaves + j) * 2) = make_float2(elu(y[t][0]), elu(y[t][1]));
+                    *reinterpret_cast<float2 *>(tile + (((nn >> 1) + 1) * kTileLeaves + j) * 2) = make_float2(elu(y[t][2]), elu(y[t][3]));
+                }
+            };
+            wide_layer(weights + w_in, weights + b_in, tile, K8x, lane, y);
+            lds_sync();
+            trunk_store();
+            lds_sync();
+            wide_layer(weights + w_out, weights + b_out, tile, K8h, lane, y);
+            float reward = 0.f;
+            {   // dynamics: [reward logits 0..S-1 | next state S..2S-1]; afterstate dynamics: next state 0..S-1
+                const int lo = ady ? 0 : S;
+                float mr = -__builtin_inff(), mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+                for (int t = 0; t < kWideTiles; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int o = 16 * t + 4 * g + r;
+                        if (!ady && o < S) mr = fmaxf(mr, y[t][r]);
+                        if (o >= lo && o < lo + S) { mn = fminf(mn, y[t][r]); mx = fmaxf(mx, y[t][r]); }
+                    }
+                mn = tile_min(mn); mx = tile_max(mx);
+                if (!ady) {
+                    mr = tile_max(mr);
+                    float den = 0.f, num = 0.f;
+#pragma unroll
+                    for (int t = 0; t < kWideTiles; t++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int o = 16 * t + 4 * g + r;
+                            if (o < S) { const float ev = smz_exp(y[t][r] - mr); den += ev; num += (float)(o - half) * ev; }
+                        }
+                    reward = support_to_scalar(wide_sum(num), wide_sum(den));
+                }
+                float sc = mx - mn;
+                if (sc < 1e-5f) sc += 1e-5f;
+                lds_sync();
+#pragma unroll
+                for (int t = 0; t < kWideTiles; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int o = 16 * t + 4 * g + r, k = o - lo;
+                        if (k >= 0 && k < S) {
+                            const float hv = __fdividef(y[t][r] - mn, sc);
+                            tile[((k >> 1) * kTileLeaves + j) * 2 + (k & 1)] = hv;
+                            if (mine) hidden_out[(size_t)row * S + k] = hv;
+                        }
+                    }
+                for (int i = lane; i < kTileLeaves * (8 * K8s - S); i += kWave) {          // zero inputs S .. 8 K8s - 1
+                    const int lf = i / (8 * K8s - S), k = S + i % (8 * K8s - S);
+                    tile[((k >> 1) * kTileLeaves + lf) * 2 + (k & 1)] = 0.f;
+                }
+            }
+            lds_sync();
+            wide_layer(weights + wp_in, weights + bp_in, tile, K8s, lane, y);
+            lds_sync();
+            trunk_store();
+            lds_sync();
+            wide_layer(weights + wp_out, weights + bp_out, tile, K8h, lane, y);
+            {   // [policy logits 0..A-1 | value logits A..A+S-1]
+                float mp = -__builtin_inff(), mv = -__builtin_inff();
+#pragma unroll
+                for (int t = 0; t < kWideTiles; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int o = 16 * t + 4 * g + r;
+                        if (o < A) mp = fmaxf(mp, y[t][r]);
+                        else if (o < A + S) mv = fmaxf(mv, y[t][r]);
+                    }
+                mp = tile_max(mp); mv = tile_max(mv);
+                float dp = 0.f, dv = 0.f, nv = 0.f;
+#pragma unroll
+                for (int t = 0; t < kWideTiles; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int o = 16 * t + 4 * g + r;
+                        if (o < A) { y[t][r] = smz_exp(y[t][r] - mp); dp += y[t][r]; }
+                        else if (o < A + S) { const float ev = smz_exp(y[t][r] - mv); dv += ev; nv += (float)(o - A - half) * ev; }
+                    }
+                dp = wide_sum(dp);
+                const float value = support_to_scalar(wide_sum(nv), wide_sum(dv));
+                if (mine) {
+#pragma unroll
+                    for (int t = 0; t < kWideTiles; t++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int o = 16 * t + 4 * g + r;
+                            if (o < A) policy_out[(size_t)row * A + o] = __fdividef(y[t][r], dp);
+                        }
+                    if (g == 0) {
+                        value_out[row] = value;
+                        if (reward_out) reward_out[row] = reward;
+                    }
+                }
+            }
+            lds_sync();
+        }
+        __syncthreads();
+    }
+}
+
 constexpr int kLdsBytes = 160 * 1024;
 constexpr int kWavesPerWg = 8;
 
@@ -476,6 +669,45 @@ int smz_mlp_recurrent_rows(const smz_mlp_desc *d, const float *weights_dev, floa
         hipLaunchKernelGGL((k_mlp_recurrent_mfma<4, true>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
                            nullptr, branch_dev, nullptr, reward_out_dev, policy_out_dev, value_out_dev, B, chunk, tr);
     }
+    return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
+}
+
+int smz_mlp_layout_wide(smz_mlp_desc *d) {
+    if (!d || d->obs < 1 || d->A < 1 || d->S < 1 || d->H < 1 || d->L != 0) return SMZ_ERR_INVALID;
+    if (d->H > kWideOP || 2 * d->S > kWideOP || d->A + d->S > kWideOP) return SMZ_ERR_TOO_LARGE;
+    d->OP = kWideOP;
+    const int K[M_COUNT] = {d->S + d->A, d->S + d->A, 0, 0, d->H, d->H, d->S, d->S, 0, 0, d->H, d->H, d->obs, 0, d->H};
+    int off = 0;
+    // every matrix padded to a multiple of 8 input rows: the tile kernel consumes inputs in groups of eight
+    for (int m = 0; m < M_COUNT; m++) { d->off[m] = off; off += ((K[m] + 7) & ~7) * d->OP; }
+    for (int m = 0; m < M_COUNT; m++) { d->off[M_COUNT + m] = off; off += d->OP; }
+    d->total_floats = off;
+    return SMZ_OK;
+}
+
+int smz_mlp_recurrent_wide(const smz_mlp_desc *d, const float *weights_dev, const float *mlp_input_dev,
+                           const uint8_t *branch_dev, float *hidden_out_dev, float *reward_out_dev, float *policy_out_dev,
+                           float *value_out_dev, int B, smz_stream stream) {
+    if (!d || !weights_dev || !mlp_input_dev || !branch_dev || !hidden_out_dev || !policy_out_dev || !value_out_dev || B < 1)
+        return SMZ_ERR_INVALID;
+    smz_mlp_desc t = *d;
+    if (smz_mlp_layout_wide(&t) != SMZ_OK || t.total_floats != d->total_floats || d->OP != kWideOP) return SMZ_ERR_INVALID;
+    // geometry: a tile is ~9 us of matrix-pipe time whatever the batch, so small batches want their tiles on as many SIMDs as
+    // possible -- chunks of 32 rows (one or two tiles per branch) and 4 waves per workgroup up to 8 k rows, then larger
+    // chunks (fuller tiles) and 8 waves
+    int chunk, waves;
+    if (B <= 8192) { chunk = 32; waves = 4; }
+    else {
+        chunk = ((B + 255) / 256 + 127) / 128 * 128;
+        if (chunk > kMaxChunk) chunk = kMaxChunk;
+        waves = kWideWaves;
+    }
+    const size_t lds = (size_t)waves * kWideTileFloats * sizeof(float) + 2 * kMaxChunk * sizeof(unsigned short) + 16;
+    int wgs = (B + chunk - 1) / chunk;
+    if (wgs > 2048) wgs = 2048;
+    if (allow_lds(k_mlp_recurrent_wide, lds) != SMZ_OK) return SMZ_ERR_HIP;
+    hipLaunchKernelGGL(k_mlp_recurrent_wide, dim3(wgs), dim3(waves * kWave), lds, (hipStream_t)stream, *d, weights_dev,
+                       mlp_input_dev, branch_dev, hidden_out_dev, reward_out_dev, policy_out_dev, value_out_dev, B, chunk);
     return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
 }
 

@@ -228,6 +228,46 @@ class HipMlpHeads:
         return hidden, reward, policy, value
 
 
+class HipMlpTileHeads(FusedMlpHeads):
+    """`mlp_model` heads too wide for the LDS-resident kernels (number_of_hidden_layer 0, H <= 128, 2 S <= 128: the
+    reference's config 434, S 61 / H 126): the recurrent networks as ONE hand-written kernel per simulation round
+    (smz_mlp_recurrent_wide: 16-leaf tiles on the matrix cores, weights streamed from L2 in the 128-wide packed layout of
+    smz_mlp_layout_wide) instead of ten library launches; the root evaluation stays on the torch GEMMs of FusedMlpHeads
+    (once per search).  Raises ValueError outside the kernel's limits."""
+    wants_mlp_input, wants_parent_hidden = True, False
+
+    def __init__(self, weights, dims, device):
+        import numpy as np
+        super().__init__(weights, dims, device)
+        d = _lib.MlpDesc(int(dims["obs"]), self.A, self.S, self.H, self.L)
+        if not hasattr(self.lib, "smz_mlp_layout_wide") or self.lib.smz_mlp_layout_wide(C.byref(d)) != 0:
+            raise ValueError("mlp heads outside the limits of the wide tile kernel (use FusedMlpHeads)")
+        self.wide_desc = d      # (not `desc`: that name marks heads the single-launch search kernel can take)
+        buf = np.zeros(d.total_floats, np.float32)
+        OP = d.OP
+        for m, (_, parts) in enumerate(HipMlpHeads._MATS):
+            if "_mid" in parts[0]:
+                continue
+            W = np.concatenate([np.asarray(weights[p + "_w"], np.float32) for p in parts], 0)      # [O, K] (torch layout)
+            b = np.concatenate([np.asarray(weights[p + "_b"], np.float32) for p in parts], 0)
+            O, K = W.shape
+            K8 = (K + 7) & ~7
+            Wt = np.zeros((K8, OP), np.float32)
+            Wt[:K, :O] = W.T
+            buf[d.off[m]:d.off[m] + K8 * OP] = Wt.reshape(K8 // 4, 4, OP).transpose(0, 2, 1).reshape(-1)
+            buf[d.off[15 + m]:d.off[15 + m] + O] = b
+        self.packed = torch.from_numpy(buf).to(self.device)
+
+    def recurrent(self, engine):
+        x, branch = engine.mlp_input, engine.branch
+        B = x.shape[0]
+        hidden, reward = self._out("h", (B, self.S)), self._out("r", (B,))
+        policy, value = self._out("p", (B, self.A)), self._out("v", (B,))
+        _lib.check(self.lib.smz_mlp_recurrent_wide(C.byref(self.wide_desc), _ptr(self.packed), _ptr(x), _ptr(branch), _ptr(hidden),
+                                                   _ptr(reward), _ptr(policy), _ptr(value), B, _stream(self.device)))
+        return hidden, reward, policy, value
+
+
 class HipVisionHeads:
     """`vision_model` heads (the reference's ResNet-v2 family, compat_vision.py) evaluated by hand-written HIP kernels:
     smz_vision_initial (one workgroup per frame) and smz_vision_recurrent (one wavefront per leaf).  Weights are

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import compat_mlp, compat_vision
-from .heads import MLP_ARRAYS, FusedMlpHeads, HipMlpHeads, HipVisionHeads, ModuleHeads
+from .heads import MLP_ARRAYS, FusedMlpHeads, HipMlpHeads, HipMlpTileHeads, HipVisionHeads, ModuleHeads
 
 _FUNCS = ("representation", "prediction", "afterstate_prediction", "afterstate_dynamics", "dynamics", "encoder")
 _FAMILY_MODULE = {"mlp_model": "neural_network_mlp_model", "lstm_model": "neural_network_lstm_model",
@@ -269,7 +269,8 @@ class Muzero:
 
     def heads(self, device, instance=0, backend="auto"):
         """Batched evaluator on `device`.  backend: "hip" = the fused LDS-resident HIP kernel (mlp_model only, when
-        the networks fit a CU's LDS), "torch" = torch-ROCm GEMMs + HIP epilogues, "auto" = hip when possible.
+        the networks fit a CU's LDS), "torch" = torch-ROCm GEMMs + HIP epilogues, "auto" = hip when possible, else (mlp_model) the wide tile
+        kernel for the recurrent networks when the shape is within its limits, else torch.
         `instance` distinguishes evaluators that must not share output buffers (one per concurrent stream group)."""
         key = (str(device), instance, backend)
         version = self.weights_version()
@@ -289,6 +290,11 @@ class Muzero:
                 except ValueError:
                     if backend == "hip":
                         raise
+                try:        # too wide for LDS residency: tiles on the matrix cores with the weights streamed from L2
+                    self._heads[key] = HipMlpTileHeads(arrays, dims, device)
+                    return self._heads[key]
+                except ValueError:
+                    pass
             if self.model_structure == "mlp_model":
                 arrays = mlp_arrays_from_modules(self.representation_function, self.prediction_function,
                                                  self.afterstate_prediction_function, self.afterstate_dynamics_function,

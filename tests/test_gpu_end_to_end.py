@@ -761,8 +761,10 @@ def test_config434_network_shape_runs_on_the_gemm_heads():
     model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_cfg434shape.npz"))
     with pytest.raises(ValueError):
         model.heads("cuda:0", backend="hip")
-    heads = model.heads("cuda:0")
-    assert type(heads).__name__ == "FusedMlpHeads" and heads.S == 61
+    heads = model.heads("cuda:0")       # wide tile kernel for the recurrent networks, torch GEMMs for the root
+    assert type(heads).__name__ == "HipMlpTileHeads" and heads.S == 61
+    gemm = model.heads("cuda:0", backend="torch")
+    assert type(gemm).__name__ == "FusedMlpHeads"
     ncase, sims = data["tape_branch"].shape
     hid, pol = heads.initial(torch.from_numpy(data["obs"]).cuda())
     torch.testing.assert_close(hid.cpu(), torch.from_numpy(data["root_hidden"]), rtol=0, atol=2e-6)
@@ -772,11 +774,13 @@ def test_config434_network_shape_runs_on_the_gemm_heads():
     onehot = torch.eye(2)[torch.from_numpy(data["tape_action"].reshape(-1)).long()]
     fe.mlp_input = torch.cat([hin, onehot], 1).cuda().contiguous()
     fe.branch = torch.from_numpy(data["tape_branch"].reshape(-1).astype(np.uint8)).cuda()
-    h2, rw, p2, v2 = heads.recurrent(fe)
-    torch.cuda.synchronize()
-    torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(ncase * sims, -1)), rtol=0, atol=2e-6)
-    torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1)), rtol=0, atol=1e-6)
-    torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=3e-5, atol=2e-4)
+    for hd in (heads, gemm):
+        h2, rw, p2, v2 = hd.recurrent(fe)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(ncase * sims, -1)), rtol=0, atol=2e-6)
+        torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1)), rtol=0, atol=1e-6)
+        torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=3e-5, atol=2e-4)
+        torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=3e-5, atol=2e-4)
     # whole batched search (step-wise kernels + GEMM heads in one HIP graph) from the fixture's seeds
     m = mcts_mod.BatchedMCTS(ncase, num_simulations=int(cfg["num_simulations"]), maxium_action_sample=2,
                              discount=float(cfg["discount"]), root_dirichlet_alpha=float(cfg["root_dirichlet_alpha"]),
