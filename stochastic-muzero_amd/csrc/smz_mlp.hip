@@ -345,36 +345,38 @@ constexpr int kWideTileFloats = 64 * 32;              // [64 input pairs][16 lea
 
 __device__ inline void wide_layer(const float *__restrict__ W, const float *__restrict__ bias, const float *xp, int K8, int lane, v4f (&y)[kWideTiles]) {
     const int g = lane >> 4, j = lane & 15;
-    v4f e[kWideTiles], o[kWideTiles];
-    float2 wa[2][kWideTiles];
+    v4f o[kWideTiles];                                      // y = the even-input accumulators (from the bias), o = the odd ones
+    float2 wa[3][kWideTiles];                               // weights of three consecutive input groups: two in flight ahead
+    const float *Wl = W + ((size_t)(g >> 1) * kWideOP + j) * 4 + 2 * (g & 1);
+    auto wload = [&](int slot, int c) {
+#pragma unroll
+        for (int t = 0; t < kWideTiles; t++) wa[slot][t] = *reinterpret_cast<const float2 *>(Wl + ((size_t)2 * c * kWideOP + 16 * t) * 4);
+    };
 #pragma unroll
     for (int t = 0; t < kWideTiles; t++) {
         const float4 b = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * g);
-        e[t] = v4f{b.x, b.y, b.z, b.w};
+        y[t] = v4f{b.x, b.y, b.z, b.w};
         o[t] = v4f{0.f, 0.f, 0.f, 0.f};
-        wa[0][t] = *reinterpret_cast<const float2 *>(W + ((size_t)(g >> 1) * kWideOP + 16 * t + j) * 4 + 2 * (g & 1));
     }
-    for (int c = 0; c < K8; c += 2) {                       // two input groups per trip: static indices into wa[]
+    wload(0, 0);
+    if (K8 > 1) wload(1, 1);
+    for (int c = 0; c < K8; c += 3) {                       // three input groups per trip: static indices into wa[]
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < 3; h++) {
             const int cc = c + h;
             if (cc < K8) {                                  // wave-uniform
                 const float2 xb = *reinterpret_cast<const float2 *>(xp + ((4 * cc + g) * kTileLeaves + j) * 2);
-                if (cc + 1 < K8) {
-#pragma unroll
-                    for (int t = 0; t < kWideTiles; t++)
-                        wa[(h + 1) & 1][t] = *reinterpret_cast<const float2 *>(W + ((size_t)(2 * (cc + 1) + (g >> 1)) * kWideOP + 16 * t + j) * 4 + 2 * (g & 1));
-                }
+                if (cc + 2 < K8) wload((h + 2) % 3, cc + 2);
 #pragma unroll
                 for (int t = 0; t < kWideTiles; t++) {
-                    e[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[h][t].x, xb.x, e[t], 0, 0, 0);
+                    y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[h][t].x, xb.x, y[t], 0, 0, 0);
                     o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[h][t].y, xb.y, o[t], 0, 0, 0);
                 }
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < kWideTiles; t++) y[t] = e[t] + o[t];
+    for (int t = 0; t < kWideTiles; t++) y[t] = y[t] + o[t];
 }
 __device__ inline float wide_sum(float s) { s = s + lane_xor16(s); return s + lane_xor32(s); }
 
