@@ -523,12 +523,14 @@ constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
 // MSK: the handle has a per-tree on / off array (smz_set_active).  Without one the validity of a tree slot is a comparison
 // that is recomputed where needed; with one it is state that stays live through the search loop -- in the specialised
 // instantiation that costs scalar registers it does not have (35 -> 45 spilled, -3 % measured), so it exists both ways.
-template <int MAXA, int KS, int U, bool INSTR, bool AEX, bool MSK = true>
+// PHX: the specialised instantiation for SMZ_RNG_PHILOX handles (counter streams: no state words to load or store).
+template <int MAXA, int KS, int U, bool INSTR, bool AEX, bool MSK = true, bool PHX = false>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train, ActOut act) {
     Params P = Pin;
     P.tree0 = 0;
     if (AEX) { P.A = MAXA; P.tpw = kFastTpw; d.A = MAXA; d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = smz_mlp::kWave; P.S = kFastS; }
+    if (AEX) P.philox = PHX ? 1 : 0;         // (a constant in everything inlined below)
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);
     if (AEX) P.hs = (kFastS + 15) & ~15;
@@ -568,7 +570,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         smz_mlp::initial_row<U>(lds, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * P.hs,
                                 nullptr, outs + t * slot);
     }
-    constexpr bool PHC = !AEX;       // the specialised instantiation serves MT19937 handles only (see the launcher)
+    constexpr bool PHC = !AEX || PHX;   // the specialised instantiations are compiled for one word source each
     int packed = wave_stage_rng<PHC>(P, tree, valid, rng_tile);
     RngT<PHC> rng;
     rng.bind(P, tree, valid);
@@ -1630,35 +1632,36 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave) * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_TOO_LARGE, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
-#define SMZ_LAUNCH_SEARCH(UU, INSTR, AEX, MSK)                                                                         \
+#define SMZ_LAUNCH_SEARCH(UU, INSTR, AEX, MSK, PHX)                                                                    \
     SMZ_SEARCH_DISPATCH2(h->maxa, h->K, {                                                                              \
         static size_t granted_dev[64] = {}; /* per instantiation and device: the opt-in is a host-side call */           \
         size_t &granted = granted_dev[h->cfg.device & 63];                                                             \
         if (lds > granted) {                                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU, INSTR, AEX, MSK>),         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, KS, UU, INSTR, AEX, MSK, PHX>),    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)               \
                 return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                            \
             granted = lds;                                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR, AEX, MSK>), dim3(blocks), dim3(kWaves * kWave), lds,       \
+        hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR, AEX, MSK, PHX>), dim3(blocks), dim3(kWaves * kWave), lds,  \
                            (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act);                           \
     })
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
     // (the specialised instantiation is the parity-mode path: a Philox handle runs the generic one)
-    const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL && !P.philox;
+    const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL;
 #if SMZ_PART != 4
-    if ((P.stats || P.dbg) && fast && (P.dbg & 32) && h->maxa == 2 && h->K == 2) {
+    if ((P.stats || P.dbg) && fast && !P.philox && (P.dbg & 32) && h->maxa == 2 && h->K == 2) {
         // phase stamps of the specialised instantiation itself (SMZ_DEBUG_SKIP=48), for the headline geometry only
         constexpr int MA = 2, KS = 2;
         hipLaunchKernelGGL((k_search_mlp<MA, KS, 1, true, true>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream,
                            P, *desc, weights_dev, obs_dev, train, act);
     } else
 #endif
-    if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false, true); }
-    else if (fast && !P.active) { SMZ_LAUNCH_SEARCH(1, false, true, false); }
-    else if (fast) { SMZ_LAUNCH_SEARCH(1, false, true, true); }
-    else { SMZ_LAUNCH_SEARCH(1, false, false, true); }
+    if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false, true, false); }
+    else if (fast && P.philox) { SMZ_LAUNCH_SEARCH(1, false, true, true, true); }
+    else if (fast && !P.active) { SMZ_LAUNCH_SEARCH(1, false, true, false, false); }
+    else if (fast) { SMZ_LAUNCH_SEARCH(1, false, true, true, false); }
+    else { SMZ_LAUNCH_SEARCH(1, false, false, true, false); }
 #undef SMZ_LAUNCH_SEARCH
     h->root_ready = true;
     h->selected = false;
