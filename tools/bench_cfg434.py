@@ -1,3 +1,5 @@
+"""Search throughput on the reference's other shipped network shape (config 434: S 61, H 126): the wide tile heads
+(heads.HipMlpTileHeads) against the torch-GEMM heads, 4096 and 65 536 trees x 50 simulations.  GPU only."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, "."); import stochastic_muzero_amd
 from importlib import import_module
