@@ -153,23 +153,24 @@ struct RngT {
     const uint32_t *stage;  // this lane's staged (tempered) words in LDS, or nullptr
     int idx, ready, used, staged;
     PhiloxState<PHC> ph;    // (PHC) blocks consumed, key, generator switch
-    __device__ bool philox() const { if constexpr (PHC) return ph.on; else return false; }
-    __device__ uint32_t block() const { if constexpr (PHC) return ph.block; else return 0u; }
-    __device__ void wrapped() { if constexpr (PHC) ++ph.block; }
-    __device__ void load(uint32_t *state, int packed, const uint32_t *lds_row, int n_staged) {
+    __device__ __forceinline__ bool philox() const { if constexpr (PHC) return ph.on; else return false; }
+    __device__ __forceinline__ uint32_t block() const { if constexpr (PHC) return ph.block; else return 0u; }
+    __device__ __forceinline__ void wrapped() { if constexpr (PHC) ++ph.block; }
+    __device__ __forceinline__ void load(uint32_t *state, int packed, const uint32_t *lds_row, int n_staged) {
         mt = state; idx = packed & 0xffff; ready = packed >> 16; stage = lds_row; staged = n_staged; used = 0;
         if (philox()) { staged = n_staged - (idx & 3); if (staged < 0) staged = 0; }   // philox tiles start on a 4-word boundary
     }
     // per-kernel set-up, before the first load(): which generator, and (philox) this tree's key and block counter
-    __device__ void bind(const Params &P, int tree, bool valid) {
+    __device__ __forceinline__ void bind(const Params &P, int tree, bool valid) {
         if constexpr (PHC) {
             ph.on = P.philox != 0; ph.block = 0u; ph.k0 = ph.k1 = 0u;
             if (ph.on && valid) { ph.block = P.rng_block[tree]; ph.k0 = P.rng_key[2 * tree]; ph.k1 = P.rng_key[2 * tree + 1]; }
         }
     }
-    __device__ void save(const Params &P, int tree) const { if constexpr (PHC) { if (ph.on) P.rng_block[tree] = ph.block; } }
-    __device__ int pack() const { return (ready << 16) | idx; }
-    __device__ uint32_t next32() {
+    __device__ __forceinline__ void save(const Params &P, int tree) const { if constexpr (PHC) { if (ph.on) P.rng_block[tree] = ph.block; } }
+    __device__ __forceinline__ int pack() const { return (ready << 16) | idx; }
+    // (forced inline: an out-of-line call takes `this` by address and the whole generator state moves to scratch memory)
+    __device__ __forceinline__ uint32_t next32() {
         if (__builtin_expect(used < staged, 1)) {   // fast path: word was twisted and tempered by the staging pass
             const uint32_t y = stage[used++];
             --ready;
@@ -200,7 +201,7 @@ struct RngT {
     }
     // N consecutive words with ONE staged-words check and one bookkeeping update (a pUCT level needs 2 per child)
     template <int N>
-    __device__ void take(uint32_t (&out)[N]) {
+    __device__ __forceinline__ void take(uint32_t (&out)[N]) {
         if (__builtin_expect(used + N <= staged, 1)) {
 #pragma unroll
             for (int i = 0; i < N; i++) out[i] = stage[used + i];
@@ -219,7 +220,7 @@ struct RngT {
         const int32_t b = (int32_t)(w1 >> 6);
         return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
     }
-    __device__ double random_sample() {
+    __device__ __forceinline__ double random_sample() {
         uint32_t w[2];
         take<2>(w);
         return to_double(w[0], w[1]);
