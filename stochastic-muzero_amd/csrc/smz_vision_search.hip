@@ -192,14 +192,17 @@ __device__ inline void mix_to_tile(float *tile, int leaf, int p, bool active, co
 
 extern __shared__ float4 smz_vsearch_lds4[];
 
-template <int MAXA>
+// AEQ: the action count equals its bucket MAXA -- a compile-time constant then for everything inlined below (the per-action
+// arrays of the root level stay in registers instead of scratch memory)
+template <int MAXA, bool AEQ>
 __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vision_desc d, const float *__restrict__ weights,
                                                               const float *__restrict__ hidden0, const float *__restrict__ policy0,
                                                               int train, ActOut act) {
     constexpr int KS = 2, VT = 1;
     Params P = Pin;
     P.K = KS; P.tpw = VT;
-    fix_layout(P, false, true);
+    if (AEQ) P.A = MAXA;            // (not d.A: a modified copy of the descriptor, indexed at run time, would live in scratch)
+    fix_layout(P, AEQ, true);
     float *lds = reinterpret_cast<float *>(smz_vsearch_lds4);
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int A = P.A, S = d.S, K4h = up4(d.H);
@@ -524,20 +527,23 @@ int search_vision_launch(smz_handle *h, const smz_vision_desc *desc, const float
     const size_t lds = (size_t)ml.total * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_TOO_LARGE, "smz_search_vision: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kVW - 1) / kVW;
-#define SMZ_LAUNCH_VS(MA)                                                                                              \
+#define SMZ_LAUNCH_VS(MA, EQ)                                                                                          \
     {                                                                                                                  \
         static size_t granted_dev[64] = {};                                                                            \
         size_t &granted = granted_dev[h->cfg.device & 63];                                                             \
         if (lds > granted) {                                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_vision<MA>),                               \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_vision<MA, EQ>),                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)               \
                 return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                             \
             granted = lds;                                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_search_vision<MA>), dim3(blocks), dim3(kVW * kWave), lds, (hipStream_t)stream, P,        \
+        hipLaunchKernelGGL((k_search_vision<MA, EQ>), dim3(blocks), dim3(kVW * kWave), lds, (hipStream_t)stream, P,    \
                            *desc, weights_dev, hidden0_dev, policy0_dev, train, act);                                  \
     }
-    if (h->maxa == 2) SMZ_LAUNCH_VS(2) else SMZ_LAUNCH_VS(4)
+    if (h->maxa == 2 && P.A == 2) SMZ_LAUNCH_VS(2, true)
+    else if (h->maxa == 2) SMZ_LAUNCH_VS(2, false)
+    else if (P.A == 4) SMZ_LAUNCH_VS(4, true)
+    else SMZ_LAUNCH_VS(4, false)
 #undef SMZ_LAUNCH_VS
     h->root_ready = true;
     h->selected = false;
