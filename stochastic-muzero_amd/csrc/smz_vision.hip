@@ -177,7 +177,8 @@ __device__ inline void conv_pixel(const float *u, int P, int y, int x, int strid
     if constexpr (COUT == 3) {      // outputs 0 and 1 advance in one v_pk_fma_f32, output 2 in a v_fma_f32
         v2f a01 = {0.f, 0.f};
         float a2 = 0.f;
-#pragma unroll
+#pragma unroll 1            // (rolled: fully unrolled, the 27 taps of a 3-channel pixel need ~200 registers and the kernel, capped at
+                            //  128 for four workgroups per CU, spilled 88 of them to scratch memory: 153 -> 117 us)
         for (int ic = 0; ic < CIN; ic++)
 #pragma unroll
             for (int t = 0; t < 9; t++) {
@@ -257,7 +258,10 @@ __device__ inline void pool_map(RepLds &l, int Nin, int Nout) {
 }
 
 // (4 workgroups per CU: the register cap costs a few spills but hides the barrier chain better: 223 -> 204 us)
-__global__ void __launch_bounds__(kRepThreads, 4) k_vision_initial(smz_vision_desc d, const float *__restrict__ weights,
+#ifndef SMZ_REP_WGS
+#define SMZ_REP_WGS 4
+#endif
+__global__ void __launch_bounds__(kRepThreads, SMZ_REP_WGS) k_vision_initial(smz_vision_desc d, const float *__restrict__ weights,
                                                                 const float *__restrict__ frames,
                                                                 float *__restrict__ hidden_out,
                                                                 float *__restrict__ policy_out) {
