@@ -53,7 +53,7 @@ WORKLOADS = {
     # (--heads torch: the same modules through torch-ROCm, for comparison)
     "vision_resnet_1024x50": dict(weights="visionnet_L1_seed0.npz", env="image", obs=3 * 98 * 98, A=2, K=2, sims=50, envs=1024),
 }
-TRAFFIC_FILES = {"cartpole_mlp_4096x50": "r02_traffic_k_search_mlp.json"}
+TRAFFIC_FILES = {"cartpole_mlp_4096x50": "r02_traffic_k_search_mlp.json", "vision_resnet_1024x50": "r02_traffic_k_search_vision.json"}
 
 
 def algorithmic_bytes(stats, A, K, S, launches):
