@@ -13,6 +13,9 @@
 // kernel for the action buckets 2 and 4 with smz_search_mlp(_act), 4 = the search kernel for the buckets 8-32,
 // 3 = only smz_expand_backup_select, 5 = nothing but the shared helpers and the handle (included by smz_vision_search.hip)
 // -- the template instantiations behind those are most of the compile time, and the parts build in parallel.
+#ifndef SMZ_EB_WAVES
+#define SMZ_EB_WAVES 4   // waves per SIMD the step-wise tree kernels are register-allocated for
+#endif
 #ifndef SMZ_PART
 #define SMZ_PART 0
 #endif
@@ -433,7 +436,7 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
 
 #if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 template <int MAXA, int KS, bool FUSE_SELECT, bool AEX>
-__global__ void __launch_bounds__(kWave, 4) k_expand_backup(Params Pin, const float *hidden, const float *reward,
+__global__ void __launch_bounds__(kWave, SMZ_EB_WAVES) k_expand_backup(Params Pin, const float *hidden, const float *reward,
                                                          const float *policy, const float *value,
                                                          float *parent_hidden, int32_t *last_action, uint8_t *branch,
                                                          float *mlp_input) {
