@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(512) k_mlp_initial(smz_mlp_desc d, const float
 // 16-neuron tiles t): sums in the association of smz_mlp::wave_sum -- registers, lanes ^ 16, ^ 32, then tiles.
 // Bit-identical to k_mlp_recurrent (tests/test_gpu_mlp_heads.py).
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kTileLeaves = 16, kMfmaWaves = 12;
+constexpr int kTileLeaves = 16, kMfmaWaves = 12;   // (twelve: 100 KB of weights + 4 KB per wavefront + the lists = 158 of 160 KB)
 constexpr int kTileFloats = 32 * 32;                 // one activation tile per wavefront: [32 input pairs][16 leaves][2]
 
 __device__ inline float lane_xor16(float v) {
@@ -188,7 +188,8 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int g = lane >> 4, j = lane & 15;
     float *tile = lds + dl.total_floats + wave * kTileFloats;
-    unsigned short *list = reinterpret_cast<unsigned short *>(lds + dl.total_floats + kMfmaWaves * kTileFloats);   // [2][kMaxChunk]
+    constexpr int W = kMfmaWaves;
+    unsigned short *list = reinterpret_cast<unsigned short *>(lds + dl.total_floats + W * kTileFloats);   // [2][kMaxChunk]
     int *cnt = reinterpret_cast<int *>(list + 2 * kMaxChunk);
     for (int base = blockIdx.x * chunk; base < B; base += gridDim.x * chunk) {
         const int n = B - base < chunk ? B - base : chunk;
@@ -220,21 +221,66 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
                 v[u] = val;
             }
         };
+        // ROWS: a row of the hidden-state storage is 32 floats on a 128-byte line (31 values + a zero): lane -> leaves
+        // lane / 8 and lane / 8 + 8, 16-byte piece lane % 8 -- two 16-byte loads per lane instead of ten 4-byte ones
+        auto fetch_rows = [&](int t, float4 (&v)[2], int (&av)[2]) {
+            const bool ady = t >= t0;
+            const int tt = ady ? t - t0 : t, count = (ady ? n1 : n0) - tt * kTileLeaves;
+            const unsigned short *li = list + (ady ? kMaxChunk : 0) + tt * kTileLeaves;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int lf = (lane >> 3) + 8 * u;
+                const int rr = base + li[lf < count ? lf : 0];
+                v[u] = *reinterpret_cast<const float4 *>(tr.hidden + ((size_t)rr * tr.n + tr.ids[2 * (size_t)rr + 1]) * tr.hs + 4 * (lane & 7));
+                av[u] = tr.last_action[rr];
+            }
+        };
         float xin[10];
-        if (wave < t0 + t1) fetch(wave, xin);
-        for (int t = wave; t < t0 + t1; t += kMfmaWaves) {
+        float4 xrow[2];
+        int xact[2];
+        if (wave < t0 + t1) {
+            if (ROWS) fetch_rows(wave, xrow, xact);
+            else fetch(wave, xin);
+        }
+        for (int t = wave; t < t0 + t1; t += W) {
             const bool ady = t >= t0;                                        // wave-uniform
             const int tt = ady ? t - t0 : t, count = (ady ? n1 : n0) - tt * kTileLeaves;   // leaves in this tile (>= 1; may exceed 16)
             const unsigned short *li = list + (ady ? kMaxChunk : 0) + tt * kTileLeaves;
             const bool mine = j < count;
             const int row = base + li[mine ? j : 0];                         // (a ragged tile repeats its first row)
+            float *hrow = ROWS ? nullptr : hidden_out + (size_t)row * S;
+            float *hrow4[2] = {nullptr, nullptr};                            // ROWS: where the lane's two 16-byte pieces of the new rows go
+            if (ROWS) {
+                const int q = lane & 7;
 #pragma unroll
-            for (int u = 0; u < 10; u++) {
-                const int i = lane + kWave * u, lf = i / 40, k = i % 40;
-                tile[((k >> 1) * kTileLeaves + lf) * 2 + (k & 1)] = xin[u];
+                for (int u = 0; u < 2; u++) {
+                    const int lf = (lane >> 3) + 8 * u;
+                    float4 v = xrow[u];
+                    if (q == 7) v.w = xact[u] == 0 ? 1.f : 0.f;              // input S = the first action's one-hot slot
+                    *reinterpret_cast<float2 *>(tile + ((2 * q) * kTileLeaves + lf) * 2) = make_float2(v.x, v.y);
+                    *reinterpret_cast<float2 *>(tile + ((2 * q + 1) * kTileLeaves + lf) * 2) = make_float2(v.z, v.w);
+                    if (q == 7) {                                            // inputs S + 1 .. 39: the other actions, then zeros
+#pragma unroll
+                        for (int pr = 16; pr < 20; pr++) {
+                            const int a0 = 2 * pr - S, a1 = a0 + 1;
+                            *reinterpret_cast<float2 *>(tile + (pr * kTileLeaves + lf) * 2) =
+                                make_float2(a0 < A && xact[u] == a0 ? 1.f : 0.f, a1 < A && xact[u] == a1 ? 1.f : 0.f);
+                        }
+                    }
+                    if (lf < count) {
+                        const int rr = base + li[lf];
+                        hrow4[u] = tr.hidden + ((size_t)rr * tr.n + tr.ids[2 * (size_t)rr]) * tr.hs + 4 * q;
+                    }
+                }
+                if (t + W < t0 + t1) fetch_rows(t + W, xrow, xact);   // (in flight during this tile's layers)
+            } else {
+#pragma unroll
+                for (int u = 0; u < 10; u++) {
+                    const int i = lane + kWave * u, lf = i / 40, k = i % 40;
+                    tile[((k >> 1) * kTileLeaves + lf) * 2 + (k & 1)] = xin[u];
+                }
+                if (t + W < t0 + t1) fetch(t + W, xin);      // (in flight during this tile's layers)
             }
-            if (t + kMfmaWaves < t0 + t1) fetch(t + kMfmaWaves, xin);      // (in flight during this tile's layers)
-            float *hrow = ROWS ? tr.hidden + ((size_t)row * tr.n + tr.ids[2 * (size_t)row]) * tr.hs : hidden_out + (size_t)row * S;
             lds_sync();
             v4f y[4];
             const MatOff m_in = pick(dl, !ady, M_DYN_IN, M_ADY_IN), m_out = pick(dl, !ady, M_DYN_OUT, M_ADY_OUT);
@@ -285,11 +331,21 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
                         if (k >= 0 && k < 32) {
                             const float hv = k < S ? __fdividef(y[t4][r] - mn, sc) : 0.f;
                             tile[((k >> 1) * kTileLeaves + j) * 2 + (k & 1)] = hv;
-                            if (k < S && mine) hrow[k] = hv;
+                            if (!ROWS && k < S && mine) hrow[k] = hv;
                         }
                     }
             }
             lds_sync();
+            if (ROWS) {                                                      // the new rows leave through the tile: 16 bytes per lane and row
+                const int q = lane & 7;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int lf = (lane >> 3) + 8 * u;
+                    const float2 lo = *reinterpret_cast<const float2 *>(tile + ((2 * q) * kTileLeaves + lf) * 2);
+                    const float2 hi = *reinterpret_cast<const float2 *>(tile + ((2 * q + 1) * kTileLeaves + lf) * 2);
+                    if (hrow4[u]) *reinterpret_cast<float4 *>(hrow4[u]) = make_float4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
             tile_layer<4>(lds + p_in.w, lds + p_in.b, tile, lane, y);
             lds_sync();
             store_trunk(tile, y, lane);
