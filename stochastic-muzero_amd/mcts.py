@@ -93,9 +93,10 @@ class BatchedMCTS(_Hyper):
         self._graph = None
         self._graph_key = None
         self._single = None
-        # beyond ~30 k trees the step-wise kernels (64 trees per wavefront, networks as 16-leaf tiles on the matrix cores, rows
-        # left in the tree) overtake the single launch: measured 425 vs 446 M simulations/s at 32 768 trees, 426 vs 374 at 24 576
-        self.single_launch_max_trees = 28672
+        # beyond ~23 k trees the step-wise kernels (64 trees per wavefront, networks as 16-leaf tiles on the matrix cores, rows
+        # left in the tree) overtake the single launch: measured on one box (tools/crossover.sh) 437 vs 384 M simulations/s at
+        # 20 480 trees, 427 vs 449 at 24 576, 424 vs 509 at 28 672
+        self.single_launch_max_trees = 23552
 
     def _ensure_engine(self, num_actions, hidden_size):
         if self.engine is None or (self.engine.A, self.engine.S) != (num_actions, hidden_size):
