@@ -167,6 +167,15 @@ __device__ inline void store_trunk(float *hp, const v4f (&y)[4], int lane) {
 // mates) and forms single-branch tiles; one 64 x 16 activation tile per wavefront serves every layer in turn (each layer's
 // inputs are dead once its MFMAs have been issued and its outputs sit in registers).
 constexpr int kMaxChunk = 2048;
+// rows per workgroup pass: the batch spread over 256 workgroups (one per CU: the weights fill its LDS), whole tiles, at most
+// kMaxChunk -- a small batch then is ONE round of tiles on every CU instead of two on some of them
+inline int mfma_chunk(int B) {
+    int chunk = ((B + 255) / 256 + kTileLeaves - 1) / kTileLeaves * kTileLeaves;
+    if (const char *e = getenv("SMZ_MLP_CHUNK")) chunk = atoi(e);
+    if (chunk < 2 * kTileLeaves) chunk = 2 * kTileLeaves;
+    if (chunk > kMaxChunk) chunk = kMaxChunk;
+    return chunk;
+}
 // ROWS: network inputs and new hidden rows live in a search handle's hidden-state storage (smz_mlp_recurrent_rows): row of
 // node n of tree t = tree_hidden + (t * tree_n + n) * tree_hs; ids [B][2] = (leaf node, parent node) per tree, < 0: skip.
 struct TreeRows {
@@ -664,16 +673,13 @@ int smz_mlp_recurrent(const smz_mlp_desc *d, const float *weights_dev, const flo
     const size_t lds = ((size_t)d->total_floats + (size_t)kWavesPerWg * scratch_floats(*d)) * sizeof(float);
     if (d->S == kFastS && d->H == kFastH && d->L == kFastL && (d->A == 2 || d->A == 4)) {
         // large batches: 16-leaf tiles on the matrix cores (bit-identical; SMZ_MLP_MFMA_MIN = smallest batch that takes it)
-        int min_rows = 16384;
+        int min_rows = 8192;      // (measured: 242 vs 217 M simulations/s at 8192 trees, 367 vs 278 at 12 288, 132 vs 144 at 4096)
         if (const char *e = getenv("SMZ_MLP_MFMA_MIN")) min_rows = atoi(e);
         const size_t lds2 = ((size_t)(d->total_floats - rep_floats(*d)) + (size_t)kMfmaWaves * kTileFloats) * sizeof(float) +
                             2 * kMaxChunk * sizeof(unsigned short) + 16;
         if (min_rows == 0 && lds2 > (size_t)kLdsBytes) return SMZ_ERR_TOO_LARGE;     // (forced: say so instead of falling back)
         if (min_rows >= 0 && B >= min_rows && lds2 <= (size_t)kLdsBytes) {
-            // rows per workgroup pass: enough chunks for 256 workgroups, a multiple of 128, at most kMaxChunk
-            int chunk = ((B + 255) / 256 + 127) / 128 * 128;
-            if (chunk < 256) chunk = 256;
-            if (chunk > kMaxChunk) chunk = kMaxChunk;
+            int chunk = mfma_chunk(B);
             int wgs = (B + chunk - 1) / chunk;
             if (wgs > 256) wgs = 256;
             if (d->A == 2) {
@@ -712,9 +718,7 @@ int smz_mlp_recurrent_rows(const smz_mlp_desc *d, const float *weights_dev, floa
                         2 * kMaxChunk * sizeof(unsigned short) + 16;
     if (!(d->S == kFastS && d->H == kFastH && d->L == kFastL && (d->A == 2 || d->A == 4)) || lds2 > (size_t)kLdsBytes)
         return SMZ_ERR_TOO_LARGE;
-    int chunk = ((B + 255) / 256 + 127) / 128 * 128;
-    if (chunk < 256) chunk = 256;
-    if (chunk > kMaxChunk) chunk = kMaxChunk;
+    int chunk = mfma_chunk(B);
     int wgs = (B + chunk - 1) / chunk;
     if (wgs > 256) wgs = 256;
     const TreeRows tr = {hidden_dev, ids_dev, last_action_dev, nodes_per_tree, row_stride};

@@ -150,7 +150,7 @@ class HipMlpHeads:
     weights packed once into the LDS layout described in include/smz.h, no library GEMMs, no torch ops.
     Raises ValueError when the networks do not fit a CU's LDS (use FusedMlpHeads then)."""
     wants_mlp_input, wants_parent_hidden = True, False
-    IN_PLACE_MIN = 16384      # from this many trees on (shipped network shape) the rows stay in the tree: see bind_engine
+    IN_PLACE_MIN = 8192       # from this many trees on (shipped network shape) the rows stay in the tree: see bind_engine
     # off[] order of smz_mlp_desc: (name of the input-major matrix, [names of the output heads concatenated])
     _MATS = [("dyn_in", ["dyn_in"]), ("ady_in", ["ady_in"]), ("dyn_mid", ["dyn_mid"]), ("ady_mid", ["ady_mid"]),
              ("dyn_out", ["dyn_rw", "dyn_st"]), ("ady_out", ["ady_st"]), ("pre_in", ["pre_in"]), ("apr_in", ["apr_in"]),

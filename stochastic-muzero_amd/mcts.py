@@ -93,10 +93,10 @@ class BatchedMCTS(_Hyper):
         self._graph = None
         self._graph_key = None
         self._single = None
-        # beyond ~23 k trees the step-wise kernels (64 trees per wavefront, networks as 16-leaf tiles on the matrix cores, rows
-        # left in the tree) overtake the single launch: measured on one box (tools/crossover.sh) 437 vs 384 M simulations/s at
-        # 20 480 trees, 427 vs 449 at 24 576, 424 vs 509 at 28 672
-        self.single_launch_max_trees = 23552
+        # beyond ~17 k trees the step-wise kernels (64 trees per wavefront, networks as 16-leaf tiles on the matrix cores, rows
+        # left in the tree) overtake the single launch: measured on one box (tools/crossover.sh) 440 vs 424 M simulations/s at
+        # 16 384 trees, 436 vs 505 at 20 480, 427 vs 586 at 24 576
+        self.single_launch_max_trees = 17408
 
     def _ensure_engine(self, num_actions, hidden_size):
         if self.engine is None or (self.engine.A, self.engine.S) != (num_actions, hidden_size):
