@@ -1204,8 +1204,9 @@ int dev_alloc(smz_handle *h, T **out, size_t count) {
 inline dim3 tree_grid(int B) { return dim3((unsigned)((B + kWave - 1) / kWave)); }
 inline dim3 wave_grid(const Params &P) { return dim3((unsigned)((P.B + P.tpw - 1) / P.tpw)); }
 inline size_t tree_lds_bytes(const Params &P) {
+    static const size_t pad = getenv("SMZ_DEBUG_LDS_PAD") ? (size_t)atoi(getenv("SMZ_DEBUG_LDS_PAD")) : 0;   // occupancy experiments
     return ((P.sims + 2 <= kPbcLdsMax) ? (size_t)(P.sims + 2) * sizeof(double) : 0) +
-           (P.lds_stage ? (size_t)kWave * kRngStride * sizeof(uint32_t) : 0);
+           (P.lds_stage ? (size_t)kWave * kRngStride * sizeof(uint32_t) : 0) + pad;
 }
 inline dim3 row_grid(int B) { return dim3((unsigned)((B + 255) / 256)); }
 inline int group_lanes(int width) { int l = 1; while (l < width && l < kWave) l <<= 1; return l; }
