@@ -89,3 +89,38 @@ def test_rows_left_in_the_tree_give_the_same_search(wname, B, sims, masked, monk
             assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
     for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
         assert np.array_equal(ka, kb) and pa == pb
+
+
+@pytest.mark.gpu
+def test_rows_left_in_the_tree_inside_a_captured_graph():
+    """The default configuration beyond the single launch's range: step-wise kernels replayed from a HIP graph with the
+    network kernel working on the tree's own rows.  Graph replay against eager launches of the same path, two searches
+    each (the second replays the captured graph): identical statistics, trees and stream positions."""
+    mcts_mod = import_module("stochastic-muzero_amd.mcts")
+    model_mod = import_module("stochastic-muzero_amd.model")
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_ckpt421.npz"))
+    heads = model.heads("cuda:0", backend="hip")
+    B, sims = 8200, 7
+    assert B >= heads.IN_PLACE_MIN
+    obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(9)).mul(0.3).cuda()
+    res = []
+    for graph in (True, False):
+        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997, root_exploration_fraction=0.25,
+                                 use_graph=graph, single_launch=False)
+        m.seed(np.arange(B, dtype=np.uint64) + 11)
+        for rep in range(2):
+            e = m.run(obs, heads, train=True)
+        assert heads._in_place is e
+        visits, priors, rv, cr = e.root_stats()
+        torch.cuda.synchronize()
+        out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr)]
+        dumps = [e.dump_tree(i) for i in (0, 17, B - 1)]
+        states = [e.get_rng_state(i) for i in (0, B - 1)]
+        res.append((out, dumps, states))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for da, db in zip(res[0][1], res[1][1]):
+        for k in da:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+    for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
+        assert np.array_equal(ka, kb) and pa == pb
