@@ -177,8 +177,9 @@ def main():
     ap.add_argument("--heads", default="auto", choices=["auto", "hip", "torch"],
                     help="hip: fused LDS-resident HIP heads kernel; torch: torch-ROCm GEMMs + HIP epilogues")
     ap.add_argument("--stepwise", action="store_true", help="never use the single-launch search kernel")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("SMZ_STREAM_GROUPS", "1")),
-                    help="independent env groups per GPU, each on its own HIP stream")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("SMZ_STREAM_GROUPS", "0")),
+                    help="independent env groups per GPU, each on its own HIP stream (0 = 2 groups from 262 144 envs on -- "
+                         "one group's tree kernel overlaps the other's network kernel: +6..14 % measured -- else 1)")
     ap.add_argument("--min-timed-seconds", type=float, default=0.5, help="repeat the K-step block until this much is timed")
     ap.add_argument("--max-blocks", type=int, default=200)
     ap.add_argument("--rng", default="mt19937", choices=["mt19937", "philox"],
@@ -238,7 +239,7 @@ def main():
     total = B * world
     lo = rank * B
     T = max(args.steps, args.warmup, 1)
-    G = max(1, args.groups)
+    G = args.groups if args.groups > 0 else (2 if (B >= 262144 and B % 2 == 0) else 1)
     assert B % G == 0, "--groups must divide the env count"
     Bg = B // G
     groups = []

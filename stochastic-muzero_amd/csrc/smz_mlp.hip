@@ -169,6 +169,11 @@ __device__ inline void store_trunk(float *hp, const v4f (&y)[4], int lane) {
 constexpr int kMaxChunk = 2048;
 // rows per workgroup pass: the batch spread over 256 workgroups (one per CU: the weights fill its LDS), whole tiles, at most
 // kMaxChunk -- a small batch then is ONE round of tiles on every CU instead of two on some of them
+inline int mfma_launch_waves() {
+    int w = kMfmaWaves;
+    if (const char *e = getenv("SMZ_MLP_MFMA_WAVES")) w = atoi(e);
+    return w < 1 ? 1 : (w > kMfmaWaves ? kMfmaWaves : w);
+}
 inline int mfma_chunk(int B) {
     int chunk = ((B + 255) / 256 + kTileLeaves - 1) / kTileLeaves * kTileLeaves;
     if (const char *e = getenv("SMZ_MLP_CHUNK")) chunk = atoi(e);
@@ -197,7 +202,7 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int g = lane >> 4, j = lane & 15;
     float *tile = lds + dl.total_floats + wave * kTileFloats;
-    constexpr int W = kMfmaWaves;
+    const int W = (int)blockDim.x / kWave;                 // wavefronts of this launch (<= kMfmaWaves: mfma_launch_waves)
     unsigned short *list = reinterpret_cast<unsigned short *>(lds + dl.total_floats + W * kTileFloats);   // [2][kMaxChunk]
     int *cnt = reinterpret_cast<int *>(list + 2 * kMaxChunk);
     for (int base = blockIdx.x * chunk; base < B; base += gridDim.x * chunk) {
@@ -714,7 +719,8 @@ int smz_mlp_recurrent_rows(const smz_mlp_desc *d, const float *weights_dev, floa
     if (mlp_check(d, weights_dev) != SMZ_OK || !hidden_dev || !ids_dev || !last_action_dev || !branch_dev || !policy_out_dev ||
         !value_out_dev || B < 1 || nodes_per_tree < 1 || row_stride < d->S)
         return SMZ_ERR_INVALID;
-    const size_t lds2 = ((size_t)(d->total_floats - rep_floats(*d)) + (size_t)kMfmaWaves * kTileFloats) * sizeof(float) +
+    const int waves = mfma_launch_waves();
+    const size_t lds2 = ((size_t)(d->total_floats - rep_floats(*d)) + (size_t)waves * kTileFloats) * sizeof(float) +
                         2 * kMaxChunk * sizeof(unsigned short) + 16;
     if (!(d->S == kFastS && d->H == kFastH && d->L == kFastL && (d->A == 2 || d->A == 4)) || lds2 > (size_t)kLdsBytes)
         return SMZ_ERR_TOO_LARGE;
@@ -724,11 +730,11 @@ int smz_mlp_recurrent_rows(const smz_mlp_desc *d, const float *weights_dev, floa
     const TreeRows tr = {hidden_dev, ids_dev, last_action_dev, nodes_per_tree, row_stride};
     if (d->A == 2) {
         if (allow_lds(k_mlp_recurrent_mfma<2, true>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
-        hipLaunchKernelGGL((k_mlp_recurrent_mfma<2, true>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
+        hipLaunchKernelGGL((k_mlp_recurrent_mfma<2, true>), dim3(wgs), dim3(waves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
                            nullptr, branch_dev, nullptr, reward_out_dev, policy_out_dev, value_out_dev, B, chunk, tr);
     } else {
         if (allow_lds(k_mlp_recurrent_mfma<4, true>, lds2) != SMZ_OK) return SMZ_ERR_HIP;
-        hipLaunchKernelGGL((k_mlp_recurrent_mfma<4, true>), dim3(wgs), dim3(kMfmaWaves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
+        hipLaunchKernelGGL((k_mlp_recurrent_mfma<4, true>), dim3(wgs), dim3(waves * kWave), lds2, (hipStream_t)stream, *d, weights_dev,
                            nullptr, branch_dev, nullptr, reward_out_dev, policy_out_dev, value_out_dev, B, chunk, tr);
     }
     return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
