@@ -153,9 +153,11 @@ def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
 class StreamGroup:
     """One slice of a rank's environments with its own engine, head buffers, trajectory chunk and HIP stream.
 
-    At 4096 envs every kernel of a simulation round is latency/launch bound and occupies a small part of the chip,
-    so a rank splits its envs into G independent groups and runs each group's (captured) search on its own stream:
-    the groups' kernels overlap on the GPU.  Trees are independent, so results do not depend on the grouping."""
+    A rank may split its envs into G independent groups and run each group's search on its own stream: the groups'
+    kernels overlap on the GPU.  Where that pays (measured, tools/groups_probe.sh): from ~262 k envs per GPU on, where the
+    step-wise tree kernel is memory-bound and the matrix-core network kernel is not -- two groups run 6-14 % faster than one
+    (bench.py does this by itself); at 65 k envs it costs 4 %, and the single-launch search of small batches fills the
+    chip with one group.  Trees are independent, so results do not depend on the grouping."""
 
     def __init__(self, env, heads, mcts, steps, stream=None):
         self.env, self.heads, self.mcts = env, heads, mcts
