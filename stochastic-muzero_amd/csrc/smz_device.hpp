@@ -52,7 +52,8 @@ struct Params {
     uint32_t *nodes;        // [B][tree_words]
     float *hidden;          // [B][N][hs]
     TreeHdr *hdr;           // [B]
-    uint4 *path;            // [B][P]   records (block << 8 | slot, visit, value_sum, reward); block 0 = root block
+    uint4 *path;            // [P][B]   records (block << 8 | slot, visit, value_sum, reward); block 0 = root block.  Level-major:
+                            //          the 64 trees of a wavefront write / read a level as one contiguous 1 KB piece (PathCol)
     uint32_t *mt;           // [B][624]
     int32_t *rng_pos;       // [B]  (ready << 16) | idx
     const double *pbc_sqrt; // [sims+2]  sqrt(n) * pb_c(n)
@@ -597,13 +598,22 @@ __device__ inline int pick_decision_pair(const Kids<2> &k, int me, double sp, bo
     return s1 >= s0 ? 1 : 0;      // exact tie -> larger action
 }
 
+// The path records of ONE tree inside the level-major global array: record i of tree t = path[i * B + t].  (The single-launch
+// kernels keep a tree's records in LDS as a plain array and pass a pointer.)
+struct PathCol {
+    uint4 *p;
+    size_t stride;
+    __device__ __forceinline__ uint4 &operator[](int i) const { return p[(size_t)i * stride]; }
+};
+__device__ __forceinline__ PathCol path_col(const Params &P, int tree) { return PathCol{P.path + tree, (size_t)P.B}; }
+
 // LUT: the reciprocal table of div_by_count follows the pb_c table (pbc_sqrt[sims + 2 + n] = 1 / n)
 // PAIR (MAXA == 2, KS == 2, A == 2): two lanes per tree, see pick_decision_pair; `me` = 0 for the tree's lane (which
 // alone writes the path records), 1 for its helper.  Chance levels are evaluated redundantly by both lanes.
-template <int MAXA, int KS, bool STATS = true, bool LUT = false, bool PAIR = false, class RNG = Rng>
+template <int MAXA, int KS, bool STATS = true, bool LUT = false, bool PAIR = false, class RNG = Rng, class REC = uint4 *>
 __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const TreeHdr &h, const double *pbc_sqrt,
                                    int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children,
-                                   uint4 *rec, int me = 0) {
+                                   REC rec, int me = 0) {
     constexpr int NK = KS > 0 ? KS : MAXA;     // register arrays of the expansion levels
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
@@ -669,9 +679,9 @@ __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const Tr
 // ---------------------------------------------------------------------------------------------------------------
 // EXPAND_ONLY: stop after the expansion and return the leaf reward through *leaf_reward_out -- the caller runs the
 // backup with backup_levels_lanes (several lanes per tree).
-template <int MAXA, int KS, bool EXPAND_ONLY = false, class RNG = Rng>
+template <int MAXA, int KS, bool EXPAND_ONLY = false, class RNG = Rng, class REC = const uint4 *>
 __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, TreeHdr &h, const float *policy_row,
-                                         float reward, float value, const uint4 *rec, float *leaf_reward_out = nullptr) {
+                                         float reward, float value, REC rec, float *leaf_reward_out = nullptr) {
     constexpr int CH = 8;   // path records fetched per round trip
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);

@@ -381,7 +381,7 @@ __device__ inline void select_phase(const Params &P, int tree, bool valid, RNG &
     unsigned n_dec = 0, n_chance = 0, n_children = 0;
     if (valid) {
         int len = 0;
-        L = select_tree<MAXA, KS, true, false, false>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, P.path + (size_t)tree * P.P);
+        L = select_tree<MAXA, KS, true, false, false>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, path_col(P, tree));
         h.path_len = len;
         if (last_action) last_action[tree] = L.action;
         if (branch) branch[tree] = (uint8_t)L.branch;
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(kWave, SMZ_EB_WAVES) k_expand_backup(Params Pi
         rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + threadIdx.x * kRngStride, n_staged);
         h = P.hdr[tree];
         leaf = expand_backup_tree<MAXA, KS>(P, tree, rng, h, policy + (size_t)tree * P.A, reward ? reward[tree] : 0.0f,
-                                            value[tree], P.path + (size_t)tree * P.P);
+                                            value[tree], path_col(P, tree));
     }
     if (P.S > 0 && hidden) {
         const int t = valid ? tree : 0;
@@ -750,7 +750,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
             expand_backup_tree<MAXA, KS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
                                          pvals + lane * P.P);
             // leave the last path where the step-wise entry points and the debug dump expect it
-            for (int i = 0; i < h.path_len; i++) P.path[(size_t)tree * P.P + i] = pvals[lane * P.P + i];
+            for (int i = 0; i < h.path_len; i++) P.path[(size_t)i * P.B + tree] = pvals[lane * P.P + i];
             packed = rng.pack();
         }
         P.hdr[tree] = h;
@@ -1941,7 +1941,7 @@ int smz_debug_dump_tree(smz_handle *h, int tree, smz_node_view *nodes, int cap, 
     if (path_len_out) *path_len_out = plen;
     if (path_out && cap_path > 0 && plen > 0) {
         std::vector<uint4> recs((size_t)hdr.path_len);
-        HIP_TRY(hipMemcpy(recs.data(), P.path + (size_t)tree * P.P, (size_t)hdr.path_len * sizeof(uint4), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy2D(recs.data(), sizeof(uint4), P.path + tree, (size_t)P.B * sizeof(uint4), sizeof(uint4), (size_t)hdr.path_len, hipMemcpyDeviceToHost));
         path_out[0] = 0;
         for (int i = 0; i < hdr.path_len && i + 1 < cap_path; i++) {
             const int blk = (int)recs[i].x >> 8, slot = (int)recs[i].x & 0xff;

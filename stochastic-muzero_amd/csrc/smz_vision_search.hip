@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
             expand_backup_tree<MAXA, KS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
                                          pvals + lane * P.P);
-            for (int i = 0; i < h.path_len; i++) P.path[(size_t)tree * P.P + i] = pvals[lane * P.P + i];
+            for (int i = 0; i < h.path_len; i++) P.path[(size_t)i * P.B + tree] = pvals[lane * P.P + i];
             packed = rng.pack();
         }
         P.hdr[tree] = h;
