@@ -6,7 +6,7 @@ rm -f $O/sweep_hip.jsonl; bash tools/sweep_envs.sh hip > /dev/null 2>&1; cp $O/s
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/pmc_traffic_1m
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
-  rocprofv3 --pmc $c --kernel-include-regex "k_expand_backup" --output-format csv -d $O/pmc_traffic_1m -- python3 $R/bench.py --envs 1048576 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --min-timed-seconds 0.01 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-include-regex "k_expand_backup" --output-format csv -d $O/pmc_traffic_1m -- python3 $R/bench.py --envs 1048576 --groups 1 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --min-timed-seconds 0.01 > /dev/null 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
