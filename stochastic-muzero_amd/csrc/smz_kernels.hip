@@ -175,6 +175,58 @@ __device__ inline int wave_stage_rng_from(const Params &P, int tree, bool valid,
     return ((ready > kRngStage ? ready : kRngStage) << 16) | idx;
 }
 
+// Half-width staging for full wavefronts (64 trees, large batches, MT19937): 32 words per tree and launch instead of 64 -- a
+// simulation draws ~10 (the rare longer one falls back to the words in global memory, same values) -- two trees per pass, lanes
+// 0..31 | 32..63.  At a million trees the 64-word window alone was 4-5 of the ~10 cache lines a tree reads per launch.
+#ifndef SMZ_RNG_NARROW
+#define SMZ_RNG_NARROW 32
+#endif
+constexpr int kRngStageNarrow = SMZ_RNG_NARROW;      // 16 or 32
+__device__ inline int wave_stage_rng_narrow(const Params &P, int tree, bool valid, uint32_t *lds_tile) {
+    constexpr int U = 8;
+    constexpr int W = kRngStageNarrow, TP = kWave / W;      // trees per pass
+    const int lane = threadIdx.x & (kWave - 1), half = lane / W, j = lane % W;
+    const int tree0 = tree - lane;
+    const int packed = valid ? P.rng_pos[tree] : 0;
+    for (int t0 = 0; t0 < kWave; t0 += TP * U) {
+        uint32_t w[U], b[U], c[U];
+        int pos[U];
+        bool tw[U], vt[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t0 + TP * u + half;
+            const int pk = __shfl(packed, t);
+            vt[u] = __shfl((int)valid, t) != 0;
+            const int idx = pk & 0xffff, ready = pk >> 16;
+            const uint32_t *mt = P.mt + (size_t)(tree0 + t) * kMtN;
+            int p = idx + j;
+            if (p >= kMtN) p -= kMtN;
+            pos[u] = p;
+            tw[u] = vt[u] && j >= ready;
+            w[u] = b[u] = c[u] = 0u;
+            if (vt[u]) w[u] = mt[p];
+            if (tw[u]) {
+                const int p1 = (p + 1 == kMtN) ? 0 : p + 1;
+                int pm = p + kMtM;
+                if (pm >= kMtN) pm -= kMtN;
+                b[u] = mt[p1];
+                c[u] = mt[pm];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t0 + TP * u + half;
+            if (tw[u]) {
+                w[u] = mt_twist(w[u], b[u], c[u]);
+                (P.mt + (size_t)(tree0 + t) * kMtN)[pos[u]] = w[u];
+            }
+            if (vt[u]) lds_tile[t * kRngStride + j] = mt_temper(w[u]);
+        }
+    }
+    const int idx = packed & 0xffff, ready = packed >> 16;
+    return ((ready > kRngStageNarrow ? ready : kRngStageNarrow) << 16) | idx;
+}
+
 template <bool PHC = true>
 __device__ inline int wave_stage_rng(const Params &P, int tree, bool valid, uint32_t *lds_tile) {
     return wave_stage_rng_from<8, PHC>(P, tree, valid, lds_tile, valid ? P.rng_pos[tree] : 0,
@@ -413,11 +465,12 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);
     uint32_t *rng_tile = rng_tile_ptr(P);
-    const int n_staged = rng_tile ? kRngStage : 0;
+    const bool narrow = rng_tile && P.tpw == kWave && !P.philox;          // (wave-uniform) large batches: wave_stage_rng_narrow
+    const int n_staged = rng_tile ? (narrow ? kRngStageNarrow : kRngStage) : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
     const bool valid = (int)threadIdx.x < P.tpw && tree < P.B && tree_active(P, tree);
     const double *pbc_lds = stage_pbc(P);
-    const int packed = wave_stage_rng<!AEX>(P, tree, valid, rng_tile);
+    const int packed = narrow ? wave_stage_rng_narrow(P, tree, valid, rng_tile) : wave_stage_rng<!AEX>(P, tree, valid, rng_tile);
     RngT<!AEX> rng;          // (the specialised instantiations serve MT19937 handles only: see smz_select)
     rng.bind(P, tree, valid);
     TreeHdr h = {0, 0, 0.f, 0.f, 0, 0.f, 0, 0};
@@ -446,11 +499,12 @@ __global__ void __launch_bounds__(kWave, SMZ_EB_WAVES) k_expand_backup(Params Pi
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);
     uint32_t *rng_tile = rng_tile_ptr(P);
-    const int n_staged = rng_tile ? kRngStage : 0;
+    const bool narrow = rng_tile && P.tpw == kWave && !P.philox;          // (wave-uniform) large batches: wave_stage_rng_narrow
+    const int n_staged = rng_tile ? (narrow ? kRngStageNarrow : kRngStage) : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
     const bool valid = (int)threadIdx.x < P.tpw && tree < P.B && tree_active(P, tree);
     const double *pbc_lds = stage_pbc(P);
-    const int packed = wave_stage_rng<!AEX>(P, tree, valid, rng_tile);
+    const int packed = narrow ? wave_stage_rng_narrow(P, tree, valid, rng_tile) : wave_stage_rng<!AEX>(P, tree, valid, rng_tile);
     RngT<!AEX> rng;
     rng.bind(P, tree, valid);
     TreeHdr h = {0, 0, 0.f, 0.f, 0, 0.f, 0, 0};
