@@ -175,7 +175,7 @@ __device__ inline int wave_stage_rng_from(const Params &P, int tree, bool valid,
     return ((ready > kRngStage ? ready : kRngStage) << 16) | idx;
 }
 
-// Half-width staging for full wavefronts (64 trees, large batches, MT19937): 32 words per tree and launch instead of 64 -- a
+// Half-width staging for wavefronts of 16+ trees (mid-size and large batches, MT19937): 32 words per tree and launch instead of 64 -- a
 // simulation draws ~10 (the rare longer one falls back to the words in global memory, same values) -- two trees per pass, lanes
 // 0..31 | 32..63.  At a million trees the 64-word window alone was 4-5 of the ~10 cache lines a tree reads per launch.
 #ifndef SMZ_RNG_NARROW
@@ -188,7 +188,7 @@ __device__ inline int wave_stage_rng_narrow(const Params &P, int tree, bool vali
     const int lane = threadIdx.x & (kWave - 1), half = lane / W, j = lane % W;
     const int tree0 = tree - lane;
     const int packed = valid ? P.rng_pos[tree] : 0;
-    for (int t0 = 0; t0 < kWave; t0 += TP * U) {
+    for (int t0 = 0; t0 < P.tpw; t0 += TP * U) {
         uint32_t w[U], b[U], c[U];
         int pos[U];
         bool tw[U], vt[U];
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);
     uint32_t *rng_tile = rng_tile_ptr(P);
-    const bool narrow = rng_tile && P.tpw == kWave && !P.philox;          // (wave-uniform) large batches: wave_stage_rng_narrow
+    const bool narrow = rng_tile && P.tpw >= 16 && !P.philox;          // (wave-uniform) 16+ trees per wavefront: wave_stage_rng_narrow
     const int n_staged = rng_tile ? (narrow ? kRngStageNarrow : kRngStage) : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
     const bool valid = (int)threadIdx.x < P.tpw && tree < P.B && tree_active(P, tree);
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(kWave, SMZ_EB_WAVES) k_expand_backup(Params Pi
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);
     uint32_t *rng_tile = rng_tile_ptr(P);
-    const bool narrow = rng_tile && P.tpw == kWave && !P.philox;          // (wave-uniform) large batches: wave_stage_rng_narrow
+    const bool narrow = rng_tile && P.tpw >= 16 && !P.philox;          // (wave-uniform) 16+ trees per wavefront: wave_stage_rng_narrow
     const int n_staged = rng_tile ? (narrow ? kRngStageNarrow : kRngStage) : 0;
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
     const bool valid = (int)threadIdx.x < P.tpw && tree < P.B && tree_active(P, tree);

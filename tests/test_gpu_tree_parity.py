@@ -308,11 +308,13 @@ def test_zero_simulations_and_eval_mode():
 
 
 @pytest.mark.parametrize("env", [dict(SMZ_TREES_PER_WAVE="64"), dict(SMZ_TREES_PER_WAVE="64", SMZ_LDS_STAGE="1"),
-                                 dict(SMZ_TREES_PER_WAVE="1"), dict(SMZ_TREES_PER_WAVE="16", SMZ_LDS_STAGE="0")])
+                                 dict(SMZ_TREES_PER_WAVE="1"), dict(SMZ_TREES_PER_WAVE="16", SMZ_LDS_STAGE="0"),
+                                 dict(SMZ_TREES_PER_WAVE="16"), dict(SMZ_TREES_PER_WAVE="32"), dict(SMZ_TREES_PER_WAVE="8")])
 @pytest.mark.parametrize("name", ["ckpt421_sims50", "lunar_K4_sims30", "wideA11_K9_sims24", "crafted_onehot_policy"])
 def test_launch_geometries_give_identical_trees(name, env, monkeypatch):
-    """Trees per wavefront and the random-word staging mode (LDS tile vs. twist-ahead + L1) are pure scheduling
-    choices: every geometry must reproduce the reference goldens bit for bit."""
+    """Trees per wavefront and the random-word staging mode (LDS tile of 64 words per tree, of 32 from 16 trees per
+    wavefront on, or twist-ahead + L1) are pure scheduling choices: every geometry must reproduce the reference goldens bit
+    for bit."""
     import gpu_harness as gh
     for k, v in env.items():
         monkeypatch.setenv(k, v)
