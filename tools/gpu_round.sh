@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, smoke, bench, kernel-trace profile.  Usage: tools_gpu_round.sh <tag> [pytest args]
+# One GPU-box visit: parity tests, smoke, bench, kernel-trace profile.  Usage: tools/gpu_round.sh <tag> [pytest args]
 TAG=${1:-r1}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
