@@ -1,4 +1,4 @@
-# Large-batch tree kernel against occupancy: dynamic-LDS padding (SMZ_DEBUG_LDS_PAD) leaves 20 / 11 / 9 / 6 / 3 wavefronts per CU
+# Large-batch tree kernel against occupancy: dynamic-LDS padding (SMZ_DEBUG_LDS_PAD) leaves 9 / 6 / 5 / 4 / 2 wavefronts per CU (17 KB of LDS per one-wavefront workgroup + the pad)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for pad in 0 9000 12000 19000 38000; do
   export SMZ_DEBUG_LDS_PAD=$pad
