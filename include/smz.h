@@ -90,6 +90,10 @@ int smz_create(const smz_config *cfg, smz_handle **out);
 /* [sync] */
 int smz_destroy(smz_handle *h);
 int smz_abi_version(void);
+/* Optional pieces compiled into this library (bit mask).  SMZ_FEATURE_SEARCH_REG: the register-resident experimental search
+ * kernel of csrc/smz_search_reg.hip (`make REG=1`; a measured dead end kept as evidence, selected with SMZ_SEARCH_REG=1). */
+#define SMZ_FEATURE_SEARCH_REG 1
+int smz_build_features(void);
 const char *smz_last_error(void);
 /* Number of nodes each tree can hold: 1 + A + num_simulations * K. */
 int smz_node_capacity(const smz_handle *h);
@@ -306,9 +310,10 @@ int smz_search_mlp_act(smz_handle *h, const smz_mlp_desc *desc, const float *wei
 /* The same for the `vision_model` family: root expansion and noise, then num_simulations x (select, the leaf's
  * (afterstate) dynamics + (afterstate) prediction networks, expansion, backup) in ONE launch.  The root's hidden state and
  * policy come from smz_vision_initial (hidden0_dev [B,147], policy0_dev [B,A]): the representation network works on whole
- * 98x98 frames, one workgroup per frame, and stays its own launch.  A workgroup of 8 wavefronts owns 16 trees; the
- * convolutional part of a leaf is evaluated by its tree's wavefront, the five 147 -> H -> S/A towers for all 16 leaves at
- * once on the matrix cores (f32 in / f32 accumulate: bit-identical to smz_vision_recurrent).  Results are read as after
+ * 98x98 frames, one workgroup per frame, and stays its own launch.  A workgroup of 4 wavefronts owns 4 trees (kept in LDS
+ * for the whole search); the convolutional part of a leaf is evaluated by its tree's wavefront, the five 147 -> H -> S/A
+ * towers for the workgroup's 4 leaves at once on the matrix cores (v_mfma_f32_4x4x1 chains, weights in registers; f32 in /
+ * f32 accumulate: bit-identical to smz_vision_recurrent).  Results are read as after
  * the step-wise calls.  SMZ_ERR_TOO_LARGE outside the kernel's limits (maxium_action_sample == 2, A <= 4, S <= 32,
  * H <= 64, MT19937 streams, working set <= 160 KB of LDS): use the step-wise entry points then.
  * monte_carlo_tree_search.py:311-349, neural_network_vision_model.py:41-515, muzero_model.py:802-909. */
@@ -381,6 +386,27 @@ int smz_cartpole_step_ctl(double *state_dev, const int32_t *action_dev, float *o
                           uint8_t *flag_out_dev, const smz_episode_ctl *ctl, double *traj_dev, int T, int t,
                           const double *policy_dev, const double *child_visits_dev, const float *root_value_dev, int B,
                           smz_stream stream);
+/* ONE launch per env step of the built-in env (the loop body of self_play.py:79-94 for every env): smz_search_mlp_act on the
+ * observations in env->obs_dev, then -- in the tail of the same kernel, in the lane that owns the tree -- the env step and
+ * the trajectory record of smz_cartpole_step / _step_pack / _step_ctl with the action just chosen.  Same results, bit for
+ * bit, as the two launches.  obs_dev [B,4] f32 is read at the start of the launch and receives the NEXT observation;
+ * state_dev [B,4] f64 in/out; reward_dev [B] f32, flag_dev [B] u8 (may be NULL); ctl NULL = plain steps (flag =
+ * terminated), else the game bookkeeping of smz_cartpole_step_ctl -- ctl->active_dev must then be the array the handle
+ * got through smz_set_active (or both NULL); traj_dev [T][B][13] f64 or NULL, row t.  2 actions, 4 observations. */
+typedef struct {
+    double *state_dev;
+    float *obs_dev;
+    float *reward_dev;
+    uint8_t *flag_dev;
+    const smz_episode_ctl *ctl;
+    double *traj_dev;
+    int32_t T;
+    int32_t t;
+} smz_cartpole_env;
+int smz_search_mlp_act_cartpole(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, int train,
+                                double temperature, const double *pow_table_host, int32_t *action_dev, double *policy_dev,
+                                double *child_visits_dev, float *root_value_dev, const smz_cartpole_env *env,
+                                smz_stream stream);
 /* Host evaluation of the reset state smz_cartpole_step_ctl gives env `env` for its game number `episode` (>= 1). */
 int smz_cartpole_reset_state(uint64_t reset_seed, int64_t env, int64_t episode, double state_out[4]);
 /* The same CartPole-v1 Euler step for environments that live on the HOST (plain C loop, no GPU call): the compiled counterpart
@@ -416,6 +442,16 @@ int smz_traj_pack(double *traj_dev, int T, int t, int obs_dim, int A, const floa
 int smz_traj_targets(const double *traj_dev, int T, int obs_dim, int A, int B, int td_steps, const double *discount_pow_dev,
                      int ignore_termination, int32_t *length_dev, double *value_target_dev, double *abs_td_error_dev,
                      smz_stream stream);
+
+/* The same for chunks that hold SEVERAL games per env (envs that restart at once, smz_cartpole_step_ctl on_end = 2;
+ * selfplay.chunk_to_games(after_end = "new_game")): game_end_dev [T][B] i32 receives, per row, one past the last row of the
+ * game the row belongs to (the row carrying its end flag 1 / 2, or T for the unfinished game at the chunk's end; -1 for a
+ * row without a step, flag 3), and every game gets its own targets (game.py:291-337 applied per game).  new_game == 0: rows
+ * behind an env's first finished game belong to no game (smz_traj_targets' cut).  length_dev [B] (may be NULL) = end of the
+ * env's first game. */
+int smz_traj_targets_games(const double *traj_dev, int T, int obs_dim, int A, int B, int td_steps,
+                           const double *discount_pow_dev, int ignore_termination, int new_game, int32_t *length_dev,
+                           int32_t *game_end_dev, double *value_target_dev, double *abs_td_error_dev, smz_stream stream);
 
 /* ---- inspection ------------------------------------------------------------------------------------------------ */
 /* [sync] Copies one tree to the host: up to `cap` nodes into `nodes`; minmax_out[2] = {min, max} (may be NULL);

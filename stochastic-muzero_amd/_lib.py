@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("SMZ_LIB_PATH") or os.path.join(_HERE, "libsmz.so")   
 
 SMZ_OK, SMZ_ERR_INVALID, SMZ_ERR_HIP, SMZ_ERR_NOMEM, SMZ_ERR_STATE, SMZ_ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5
 RNG_MT19937_NUMPY, RNG_PHILOX = 0, 1
+FEATURE_SEARCH_REG = 1
 MAX_ACTIONS = 32
 
 
@@ -46,6 +47,12 @@ class EpisodeCtl(C.Structure):
                 ("limit", C.c_int32), ("on_end", C.c_int32), ("reset_seed", C.c_uint64), ("first_env", C.c_int64)]
 
 
+class CartPoleEnv(C.Structure):
+    """smz_cartpole_env (include/smz.h): the built-in env's buffers for smz_search_mlp_act_cartpole."""
+    _fields_ = [("state_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("reward_dev", C.c_void_p), ("flag_dev", C.c_void_p),
+                ("ctl", C.POINTER(EpisodeCtl)), ("traj_dev", C.c_void_p), ("T", C.c_int32), ("t", C.c_int32)]
+
+
 class NodeView(C.Structure):
     _fields_ = [("visit_count", C.c_int32), ("value_sum", C.c_float), ("reward", C.c_float), ("prior", C.c_float),
                 ("child_base", C.c_int32), ("action", C.c_int32)]
@@ -57,6 +64,7 @@ SIGNATURES = {
     "smz_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "smz_destroy": (C.c_int, [_P]),
     "smz_abi_version": (C.c_int, []),
+    "smz_build_features": (C.c_int, []),
     "smz_last_error": (C.c_char_p, []),
     "smz_node_capacity": (C.c_int, [_P]),
     "smz_set_pb_c_table": (C.c_int, [_P, _P, C.c_int]),
@@ -86,6 +94,8 @@ SIGNATURES = {
     "smz_vision_initial": (C.c_int, [C.POINTER(VisionDesc), _P, _P, _P, _P, C.c_int, _P]),
     "smz_vision_recurrent": (C.c_int, [C.POINTER(VisionDesc), _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_search_mlp_act": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
+    "smz_search_mlp_act_cartpole": (C.c_int, [_P, C.POINTER(MlpDesc), _P, C.c_int, C.c_double, _P, _P, _P, _P, _P,
+                                              C.POINTER(CartPoleEnv), _P]),
     "smz_search_mlp": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, _P]),
     "smz_search_vision": (C.c_int, [_P, C.POINTER(VisionDesc), _P, _P, _P, C.c_int, _P]),
     "smz_search_vision_act": (C.c_int, [_P, C.POINTER(VisionDesc), _P, _P, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
@@ -102,6 +112,7 @@ SIGNATURES = {
     "smz_traj_floats": (C.c_int, [C.c_int, C.c_int]),
     "smz_traj_pack": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_traj_targets": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
+    "smz_traj_targets_games": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "smz_debug_div_by_count": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "smz_debug_dump_tree": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int32), _P]),
     "smz_enable_stats": (C.c_int, [_P, C.c_int]),
@@ -109,6 +120,21 @@ SIGNATURES = {
 }
 
 _lib = None
+MISSING = []          # symbols an SMZ_LIB_PATH library lacks (A/B runs against older builds)
+
+
+class _Partial:
+    """An older library loaded on purpose (SMZ_LIB_PATH): using an entry point it lacks says so by name instead of failing
+    inside ctypes."""
+
+    def __init__(self, lib, missing):
+        self.__dict__["_lib"], self.__dict__["_missing"] = lib, missing
+
+    def __getattr__(self, name):
+        if name in self._missing:
+            # (an AttributeError, so that `hasattr(lib, name)` feature checks keep working)
+            raise AttributeError(f"{LIB_PATH} (SMZ_LIB_PATH) does not export {name}; it was skipped at load time")
+        return getattr(self._lib, name)
 
 
 def load():
@@ -125,11 +151,15 @@ def load():
                 fn = getattr(lib, name)   # AttributeError here = header/library mismatch
             except AttributeError:
                 if os.environ.get("SMZ_LIB_PATH"):      # an older build loaded on purpose for an A/B run (tools/ab_lib.sh)
+                    MISSING.append(name)
                     continue
-                raise
+                raise RuntimeError(f"{LIB_PATH} does not export {name}: the library is older than include/smz.h "
+                                   "(rebuild: python __graft_entry__.py build)") from None
             fn.restype, fn.argtypes = res, args
         if lib.smz_abi_version() != 1:
             raise RuntimeError("libsmz.so ABI version mismatch")
+        if MISSING:
+            lib = _Partial(lib, tuple(MISSING))
         _lib = lib
     return _lib
 

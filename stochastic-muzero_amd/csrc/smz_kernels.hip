@@ -43,6 +43,20 @@
 
 using namespace smz;
 
+// (file scope, not the anonymous namespace: it crosses the translation units this file is compiled into)
+struct EnvStep {
+    double *state;                 // [B][4] f64 in/out; nullptr: no env step in this launch
+    float *obs_out, *reward_out;
+    uint8_t *flag_out;
+    int32_t *step_count, *episode; // nullptr: no bookkeeping (plain step: flag = terminated)
+    uint8_t *active;
+    int limit, on_end;
+    uint64_t reset_seed;
+    long long first_env;
+    double *traj;                  // [T][B][13] f64 or nullptr
+    int t;
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------------
@@ -489,7 +503,7 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
 
 #if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 template <int MAXA, int KS, bool FUSE_SELECT, bool AEX>
-__global__ void __launch_bounds__(kWave, SMZ_EB_WAVES) k_expand_backup(Params Pin, const float *hidden, const float *reward,
+__global__ void __launch_bounds__(kWave, MAXA > 16 ? 1 : SMZ_EB_WAVES) k_expand_backup(Params Pin, const float *hidden, const float *reward,
                                                          const float *policy, const float *value,
                                                          float *parent_hidden, int32_t *last_action, uint8_t *branch,
                                                          float *mlp_input) {
@@ -531,6 +545,80 @@ __global__ void __launch_bounds__(kWave, SMZ_EB_WAVES) k_expand_backup(Params Pi
     }
 }
 #endif
+
+// Counter-based generator of the built-in environments (reset states of later episodes, stand-in observations):
+// splitmix64 of (seed, env, episode / step, component) -- the same value whatever the shard or launch geometry.
+__host__ __device__ inline uint64_t smz_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline double smz_unit(uint64_t seed, uint64_t env, uint64_t epoch, uint64_t comp) {   // [0, 1)
+    const uint64_t z = smz_mix64(smz_mix64(smz_mix64(seed ^ (env * 0xD1342543DE82EF95ull)) + epoch) + comp);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// One env step of the built-in CartPole-v1 shaped env + its trajectory record (k_traj_pack's layout, A = 2), with the game
+// bookkeeping of self_play.py:79 / game.py:270-271 -- the ONE body behind smz_cartpole_step, _step_pack, _step_ctl and
+// the tail of the single-launch search (smz_search_mlp_act_cartpole).  The flag written to flag_out / the record's
+// `terminated` slot is 0 running, 1 terminated (Game.done True), 2 stopped by limit_of_game_play (the game is over but
+// Game.done stays False, game.py:270-271), 3 no step taken (env switched off).  on_end: 1 = a finished env is switched off
+// (active[e] = 0: the searches skip it from now on), 2 = it starts its next episode at once (state ~ U(-0.05, 0.05)^4 from
+// the counter-based generator, episode[e] + 1).
+__device__ inline void cartpole_env_step(const EnvStep &E, int e, int B, const int32_t *action, const double *policy,
+                                         const double *child_visits, const float *root_value) {
+    constexpr int A = 2, F = 4 + 3 * A + 3;
+    double *r = E.traj ? E.traj + ((size_t)E.t * B + e) * F : nullptr;
+    if (E.active && !E.active[e]) {
+        if (E.flag_out) E.flag_out[e] = 3;
+        if (E.reward_out) E.reward_out[e] = 0.f;
+        if (r) { for (int k = 0; k < F; k++) r[k] = 0.0; r[5] = 3.0; }
+        return;
+    }
+    const double g = 9.8, mc = 1.0, mp = 0.1, tm = mc + mp, len = 0.5, pml = mp * len, fm = 10.0, tau = 0.02;
+    double *st = E.state + (size_t)e * 4;
+    const double x = st[0], xd = st[1], th = st[2], thd = st[3];
+    const int act = action[e];
+    const double force = act == 1 ? fm : -fm;
+    const double ct = cos(th), sn = sin(th);
+    const double temp = (force + pml * thd * thd * sn) / tm;
+    const double tha = (g * sn - ct * temp) / (len * (4.0 / 3.0 - mp * ct * ct / tm));
+    const double xa = temp - pml * tha * ct / tm;
+    double nx = x + tau * xd, nxd = xd + tau * xa, nth = th + tau * thd, nthd = thd + tau * tha;
+    const bool term = fabs(nx) > 2.4 || fabs(nth) > 12.0 * 2.0 * 3.14159265358979323846 / 360.0;
+    const int count = E.step_count ? E.step_count[e] + 1 : 0;
+    const int flag = (E.limit > 0 && count == E.limit) ? 2 : (term ? 1 : 0);
+    if (r) {
+        r[0] = (double)(float)nx; r[1] = (double)(float)nxd; r[2] = (double)(float)nth; r[3] = (double)(float)nthd;
+        r[4] = 1.0;
+        r[5] = (double)flag;
+        r[6] = policy[(size_t)e * A]; r[7] = policy[(size_t)e * A + 1];
+        r[8] = act == 0 ? 1.0 : 0.0; r[9] = act == 1 ? 1.0 : 0.0;
+        r[10] = (double)root_value[e];
+        r[11] = child_visits[(size_t)e * A]; r[12] = child_visits[(size_t)e * A + 1];
+    }
+    if (E.reward_out) E.reward_out[e] = 1.0f;
+    if (E.flag_out) E.flag_out[e] = (uint8_t)flag;
+    int next_count = count;
+    if (flag != 0 && E.on_end == 2) {
+        const int ep = E.episode[e] + 1;
+        E.episode[e] = ep;
+        nx = -0.05 + 0.1 * smz_unit(E.reset_seed, (uint64_t)(E.first_env + e), (uint64_t)ep, 0);
+        nxd = -0.05 + 0.1 * smz_unit(E.reset_seed, (uint64_t)(E.first_env + e), (uint64_t)ep, 1);
+        nth = -0.05 + 0.1 * smz_unit(E.reset_seed, (uint64_t)(E.first_env + e), (uint64_t)ep, 2);
+        nthd = -0.05 + 0.1 * smz_unit(E.reset_seed, (uint64_t)(E.first_env + e), (uint64_t)ep, 3);
+        next_count = 0;
+    } else if (flag != 0 && E.on_end == 1 && E.active) {
+        E.active[e] = 0;
+    }
+    if (E.step_count) E.step_count[e] = next_count;
+    st[0] = nx; st[1] = nxd; st[2] = nth; st[3] = nthd;
+    if (E.obs_out) {
+        float *o = E.obs_out + (size_t)e * 4;
+        o[0] = (float)nx; o[1] = (float)nxd; o[2] = (float)nth; o[3] = (float)nthd;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Whole search in ONE launch (mlp_model heads): Monte_carlo_tree_search.run (mcts:311-349) for every tree.
@@ -583,7 +671,7 @@ constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
 // PHX: the specialised instantiation for SMZ_RNG_PHILOX handles (counter streams: no state words to load or store).
 template <int MAXA, int KS, int U, bool INSTR, bool AEX, bool MSK = true, bool PHX = false>
 __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
-                                                    int train, ActOut act) {
+                                                    int train, ActOut act, EnvStep env) {
     Params P = Pin;
     P.tree0 = 0;
     if (AEX) { P.A = MAXA; P.tpw = kFastTpw; d.A = MAXA; d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = smz_mlp::kWave; P.S = kFastS; }
@@ -617,7 +705,11 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
     const bool valid = lane < tpw && tree < P.B && (!MSK || tree_active(P, tree));
     // a wave none of whose trees is searched (beyond B, or switched off with smz_set_active) is done: there is no
     // workgroup barrier after the weight staging above
-    if (MSK && __ballot(valid) == 0ull) return;
+    if (MSK && __ballot(valid) == 0ull) {
+        // (smz_search_mlp_act_cartpole: the switched-off envs of this wave still get their "no step" record)
+        if (env.state && lane < tpw && tree < P.B) cartpole_env_step(env, tree, P.B, act.action, act.policy, act.child_visits, act.root_value);
+        return;
+    }
 
     // ---- root: representation + prediction per row, then root expansion per lane ---------------------------------
     for (int t = 0; t < tpw; t++) {
@@ -817,6 +909,11 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         P.rng_pos[tree] = packed;
         rng.save(P, tree);
     }
+    // smz_search_mlp_act_cartpole: the env step + trajectory record of this tree's env in the same lane (it reads back
+    // the action / policy / child_visits / root value it has just written); a switched-off tree of a live wave gets its
+    // "no step" record.  The next observation goes where this launch read the current one: only this wave reads that row.
+    if (env.state && lane < tpw && tree < P.B)
+        cartpole_env_step(env, tree, P.B, act.action, act.policy, act.child_visits, act.root_value);
     if (INSTR) wave_add_stats(P.stats, n_dec, n_chance, n_desc, n_children);
 }
 #endif
@@ -964,122 +1061,16 @@ __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pr
 
 // ---- synthetic env + trajectory record ---------------------------------------------------------------------------
 #if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
-// traj != nullptr: also appends the step's record (the layout of k_traj_pack, A = 2) -- one launch less per env step
-__global__ void __launch_bounds__(256) k_cartpole_step(double *state, const int32_t *action, float *obs_out,
-                                                       float *reward_out, uint8_t *term_out, int B, double *traj, int t,
-                                                       const double *policy, const double *child_visits,
-                                                       const float *root_value) {
+// one thread per env; traj != nullptr: also appends the step's record -- one launch less per env step
+__global__ void __launch_bounds__(256) k_cartpole_step_env(EnvStep E, const int32_t *action, int B, const double *policy,
+                                                           const double *child_visits, const float *root_value) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B) return;
-    const double g = 9.8, mc = 1.0, mp = 0.1, tm = mc + mp, len = 0.5, pml = mp * len, fm = 10.0, tau = 0.02;
-    double *st = state + (size_t)e * 4;
-    const double x = st[0], xd = st[1], th = st[2], thd = st[3];
-    const double force = action[e] == 1 ? fm : -fm;
-    const double ct = cos(th), sn = sin(th);
-    const double temp = (force + pml * thd * thd * sn) / tm;
-    const double tha = (g * sn - ct * temp) / (len * (4.0 / 3.0 - mp * ct * ct / tm));
-    const double xa = temp - pml * tha * ct / tm;
-    const double nx = x + tau * xd, nxd = xd + tau * xa, nth = th + tau * thd, nthd = thd + tau * tha;
-    st[0] = nx; st[1] = nxd; st[2] = nth; st[3] = nthd;
-    if (obs_out) {
-        float *o = obs_out + (size_t)e * 4;
-        o[0] = (float)nx; o[1] = (float)nxd; o[2] = (float)nth; o[3] = (float)nthd;
-    }
-    if (reward_out) reward_out[e] = 1.0f;
-    const bool term = fabs(nx) > 2.4 || fabs(nth) > 12.0 * 2.0 * 3.14159265358979323846 / 360.0;
-    if (term_out) term_out[e] = term ? 1 : 0;
-    if (traj) {
-        constexpr int A = 2, F = 4 + 3 * A + 3;
-        double *r = traj + ((size_t)t * B + e) * F;
-        r[0] = (double)(float)nx; r[1] = (double)(float)nxd; r[2] = (double)(float)nth; r[3] = (double)(float)nthd;
-        r[4] = 1.0;
-        r[5] = term ? 1.0 : 0.0;
-        r[6] = policy[(size_t)e * A]; r[7] = policy[(size_t)e * A + 1];
-        r[8] = action[e] == 0 ? 1.0 : 0.0; r[9] = action[e] == 1 ? 1.0 : 0.0;
-        r[10] = (double)root_value[e];
-        r[11] = child_visits[(size_t)e * A]; r[12] = child_visits[(size_t)e * A + 1];
-    }
+    cartpole_env_step(E, e, B, action, policy, child_visits, root_value);
 }
 #endif
 
-// Counter-based generator of the built-in environments (reset states of later episodes, stand-in observations):
-// splitmix64 of (seed, env, episode / step, component) -- the same value whatever the shard or launch geometry.
-__host__ __device__ inline uint64_t smz_mix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__host__ __device__ inline double smz_unit(uint64_t seed, uint64_t env, uint64_t epoch, uint64_t comp) {   // [0, 1)
-    const uint64_t z = smz_mix64(smz_mix64(smz_mix64(seed ^ (env * 0xD1342543DE82EF95ull)) + epoch) + comp);
-    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
-}
-
 #if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
-// k_cartpole_step with the game bookkeeping of self_play.py:79 / game.py:270-271 per env: the flag written to
-// flag_out / the record's `terminated` slot is 0 running, 1 terminated (Game.done True), 2 stopped by
-// limit_of_game_play (the game is over but Game.done stays False, game.py:270-271), 3 no step taken (env switched off).
-// on_end: 1 = a finished env is switched off (active[e] = 0: the searches skip it from now on), 2 = it starts its next
-// episode at once (state ~ U(-0.05, 0.05)^4 from the counter-based generator, episode[e] + 1).
-__global__ void __launch_bounds__(256) k_cartpole_step_ctl(double *state, const int32_t *action, float *obs_out,
-                                                           float *reward_out, uint8_t *flag_out, int32_t *step_count,
-                                                           int32_t *episode, uint8_t *active, int limit, int on_end,
-                                                           uint64_t reset_seed, long long first_env, int B, double *traj,
-                                                           int t, const double *policy, const double *child_visits,
-                                                           const float *root_value) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= B) return;
-    constexpr int A = 2, F = 4 + 3 * A + 3;
-    double *r = traj ? traj + ((size_t)t * B + e) * F : nullptr;
-    if (active && !active[e]) {
-        if (flag_out) flag_out[e] = 3;
-        if (reward_out) reward_out[e] = 0.f;
-        if (r) { for (int k = 0; k < F; k++) r[k] = 0.0; r[5] = 3.0; }
-        return;
-    }
-    const double g = 9.8, mc = 1.0, mp = 0.1, tm = mc + mp, len = 0.5, pml = mp * len, fm = 10.0, tau = 0.02;
-    double *st = state + (size_t)e * 4;
-    const double x = st[0], xd = st[1], th = st[2], thd = st[3];
-    const double force = action[e] == 1 ? fm : -fm;
-    const double ct = cos(th), sn = sin(th);
-    const double temp = (force + pml * thd * thd * sn) / tm;
-    const double tha = (g * sn - ct * temp) / (len * (4.0 / 3.0 - mp * ct * ct / tm));
-    const double xa = temp - pml * tha * ct / tm;
-    double nx = x + tau * xd, nxd = xd + tau * xa, nth = th + tau * thd, nthd = thd + tau * tha;
-    const bool term = fabs(nx) > 2.4 || fabs(nth) > 12.0 * 2.0 * 3.14159265358979323846 / 360.0;
-    const int count = step_count[e] + 1;
-    const int flag = (limit > 0 && count == limit) ? 2 : (term ? 1 : 0);
-    if (r) {
-        r[0] = (double)(float)nx; r[1] = (double)(float)nxd; r[2] = (double)(float)nth; r[3] = (double)(float)nthd;
-        r[4] = 1.0;
-        r[5] = (double)flag;
-        r[6] = policy[(size_t)e * A]; r[7] = policy[(size_t)e * A + 1];
-        r[8] = action[e] == 0 ? 1.0 : 0.0; r[9] = action[e] == 1 ? 1.0 : 0.0;
-        r[10] = (double)root_value[e];
-        r[11] = child_visits[(size_t)e * A]; r[12] = child_visits[(size_t)e * A + 1];
-    }
-    if (reward_out) reward_out[e] = 1.0f;
-    if (flag_out) flag_out[e] = (uint8_t)flag;
-    int next_count = count;
-    if (flag != 0 && on_end == 2) {
-        const int ep = episode[e] + 1;
-        episode[e] = ep;
-        nx = -0.05 + 0.1 * smz_unit(reset_seed, (uint64_t)(first_env + e), (uint64_t)ep, 0);
-        nxd = -0.05 + 0.1 * smz_unit(reset_seed, (uint64_t)(first_env + e), (uint64_t)ep, 1);
-        nth = -0.05 + 0.1 * smz_unit(reset_seed, (uint64_t)(first_env + e), (uint64_t)ep, 2);
-        nthd = -0.05 + 0.1 * smz_unit(reset_seed, (uint64_t)(first_env + e), (uint64_t)ep, 3);
-        next_count = 0;
-    } else if (flag != 0 && on_end == 1 && active) {
-        active[e] = 0;
-    }
-    step_count[e] = next_count;
-    st[0] = nx; st[1] = nxd; st[2] = nth; st[3] = nthd;
-    if (obs_out) {
-        float *o = obs_out + (size_t)e * 4;
-        o[0] = (float)nx; o[1] = (float)nxd; o[2] = (float)nth; o[3] = (float)nthd;
-    }
-}
-
 // N(0,1) float32 observations of a stand-in env (Box-Muller on two counter-based uniforms), env-major [B][obs_dim]
 __global__ void __launch_bounds__(256) k_synthetic_obs(float *obs, int B, int obs_dim, uint64_t seed, long long first_env,
                                                        long long t) {
@@ -1137,6 +1128,30 @@ __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T,
 }
 #endif
 
+// Several games per env and chunk (on_end = "reset"; chunk_to_games(after_end = "new_game")): game_end[t][e] = one past the
+// last row of the game that row t of env e belongs to -- the row of its end flag (1 terminated / 2 step limit) + 1, or T
+// for the unfinished game at the end of the chunk; -1 for a row without a step (flag 3).  new_game == 0: rows behind the
+// first finished game belong to no game (the cut of k_traj_lengths).  length[e] = end of the env's first game.
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+__global__ void __launch_bounds__(256) k_traj_game_ends(const double *traj, int T, int obs_dim, int A, int B, int ignore_term,
+                                                        int new_game, int32_t *length, int32_t *game_end) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    const int F = obs_dim + 3 * A + 3;
+    int end = T, first = T;
+    for (int t = T - 1; t >= 0; t--) {
+        const int flag = ignore_term ? 0 : (int)traj[((size_t)t * B + e) * F + obs_dim + 1];
+        if (flag == 3) { end = t; game_end[(size_t)t * B + e] = -1; continue; }
+        if (flag != 0) end = t + 1;
+        game_end[(size_t)t * B + e] = end;
+        first = end;
+    }
+    if (!new_game)
+        for (int t = first; t < T; t++) game_end[(size_t)t * B + e] = -1;
+    if (length) length[e] = first;
+}
+#endif
+
 // n-step value target of every stored position (the value entry of Game.make_target and the target inside
 // Game.make_priority, game.py:291-337), with the reference's scalar types: root values are numpy float32, rewards and
 // discount powers Python floats, so under NEP 50 a bootstrapped chain (position + td_steps inside the game) runs in
@@ -1146,11 +1161,13 @@ __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T,
 #if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
 __global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T, int obs_dim, int A, int B, int td,
                                                       const double *disc_pow, const int32_t *length, double *target,
-                                                      double *abs_td) {
+                                                      double *abs_td, const int32_t *game_end = nullptr) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)T * B) return;
     const int t = (int)(i / B), e = (int)(i % B);
-    const int F = obs_dim + 3 * A + 3, n = length[e];
+    // (a game that starts inside the chunk: positions, bootstrap index and end are all chunk rows, so the arithmetic of a
+    // game-relative index is unchanged)
+    const int F = obs_dim + 3 * A + 3, n = game_end ? game_end[i] : length[e];
     const size_t rv_off = obs_dim + 2 + 2 * A;
     double out = 0.0, err = 0.0;
     if (t < n) {
@@ -1310,6 +1327,13 @@ extern "C" {
 #if SMZ_PART == 0 || SMZ_PART == 1
 const char *smz_last_error(void) { return g_err; }
 int smz_abi_version(void) { return SMZ_ABI_VERSION; }
+int smz_build_features(void) {
+#ifdef SMZ_WITH_REG
+    return SMZ_FEATURE_SEARCH_REG;
+#else
+    return 0;
+#endif
+}
 int smz_node_capacity(const smz_handle *h) { return h ? h->N : SMZ_ERR_INVALID; }
 
 int smz_create(const smz_config *cfg, smz_handle **out) {
@@ -1621,11 +1645,12 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
 #define SMZ_SEARCH_DISPATCH2(maxa, k, ...)                                          \
     if ((k) == 2) { constexpr int KS = 2; SMZ_SEARCH_DISPATCH(maxa, __VA_ARGS__); }  \
     else { constexpr int KS = 0; SMZ_SEARCH_DISPATCH(maxa, __VA_ARGS__); }
-struct SearchActArgs {       // ActOut across the translation-unit boundary (plain data)
+struct SearchActArgs {       // ActOut (+ the fused env step) across the translation-unit boundary (plain data)
     double temperature;
     int32_t *action;
     double *policy, *child_visits;
     float *root_value;
+    EnvStep env;             // env.state == nullptr: no env step in the launch
 };
 }  // extern "C" (internal C++ linkage for the two launchers)
 int smz_internal_search_launch_narrow(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
@@ -1651,8 +1676,8 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     if (train && h->cfg.num_simulations > 0 && !(h->cfg.root_dirichlet_alpha > 0))
         return fail(SMZ_ERR_INVALID, "root_dirichlet_alpha must be > 0 to draw noise (numpy raises ValueError)%s");
     DeviceGuard guard(h->cfg.device);
-#if SMZ_PART == 2
-    {   // SMZ_SEARCH_REG=1: the experimental kernel of smz_search_reg.hip for the shipped shape (S 31, H 64, L 0; 2 or 4
+#if SMZ_PART == 2 && defined(SMZ_WITH_REG)
+    {   // (library built with `make REG=1`) SMZ_SEARCH_REG=1: the experimental kernel of smz_search_reg.hip for the shipped shape (S 31, H 64, L 0; 2 or 4
         // actions, two sampled children, MT19937 streams) -- four trees per wavefront, weights in registers, layers on the
         // matrix cores.  Bit-identical to the kernel below; measured slower at 4096 trees (338 M vs 392 M simulations/s: one
         // wavefront per SIMD cannot overlap its tree phases with another wave's network evaluation), hence opt-in.
@@ -1661,7 +1686,7 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
         const bool shape = h->K == 2 && (h->P.A == 2 || h->P.A == 4) && h->P.A == h->maxa && desc->S == kFastS &&
                            desc->H == kFastH && desc->L == kFastL && !h->P.philox;
         const bool plain = !(h->P.stats || h->P.dbg) || (h->P.dbg & 64) != 0;
-        if (reg_on && shape && plain)
+        if (reg_on && shape && plain && !a.env.state)
             return smz_internal_search_launch_reg(h, desc, weights_dev, obs_dev, train, a.temperature, a.action, a.policy,
                                                   a.child_visits, a.root_value, pow_table_host, stream);
     }
@@ -1701,7 +1726,7 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
             granted = lds;                                                                                             \
         }                                                                                                              \
         hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR, AEX, MSK, PHX>), dim3(blocks), dim3(kWaves * kWave), lds,  \
-                           (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act);                           \
+                           (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act, a.env);                    \
     })
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
@@ -1712,7 +1737,7 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
         // phase stamps of the specialised instantiation itself (SMZ_DEBUG_SKIP=48), for the headline geometry only
         constexpr int MA = 2, KS = 2;
         hipLaunchKernelGGL((k_search_mlp<MA, KS, 1, true, true>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream,
-                           P, *desc, weights_dev, obs_dev, train, act);
+                           P, *desc, weights_dev, obs_dev, train, act, a.env);
     } else
 #endif
     if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false, true, false); }
@@ -1731,7 +1756,7 @@ extern "C" {
 int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
                    smz_stream stream) {
     return smz_internal_search_launch_narrow(h, desc, weights_dev, obs_dev, train,
-                                             SearchActArgs{0.0, nullptr, nullptr, nullptr, nullptr}, nullptr, stream);
+                                             SearchActArgs{0.0, nullptr, nullptr, nullptr, nullptr, EnvStep{}}, nullptr, stream);
 }
 
 int smz_search_mlp_act(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
@@ -1739,7 +1764,33 @@ int smz_search_mlp_act(smz_handle *h, const smz_mlp_desc *desc, const float *wei
                        double *child_visits_dev, float *root_value_dev, smz_stream stream) {
     if (!action_dev || !policy_dev || !child_visits_dev) return fail(SMZ_ERR_INVALID, "smz_search_mlp_act: null output%s");
     return smz_internal_search_launch_narrow(h, desc, weights_dev, obs_dev, train,
-                                             SearchActArgs{temperature, action_dev, policy_dev, child_visits_dev, root_value_dev},
+                                             SearchActArgs{temperature, action_dev, policy_dev, child_visits_dev, root_value_dev,
+                                                           EnvStep{}},
+                                             pow_table_host, stream);
+}
+
+int smz_search_mlp_act_cartpole(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, int train,
+                                double temperature, const double *pow_table_host, int32_t *action_dev, double *policy_dev,
+                                double *child_visits_dev, float *root_value_dev, const smz_cartpole_env *env,
+                                smz_stream stream) {
+    if (!action_dev || !policy_dev || !child_visits_dev || !root_value_dev || !env || !env->state_dev || !env->obs_dev)
+        return fail(SMZ_ERR_INVALID, "smz_search_mlp_act_cartpole: null argument%s");
+    if (!h || !desc || h->P.A != 2 || desc->obs != 4)
+        return fail(SMZ_ERR_INVALID, "smz_search_mlp_act_cartpole: the built-in env has 4 observations and 2 actions%s");
+    const smz_episode_ctl *c = env->ctl;
+    if (c && (!c->step_count_dev || c->on_end < 0 || c->on_end > 2 || (c->on_end == 2 && !c->episode_dev) ||
+              (c->on_end == 1 && !c->active_dev)))
+        return fail(SMZ_ERR_INVALID, "smz_search_mlp_act_cartpole: bad smz_episode_ctl (as smz_cartpole_step_ctl)%s");
+    if ((c ? c->active_dev : nullptr) != h->P.active)
+        return fail(SMZ_ERR_INVALID, "smz_search_mlp_act_cartpole: ctl->active_dev must be the array given to smz_set_active%s");
+    if (env->traj_dev && (env->t < 0 || env->t >= env->T))
+        return fail(SMZ_ERR_INVALID, "smz_search_mlp_act_cartpole: bad trajectory argument%s");
+    if (h->maxa > 4) return fail(SMZ_ERR_INVALID, "smz_search_mlp_act_cartpole: 2 actions%s");
+    const EnvStep E = {env->state_dev, env->obs_dev, env->reward_dev, env->flag_dev, c ? c->step_count_dev : nullptr,
+                       c ? c->episode_dev : nullptr, c ? c->active_dev : nullptr, c ? c->limit : 0, c ? c->on_end : 0,
+                       c ? (uint64_t)c->reset_seed : 0, c ? (long long)c->first_env : 0, env->traj_dev, env->t};
+    return smz_internal_search_launch_narrow(h, desc, weights_dev, env->obs_dev, train,
+                                             SearchActArgs{temperature, action_dev, policy_dev, child_visits_dev, root_value_dev, E},
                                              pow_table_host, stream);
 }
 #endif  // SMZ_PART != 4
@@ -1821,9 +1872,9 @@ int smz_prediction_epilogue(const float *policy_logits_pred_dev, const float *va
 int smz_cartpole_step(double *state_dev, const int32_t *action_dev, float *obs_out_dev, float *reward_out_dev,
                       uint8_t *terminated_out_dev, int B, smz_stream stream) {
     if (!state_dev || !action_dev || B < 1) return fail(SMZ_ERR_INVALID, "smz_cartpole_step: bad argument%s");
-    hipLaunchKernelGGL(k_cartpole_step, row_grid(B), dim3(256), 0, (hipStream_t)stream, state_dev, action_dev, obs_out_dev,
-                       reward_out_dev, terminated_out_dev, B, (double *)nullptr, 0, (const double *)nullptr,
-                       (const double *)nullptr, (const float *)nullptr);
+    const EnvStep E = {state_dev, obs_out_dev, reward_out_dev, terminated_out_dev, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0};
+    hipLaunchKernelGGL(k_cartpole_step_env, row_grid(B), dim3(256), 0, (hipStream_t)stream, E, action_dev, B,
+                       (const double *)nullptr, (const double *)nullptr, (const float *)nullptr);
     return launch_check();
 }
 
@@ -1832,8 +1883,9 @@ int smz_cartpole_step_pack(double *state_dev, const int32_t *action_dev, float *
                            const double *child_visits_dev, const float *root_value_dev, int B, smz_stream stream) {
     if (!state_dev || !action_dev || !traj_dev || !policy_dev || !child_visits_dev || !root_value_dev || t < 0 || t >= T || B < 1)
         return fail(SMZ_ERR_INVALID, "smz_cartpole_step_pack: bad argument%s");
-    hipLaunchKernelGGL(k_cartpole_step, row_grid(B), dim3(256), 0, (hipStream_t)stream, state_dev, action_dev, obs_out_dev,
-                       reward_out_dev, terminated_out_dev, B, traj_dev, t, policy_dev, child_visits_dev, root_value_dev);
+    const EnvStep E = {state_dev, obs_out_dev, reward_out_dev, terminated_out_dev, nullptr, nullptr, nullptr, 0, 0, 0, 0, traj_dev, t};
+    hipLaunchKernelGGL(k_cartpole_step_env, row_grid(B), dim3(256), 0, (hipStream_t)stream, E, action_dev, B, policy_dev,
+                       child_visits_dev, root_value_dev);
     return launch_check();
 }
 
@@ -1847,9 +1899,9 @@ int smz_cartpole_step_ctl(double *state_dev, const int32_t *action_dev, float *o
         return fail(SMZ_ERR_INVALID, "smz_cartpole_step_ctl: on_end 1 needs active_dev, on_end 2 needs episode_dev%s");
     if (traj_dev && (!policy_dev || !child_visits_dev || !root_value_dev || t < 0 || t >= T))
         return fail(SMZ_ERR_INVALID, "smz_cartpole_step_ctl: bad trajectory argument%s");
-    hipLaunchKernelGGL(k_cartpole_step_ctl, row_grid(B), dim3(256), 0, (hipStream_t)stream, state_dev, action_dev, obs_out_dev,
-                       reward_out_dev, flag_out_dev, ctl->step_count_dev, ctl->episode_dev, ctl->active_dev, ctl->limit,
-                       ctl->on_end, (uint64_t)ctl->reset_seed, (long long)ctl->first_env, B, traj_dev, t, policy_dev,
+    const EnvStep E = {state_dev, obs_out_dev, reward_out_dev, flag_out_dev, ctl->step_count_dev, ctl->episode_dev,
+                       ctl->active_dev, ctl->limit, ctl->on_end, (uint64_t)ctl->reset_seed, (long long)ctl->first_env, traj_dev, t};
+    hipLaunchKernelGGL(k_cartpole_step_env, row_grid(B), dim3(256), 0, (hipStream_t)stream, E, action_dev, B, policy_dev,
                        child_visits_dev, root_value_dev);
     return launch_check();
 }
@@ -1943,7 +1995,23 @@ int smz_traj_targets(const double *traj_dev, int T, int obs_dim, int A, int B, i
                        ignore_termination, length_dev);
     const size_t cells = (size_t)T * B;
     hipLaunchKernelGGL(k_traj_targets, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, (hipStream_t)stream, traj_dev, T,
-                       obs_dim, A, B, td_steps, discount_pow_dev, length_dev, value_target_dev, abs_td_error_dev);
+                       obs_dim, A, B, td_steps, discount_pow_dev, (const int32_t *)length_dev, value_target_dev,
+                       abs_td_error_dev, (const int32_t *)nullptr);
+    return launch_check();
+}
+
+int smz_traj_targets_games(const double *traj_dev, int T, int obs_dim, int A, int B, int td_steps,
+                           const double *discount_pow_dev, int ignore_termination, int new_game, int32_t *length_dev,
+                           int32_t *game_end_dev, double *value_target_dev, double *abs_td_error_dev, smz_stream stream) {
+    if (!traj_dev || !discount_pow_dev || !game_end_dev || !value_target_dev || T < 1 || B < 1 || A < 1 || obs_dim < 1 ||
+        td_steps < 0)
+        return fail(SMZ_ERR_INVALID, "smz_traj_targets_games: bad argument%s");
+    hipLaunchKernelGGL(k_traj_game_ends, row_grid(B), dim3(256), 0, (hipStream_t)stream, traj_dev, T, obs_dim, A, B,
+                       ignore_termination, new_game, length_dev, game_end_dev);
+    const size_t cells = (size_t)T * B;
+    hipLaunchKernelGGL(k_traj_targets, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, (hipStream_t)stream, traj_dev, T,
+                       obs_dim, A, B, td_steps, discount_pow_dev, (const int32_t *)nullptr, value_target_dev, abs_td_error_dev,
+                       (const int32_t *)game_end_dev);
     return launch_check();
 }
 

@@ -149,6 +149,7 @@ class SearchEngine:
 
     def root_init(self, hidden, policy, train=True, noise_override=None):
         self._act_done = None
+        self.env_stepped = False
         hidden = self._f32(hidden.reshape(self.B, -1), (self.B, self.S)) if self.S > 0 else None
         policy = self._f32(policy, (self.B, self.A))
         if noise_override is not None:
@@ -186,12 +187,26 @@ class SearchEngine:
             tab = self._pow_tables[temperature] = pow_table(temperature, self.sims + 1)
         return tab
 
-    def search_mlp(self, mlp_desc, weights, obs, train=True, act_temperature=None):
+    def search_mlp(self, mlp_desc, weights, obs, train=True, act_temperature=None, env_step=None):
         """Whole search (root + num_simulations rounds) in one launch with LDS-resident mlp_model heads.  With
         `act_temperature` the action selection of act() runs in the tail of the same launch; the next act() call with
-        that temperature returns its outputs without launching anything."""
+        that temperature returns its outputs without launching anything.  `env_step` (a _lib.CartPoleEnv whose obs_dev is
+        `obs`; needs act_temperature): the built-in env's step + trajectory record run in the tail too
+        (smz_search_mlp_act_cartpole) -- one launch per env step."""
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[0] == self.B
         self._act_done = None
+        self.env_stepped = False
+        if env_step is not None:
+            assert act_temperature is not None and env_step.obs_dev == obs.data_ptr()
+            T = float(act_temperature)
+            tab = self._pow_table(T)
+            _lib.check(self.lib.smz_search_mlp_act_cartpole(self.h, C.byref(mlp_desc), _ptr(weights), int(bool(train)), T,
+                                                            None if tab is None else tab.ctypes.data_as(C.c_void_p),
+                                                            _ptr(self.action), _ptr(self.policy), _ptr(self.child_visits),
+                                                            _ptr(self.root_value), C.byref(env_step), self._stream()))
+            self._act_done = T
+            self.env_stepped = True
+            return
         if act_temperature is None:
             _lib.check(self.lib.smz_search_mlp(self.h, C.byref(mlp_desc), _ptr(weights), _ptr(obs), int(bool(train)),
                                                self._stream()))
@@ -210,6 +225,7 @@ class SearchEngine:
         hidden0 = self._f32(hidden0.reshape(self.B, -1), (self.B, self.S))
         policy0 = self._f32(policy0, (self.B, self.A))
         self._act_done = None
+        self.env_stepped = False
         if act_temperature is None:
             _lib.check(self.lib.smz_search_vision(self.h, C.byref(vision_desc), _ptr(weights), _ptr(hidden0), _ptr(policy0),
                                                   int(bool(train)), self._stream()))

@@ -6,6 +6,7 @@ LunarLander-shaped stand-in that only provides observations of the right width. 
 state from `RandomState(seed).uniform(...)[i]`, so a shard sees exactly the rows it would see in a single-GPU run.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -76,6 +77,16 @@ class CartPoleVec:
     def step(self, action):
         """action: int32 [B] device tensor (index into action_map).  Asynchronous on the current stream."""
         return self.step_and_record(action, None, 0, None, None, None)
+
+    def fused_step(self, chunk_data, t):
+        """The arguments of smz_search_mlp_act_cartpole for this env's next step (the step + record run in the tail of the
+        search launch: one launch per env step).  SMZ_FUSED_ENV_STEP=0 keeps the two launches (A/B runs)."""
+        if os.environ.get("SMZ_FUSED_ENV_STEP", "1") == "0":
+            return None
+        P = lambda x: None if x is None else x.data_ptr()
+        ctl = C.pointer(self._ctl_struct()) if self._controlled() else None
+        return _lib.CartPoleEnv(P(self.state), P(self.obs), P(self.reward), P(self.terminated), ctl, P(chunk_data),
+                                0 if chunk_data is None else chunk_data.shape[0], int(t))
 
     def step_and_record(self, action, chunk_data, t, policy, child_visits, root_value):
         """step(action) + the trajectory record of this step (smz_traj_pack's layout) in one launch."""

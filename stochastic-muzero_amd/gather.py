@@ -44,7 +44,8 @@ def broadcast_model(model, src=0, group=None, device=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return model
     use_cuda = dist.get_backend(group) == "nccl"
-    dev = torch.device(device if device is not None else ("cuda" if use_cuda else "cpu"))
+    # (gloo = the functional runs without RCCL: the message goes through the host whatever `device` says)
+    dev = torch.device((device if device is not None else "cuda") if use_cuda else "cpu")
     for name in ("representation", "prediction", "afterstate_prediction", "afterstate_dynamics", "dynamics", "encoder"):
         module = getattr(model, name + "_function")
         tensors, seen = [], set()

@@ -92,6 +92,7 @@ class BatchedMCTS(_Hyper):
         self.engine = None
         self._graph = None
         self._graph_key = None
+        self._graph_heads = None
         self._single = None
         # beyond ~17 k trees the step-wise kernels (64 trees per wavefront, networks as 16-leaf tiles on the matrix cores, rows
         # left in the tree) overtake the single launch: measured on one box (tools/crossover.sh) 440 vs 424 M simulations/s at
@@ -119,6 +120,9 @@ class BatchedMCTS(_Hyper):
     def set_active(self, active):
         """uint8 [num_trees] device tensor (or None): trees whose byte is 0 are skipped by run() and act() -- finished
         games stop consuming simulations (self_play.py:79).  A captured graph holds the pointer, so it is dropped."""
+        if active is getattr(self, "_active", None) and (active is None or self.engine is None or
+                                                         getattr(self.engine, "_active", None) is active):
+            return                          # the same array is bound already: a captured graph stays valid
         self._active = active
         self._graph = None
         if self.engine is not None:
@@ -171,11 +175,13 @@ class BatchedMCTS(_Hyper):
             self._search(self._static_obs, heads, train)
         self._graph, self._graph_key = g, key
 
-    def run(self, observations, heads, train=True, act_temperature=None):
+    def run(self, observations, heads, train=True, act_temperature=None, env_step=None):
         """observations: [B, ...] float32 tensor on the engine's device.  Returns the engine; the search has been
         enqueued on the current stream (read results with engine.root_stats() / engine.act()).
         With HipMlpHeads the whole search is ONE kernel launch (smz_search_mlp) when it fits in LDS; otherwise the
-        step-wise kernels run, captured in a HIP graph unless use_graph is off."""
+        step-wise kernels run, captured in a HIP graph unless use_graph is off.
+        `env_step` (envs.CartPoleVec.fused_step): the single launch also steps the built-in env and appends the record;
+        `engine.env_stepped` says whether it did (any other path leaves the env to the caller)."""
         # (single_launch_max_trees: where the step-wise kernels overtake the single launch)
         if (self.single_launch and isinstance(getattr(heads, "desc", None), _lib.MlpDesc) and self._single is not False
                 and self.num_trees <= self.single_launch_max_trees):
@@ -184,7 +190,8 @@ class BatchedMCTS(_Hyper):
                 eng.seed(self._pending_seed)
                 self._pending_seed = None
             try:
-                eng.search_mlp(heads.desc, heads.weights, observations, train=train, act_temperature=act_temperature)
+                eng.search_mlp(heads.desc, heads.weights, observations, train=train, act_temperature=act_temperature,
+                               env_step=env_step if act_temperature is not None else None)
                 self._single = True
                 return eng
             except _lib.SmzError as err:
@@ -216,9 +223,13 @@ class BatchedMCTS(_Hyper):
         if not self.use_graph:
             self._search(observations, heads, train)
             return self.engine
-        key = (tuple(observations.shape), id(heads), bool(train))
-        if self._graph is None or self._graph_key != key:
+        # the captured graph holds raw pointers into `heads` (weights, output buffers): the object is kept alive with the
+        # graph and compared by identity -- Muzero.heads() builds a NEW evaluator after every weight update, and a bare
+        # id() of a freed one can be handed out again by CPython
+        key = (tuple(observations.shape), bool(train))
+        if self._graph is None or self._graph_key != key or self._graph_heads is not heads:
             self._build_graph(observations, heads, train, key)
+            self._graph_heads = heads
         self._static_obs.copy_(observations)
         self._graph.replay()
         return self.engine

@@ -63,11 +63,19 @@ class TrajectoryChunk:
                     child_visits=d[..., o + 3 + 2 * A:o + 3 + 3 * A])
 
 
-def chunk_targets(chunk_data, obs_dim, A, discount, td_steps, ignore_termination=False):
-    """Vectorised replay ingest on the device (smz_traj_targets): for a [T][B][F] chunk returns
+def chunk_targets(chunk_data, obs_dim, A, discount, td_steps, ignore_termination=False, after_end="drop",
+                  return_game_end=False):
+    """Vectorised replay ingest on the device (smz_traj_targets_games): for a [T][B][F] chunk returns
     (length [B] i32, value_target [T][B] f64, abs_td_error [T][B] f64) -- per stored position the n-step return that
     GameRecord.make_target / make_priority (game.py:291-337) compute one position at a time, bit for bit, and
-    |root value - return| (the priority before `** priority_scale`)."""
+    |root value - return| (the priority before `** priority_scale`).
+
+    after_end as in chunk_to_games: "drop" -- an env's rows behind its first finished game belong to no game (targets 0);
+    "new_game" -- they are its next games (on_end="reset" chunks), each with its own targets, the rows after the last end
+    flag forming an unfinished game cut at the chunk's end (chunk_to_games(keep_partial=True)).  `length` is the end of
+    each env's FIRST game either way; return_game_end adds game_end [T][B] i32 (one past the last row of the row's game,
+    -1: no game) as a fourth result."""
+    assert after_end in ("drop", "new_game")
     lib = _lib.load()
     T, B, F = chunk_data.shape
     assert chunk_data.is_cuda and chunk_data.dtype == torch.float64 and chunk_data.is_contiguous()
@@ -75,13 +83,15 @@ def chunk_targets(chunk_data, obs_dim, A, discount, td_steps, ignore_termination
     dev = chunk_data.device
     pows = torch.tensor([discount ** i for i in range(int(td_steps) + 1)], dtype=torch.float64).to(dev)   # Python's pow
     length = torch.empty(B, dtype=torch.int32, device=dev)
+    game_end = torch.empty(T, B, dtype=torch.int32, device=dev)
     target = torch.empty(T, B, dtype=torch.float64, device=dev)
     err = torch.empty(T, B, dtype=torch.float64, device=dev)
     P = lambda t: C.c_void_p(t.data_ptr())
-    _lib.check(lib.smz_traj_targets(P(chunk_data), T, int(obs_dim), int(A), B, int(td_steps), P(pows),
-                                    int(bool(ignore_termination)), P(length), P(target), P(err),
-                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-    return length, target, err
+    _lib.check(lib.smz_traj_targets_games(P(chunk_data), T, int(obs_dim), int(A), B, int(td_steps), P(pows),
+                                          int(bool(ignore_termination)), int(after_end == "new_game"), P(length),
+                                          P(game_end), P(target), P(err),
+                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return (length, target, err, game_end) if return_game_end else (length, target, err)
 
 
 def chunk_to_games(chunk_data, obs_dim, A, discount, priority_scale=1, limit_of_game_play=float("inf"),
@@ -123,30 +133,43 @@ def chunk_to_games(chunk_data, obs_dim, A, discount, priority_scale=1, limit_of_
     return games
 
 
+def _sync_active(env, mcts):
+    """Hands the env's on/off array to the search (finished games stop consuming simulations, self_play.py:79)."""
+    if getattr(env, "active", None) is not None or getattr(mcts, "_active", None) is not None:
+        mcts.set_active(getattr(env, "active", None))
+
+
+def _play_step(env, heads, mcts, chunk, t, temperature, train=True):
+    """ONE env step of all env.B environments on the current stream -- the loop body of self_play.py:79-94: search the
+    current observation, pick the action (game.py:179-232), step the env, append the record (game.py:193-195,
+    263-267).  The single code path behind play_games and play_games_grouped."""
+    fused = getattr(env, "fused_step", None)     # built-in env + single-launch search: ONE launch per env step
+    env_step = fused(chunk.data, t) if fused is not None else None
+    eng = mcts.run(env.obs, heads, train=train, act_temperature=temperature, **({} if env_step is None else dict(env_step=env_step)))
+    if env_step is not None and getattr(eng, "env_stepped", False):
+        return
+    action, policy, child_visits, root_value = eng.act(temperature)
+    if hasattr(env, "step_and_record"):          # built-in env: step + record in one launch
+        env.step_and_record(action, chunk.data, t, policy, child_visits, root_value)
+        return
+    obs, reward, terminated = env.step(action)
+    rec_obs = getattr(env, "record_obs", None)   # post-step observation when `obs` already is the next game's reset one
+    P = lambda x: C.c_void_p(x.data_ptr())
+    _lib.check(_lib.load().smz_traj_pack(P(chunk.data), chunk.T, t, env.obs_dim, env.num_actions,
+                                         P(obs if rec_obs is None else rec_obs), P(reward), P(terminated), P(action),
+                                         P(policy), P(child_visits), P(root_value), env.B,
+                                         C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)))
+
+
 def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
     """Plays `steps` env steps of all env.B environments; returns the TrajectoryChunk (device resident).
     Everything is enqueued asynchronously on the current stream; the caller synchronises."""
-    lib = _lib.load()
-    dev = env.device
-    A = env.num_actions
     if chunk is None:
-        chunk = TrajectoryChunk(steps, env.B, env.obs_dim, A, dev)
+        chunk = TrajectoryChunk(steps, env.B, env.obs_dim, env.num_actions, env.device)
     assert chunk.T >= steps and chunk.B == env.B
-    obs = env.obs
-    P = lambda t: C.c_void_p(t.data_ptr())
-    if getattr(env, "active", None) is not None or getattr(mcts, "_active", None) is not None:
-        mcts.set_active(getattr(env, "active", None))      # finished games stop consuming simulations (self_play.py:79)
+    _sync_active(env, mcts)
     for t in range(steps):
-        eng = mcts.run(obs, heads, train=train, act_temperature=temperature)
-        action, policy, child_visits, root_value = eng.act(temperature)
-        if hasattr(env, "step_and_record"):          # built-in env: step + record in one launch
-            obs, reward, terminated = env.step_and_record(action, chunk.data, t, policy, child_visits, root_value)
-        else:
-            obs, reward, terminated = env.step(action)
-            rec_obs = getattr(env, "record_obs", None)       # post-step observation when `obs` already is a reset one
-            _lib.check(lib.smz_traj_pack(P(chunk.data), chunk.T, t, env.obs_dim, A, P(obs if rec_obs is None else rec_obs),
-                                         P(reward), P(terminated), P(action), P(policy), P(child_visits), P(root_value),
-                                         env.B, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        _play_step(env, heads, mcts, chunk, t, temperature, train)
     return chunk
 
 
@@ -167,26 +190,18 @@ class StreamGroup:
 
 def play_games_grouped(groups, temperature, steps, train=True):
     """play_games for several StreamGroups concurrently: step t of every group is enqueued before step t+1 of any,
-    each on its group's stream; the caller's stream waits for all of them at the end."""
+    each on its group's stream; the caller's stream waits for all of them at the end.  Per group it is play_games' own
+    step (_play_step), so the chunks equal the ungrouped ones env by env."""
     dev = groups[0].env.device
     cur = torch.cuda.current_stream(dev)
     for g in groups:
         g.stream.wait_stream(cur)
-    lib = _lib.load()
-    P = lambda t: C.c_void_p(t.data_ptr())
+        assert g.chunk.T >= steps
+        _sync_active(g.env, g.mcts)
     for t in range(steps):
         for g in groups:
             with torch.cuda.stream(g.stream):
-                env = g.env
-                eng = g.mcts.run(env.obs, g.heads, train=train, act_temperature=temperature)
-                action, policy, child_visits, root_value = eng.act(temperature)
-                if hasattr(env, "step_and_record"):      # built-in env: step + record in one launch
-                    env.step_and_record(action, g.chunk.data, t, policy, child_visits, root_value)
-                else:
-                    obs, reward, terminated = env.step(action)
-                    _lib.check(lib.smz_traj_pack(P(g.chunk.data), g.chunk.T, t, env.obs_dim, env.num_actions, P(obs),
-                                                 P(reward), P(terminated), P(action), P(policy), P(child_visits),
-                                                 P(root_value), env.B, C.c_void_p(g.stream.cuda_stream)))
+                _play_step(g.env, g.heads, g.mcts, g.chunk, t, temperature, train)
     for g in groups:
         cur.wait_stream(g.stream)
     return [g.chunk for g in groups]
@@ -325,7 +340,7 @@ def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None
 def learning_cycle(number_of_iteration=10000, number_of_self_play_before_training=1, number_of_training_before_self_play=1,
                    model_tag_number=124, number_of_worker_selfplay=1, temperature_type="static_temperature", verbose=True,
                    muzero_model=None, gameplay=None, monte_carlo_tree_search=None, replay_buffer=None,
-                   steps_per_iteration=None, gather=None, model_directory="model_checkpoint"):
+                   steps_per_iteration=None, gather=None, model_directory="model_checkpoint", broadcast=None):
     """The reference's learning_cycle (self_play.py:168-306), same keyword arguments, assertions and return value
     (epoch_pr, loss, reward, configuration).  What plays the games is chosen the way the reference chooses its backend
     (self_play.py:237-243), by `number_of_worker_selfplay` and by what `gameplay` is:
@@ -338,6 +353,12 @@ def learning_cycle(number_of_iteration=10000, number_of_self_play_before_trainin
         workers of the reference are not part of this build -- a worker count >= 2 with a single-game `gameplay` is
         served sequentially).
 
+    Several ranks (one process per GPU): pass `gather=gather.gather_to_learner`.  Every rank plays its env shard; the
+    learner rank (0) receives all trajectories, stores the games, saves and trains; the actor ranks do none of that (their
+    reward / loss entries are nan); after the training phase the learner's weights are broadcast to every rank
+    (`broadcast`, default gather.broadcast_model) so that the next iteration's searches use them -- the place where the
+    reference re-pickles the model into its Ray tasks (self_play.py:249-256).
+
     The training half (self_play.py:285-288) calls muzero_model.train(replay_buffer.sample_batch()) exactly as the
     reference does; this package's Muzero raises NotImplementedError there (training is the reference's), any model
     object with the reference's train() works."""
@@ -349,35 +370,50 @@ def learning_cycle(number_of_iteration=10000, number_of_self_play_before_trainin
     assert isinstance(temperature_type, str) and temperature_type in ["reversal_tanh_temperature", "extreme_temperature", "linear_decrease_temperature", "static_temperature", "static_one_temperature"], "temperature_type ∈ {reversal_tanh_temperature,extreme_temperature,linear_decrease_temperature,static_temperature,static_one_temperature} ⊆ str "
     assert isinstance(verbose, bool), "verbose ∈ bool"
     batched = number_of_worker_selfplay == "gpu" or hasattr(gameplay, "B")
+    if broadcast is None and gather is not None:
+        from . import gather as _gather                       # the learner -> actors hand-off that goes with `gather`
+        broadcast = lambda m: _gather.broadcast_model(m, src=0, device=getattr(gameplay, "device", None))
     reward, epoch_pr, loss = [-float("inf")], [], []
+    if broadcast is not None:
+        broadcast(muzero_model)               # every rank starts from the learner's weights (Ray pickles the learner's model)
     for ep in range(1, number_of_iteration + 1):
         temperature = temperature_scheduler(number_of_iteration + 1, ep, mode=temperature_type)
         if isinstance(temperature, np.ndarray):
             temperature = float(temperature.reshape(-1)[0])
+        learner = True
         if batched:
             steps = steps_per_iteration or getattr(gameplay, "limit", 0) or 500
             game, _ = self_play_iteration(gameplay, muzero_model, monte_carlo_tree_search, temperature, steps, gather=gather)
+            learner = game is not None        # with `gather`, only the learner rank receives the games (self_play.py:240-256)
             game = game or []
         else:
             game = [play_game(environment=gameplay, model=muzero_model, monte_carlo_tree_search=monte_carlo_tree_search,
                               temperature=temperature, replay_buffer=replay_buffer)
                     for _ in range(number_of_self_play_before_training)]
         cache_reward, cache_loss = [], []
-        for g in game:
-            replay_buffer.save_game(g)
-            cache_reward.append(sum(g.rewards))
-        reward.append(sum(cache_reward) / len(cache_reward))
-        did_better = None if reward[-1] == max(reward) and not all(g.reanalyzed for g in game) else "do not save"
-        if did_better is None and verbose:
-            print("save model with : ", reward[-1], " reward")
-        muzero_model.save_model(directory=model_directory, tag=model_tag_number, model_update_or_backtrack=did_better)
-        for _ in range(number_of_training_before_self_play):
-            new_priority, batch_game_position = muzero_model.train(replay_buffer.sample_batch())
-            replay_buffer.update_value(new_priority, batch_game_position)
-            cache_loss.append(muzero_model.store_loss[-1][0])
+        if learner:
+            for g in game:
+                replay_buffer.save_game(g)
+                cache_reward.append(sum(g.rewards))
+            # (the reference divides by zero when an iteration yields no game; a chunk of on_end="reset" envs may hold no
+            # FINISHED game: nan, which never equals max(reward), so nothing is saved for it)
+            reward.append(sum(cache_reward) / len(cache_reward) if cache_reward else float("nan"))
+            did_better = None if (game and reward[-1] == max(r for r in reward if r == r)
+                                  and not all(g.reanalyzed for g in game)) else "do not save"
+            if did_better is None and verbose:
+                print("save model with : ", reward[-1], " reward")
+            muzero_model.save_model(directory=model_directory, tag=model_tag_number, model_update_or_backtrack=did_better)
+            for _ in range(number_of_training_before_self_play):
+                new_priority, batch_game_position = muzero_model.train(replay_buffer.sample_batch())
+                replay_buffer.update_value(new_priority, batch_game_position)
+                cache_loss.append(muzero_model.store_loss[-1][0])
+        else:
+            reward.append(float("nan"))       # an actor rank neither stores games, nor saves, nor trains
+        if broadcast is not None:
+            broadcast(muzero_model)           # the new weights reach the actors (self_play.py:285-288 -> next :249-256)
         loss.append(sum(cache_loss) / len(cache_loss) if cache_loss else float("nan"))   # (the reference divides by 0 here)
         epoch_pr.append(f"EPOCH {ep} || selfplay reward: {reward[-1]} || training loss: {loss[-1]}||")
-        if verbose:
+        if verbose and learner:
             print(epoch_pr[-1], end="\r")
     configuration = {"number_of_iteration": number_of_iteration,
                      "number_of_self_play_before_training": number_of_self_play_before_training,

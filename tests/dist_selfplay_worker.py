@@ -54,9 +54,14 @@ def main():
     chunk = sp.play_games(env, heads, m, 1.0, a.steps)
     parts = g.gather_to_learner(chunk.data)
     torch.cuda.synchronize(dev)
+    ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(ones)                                           # the rank count as the collective itself sees it
+    single = [None] * world
+    dist.all_gather_object(single, m._single is True)
     if rank == 0:
         assert parts is not None and len(parts) == world
         torch.save(dict(data=torch.cat([p.cpu() for p in parts], dim=1), backend=backend, world=world,
+                        ranks_seen_by_collective=int(ones.item()), single_launch=single,
                         weights=heads.weights.cpu()), os.path.join(a.out, "gathered.pt"))
     else:
         assert parts is None

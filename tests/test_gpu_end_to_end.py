@@ -251,6 +251,9 @@ def test_register_resident_search_kernel_equals_production_kernel(wname, B, sims
     vector-unit heads (even / odd accumulator chains, sums in wave_sum's association), so whole searches must agree bit for
     bit with the production kernel: visits, priors, values, every dumped tree array, stream positions."""
     mcts_mod, model_mod, _, _ = _mods()
+    lib_mod = import_module("stochastic-muzero_amd._lib")
+    if not lib_mod.load().smz_build_features() & lib_mod.FEATURE_SEARCH_REG:
+        pytest.skip("libsmz.so built without the experimental kernel (make -C stochastic-muzero_amd/csrc REG=1)")
     model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
     heads = model.heads("cuda:0", backend="hip")
     obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(3)).mul(0.3).cuda()

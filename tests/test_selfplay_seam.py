@@ -194,6 +194,31 @@ def test_learning_cycle_keeps_the_references_call_sequence():
             sp.learning_cycle(**kw)
 
 
+def test_learning_cycle_on_an_actor_rank_and_without_finished_games(monkeypatch):
+    """ADVICE r2 / VERDICT r2 #1b: with `gather`, self_play_iteration returns the games on the learner rank only.  An actor
+    rank must not store, save or train -- and must not divide by zero; the weights are broadcast before the first and after
+    every iteration on every rank.  A learner iteration without a finished game (on_end="reset" chunk too short) records
+    nan and saves nothing."""
+    sp = _pkg("selfplay")
+    cfg, data = gu.load("selfplay421_sims10_T0")
+
+    class _Vec:
+        B, limit, device = 4, 0, "cpu"
+    for games_per_iteration, learner in ((None, False), ([], True)):
+        model, buf, sent = _TrainableStub(data), sh.FakeBuffer(), []
+        monkeypatch.setattr(sp, "self_play_iteration", lambda *a, **k: (games_per_iteration, None))
+        epoch_pr, loss, reward, conf = sp.learning_cycle(
+            number_of_iteration=2, number_of_training_before_self_play=1, model_tag_number=7, verbose=False,
+            muzero_model=model, gameplay=_Vec(), monte_carlo_tree_search=None, replay_buffer=buf, steps_per_iteration=3,
+            gather=lambda slab: None, broadcast=lambda m: sent.append(m))
+        assert len(sent) == 3 and all(m is model for m in sent) and buf.saved == []
+        assert len(reward) == 3 and all(np.isnan(r) for r in reward[1:])
+        if learner:
+            assert model.saved == [(7, "do not save")] * 2 and model.trained == 2 and loss == [0.25, 0.5]
+        else:
+            assert model.saved == [] and model.trained == 0 and all(np.isnan(x) for x in loss)
+
+
 def test_chunk_flags_cut_games_like_the_loop_does():
     """Trajectory records -> games: flag 1 ends a game with done True, 2 (limit_of_game_play) with done False
     (game.py:270-271), 3 marks rows of a switched-off env; a restarting env yields several games per chunk."""
