@@ -86,7 +86,8 @@ def test_every_tree_of_every_step_of_the_timed_loop_equals_the_oracle(on_end, B,
     mcts_mod, model_mod, envs_mod, sp = (_pkg(m) for m in ("mcts", "model", "envs", "selfplay"))
     model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_ckpt421.npz"))
     heads = model.heads("cuda:0", backend="hip")
-    A, S, K, temperature, limit = 2, heads.S, 2, 1.0, (0 if on_end == "continue" else 5)
+    # (mask: everybody is stopped by the limit exactly with the last step, so that every step still has live trees)
+    A, S, K, temperature, limit = 2, heads.S, 2, 1.0, {"continue": 0, "reset": 5, "mask": T}[on_end]
     seeds = np.arange(B, dtype=np.uint64) + 4242
     # ---- the production loop's objects (what bench.py builds) ----
     env = envs_mod.CartPoleVec(B, "cuda:0", seed=0, on_end=on_end, limit=limit)
