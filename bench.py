@@ -53,7 +53,40 @@ WORKLOADS = {
     # (--heads torch: the same modules through torch-ROCm, for comparison)
     "vision_resnet_1024x50": dict(weights="visionnet_L1_seed0.npz", env="image", obs=3 * 98 * 98, A=2, K=2, sims=50, envs=1024),
 }
-TRAFFIC_FILES = {"cartpole_mlp_4096x50": "r02_traffic_k_search_mlp.json", "vision_resnet_1024x50": "r02_traffic_k_search_vision.json"}
+
+
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) of the kernel sources + the ABI header: counter files under profiles/ carry the value they
+    were measured with, so a later kernel change drops stale `roofline.traffic` figures by itself."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "stochastic-muzero_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.hpp")) + [os.path.join(ROOT, "include", "smz.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def find_traffic(workload, kernel):
+    """The committed TCC counter file (profiles/*traffic*.json) measured on exactly this kernel instantiation, this workload
+    and these kernel sources -- or (None, why not)."""
+    import glob
+    sha = kernel_source_sha16()
+    seen = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            tj = json.load(open(f))
+        except Exception:
+            continue
+        if tj.get("workload") != workload or tj.get("kernel") != kernel:
+            continue
+        if tj.get("source_sha16") != sha:
+            seen.append(os.path.basename(f))
+            continue
+        return tj, os.path.basename(f)
+    return None, ("no counter file for kernel %s on workload %s with the current kernel sources (sha %s)%s" %
+                  (kernel, workload, sha, "; stale: " + ", ".join(seen[:3]) if seen else ""))
 
 
 def algorithmic_bytes(stats, A, K, S, launches):
@@ -252,6 +285,11 @@ def main():
                                       on_end="reset", first_env=glo)
         elif wl["env"] == "cartpole":
             env = envs_mod.CartPoleVec(Bg, dev, seed=0, first_env=glo, total_envs=total)
+        elif wl["env"] == "image" and args.host_env:
+            # host envs observed through rendered 400x600x3 uint8 frames (CartPole-v1's render size), uploaded
+            # through pinned memory and resized to 98x98 on the engine's stream (smz_frames_resize_u8)
+            env = envs_mod.HostImageVecEnv([envs_mod.HostCartPoleRender((400, 600)) for _ in range(Bg)], (400, 600), wl["A"], dev,
+                                           env_seed=0, limit=0, on_end="reset", first_env=glo)
         elif wl["env"] == "image":
             env = envs_mod.ImageVec(Bg, wl["A"], dev, seed=0, first_env=glo, total_envs=total)
         else:
@@ -277,13 +315,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_chunks(chunks, n):
+        """The finished chunk of this rank -> learner rank: the float64 records and, for image workloads, the float32 frames."""
+        gather_mod.gather_to_learner(torch.cat([c.data[:n] for c in chunks], dim=1))
+        if chunks[0].obs is not None:
+            gather_mod.gather_to_learner(torch.cat([c.obs[:n] for c in chunks], dim=1))
+
     def timed_block():
         """EXACTLY K steps (+ the trajectory gather when N > 1) between two barrier + synchronize pairs; max over ranks."""
         barrier()
         t0 = time.perf_counter()
         chunks = sp.play_games_grouped(groups, args.temperature, args.steps)
         if world > 1:
-            gather_mod.gather_to_learner(torch.cat([c.data[:args.steps] for c in chunks], dim=1))   # -> learner rank
+            gather_chunks(chunks, args.steps)
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
@@ -300,21 +344,34 @@ def main():
     gc.disable()
     chunks = sp.play_games_grouped(groups, args.temperature, args.warmup)                 # W untimed warm-up steps
     if world > 1:      # the first grouped send/recv builds the RCCL communicators: keep that out of the timed region
-        gather_mod.gather_to_learner(torch.cat([c.data[:max(1, args.warmup)] for c in chunks], dim=1))
+        gather_chunks(chunks, max(1, args.warmup))
     first = timed_block()                                      # block 1 (timed like the others; also sizes R)
     R = int(min(args.max_blocks, max(1, np.ceil(args.min_timed_seconds / max(first, 1e-6)))))
     blocks = [first] + [timed_block() for _ in range(R - 1)]
     dt = float(np.median(blocks))
-    per_rank_rate = None
+    per_rank_rate, ranks_seen, gather_ms = None, None, None
     if world > 1:                                              # every rank's own rate of its last block, for the record
         barrier()
         t0 = time.perf_counter()
-        sp.play_games_grouped(groups, args.temperature, args.steps)
+        chunks = sp.play_games_grouped(groups, args.temperature, args.steps)
         torch.cuda.synchronize(dev)
         mine = B * wl["sims"] * args.steps / (time.perf_counter() - t0)
         rates = [None] * world
         dist.all_gather_object(rates, mine)
         per_rank_rate = [float(r) for r in rates]
+        # the rank count as the collective itself sees it, and the gather alone (a K-step chunk per rank -> rank 0), timed
+        # between barrier + synchronize pairs, max over ranks: what of a block's time is the exchange
+        ones = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        gts = []
+        for _ in range(5):
+            barrier()
+            t0 = time.perf_counter()
+            gather_chunks(chunks, args.steps)
+            barrier()
+            gts.append(max_over_ranks(time.perf_counter() - t0))
+        gather_ms = 1e3 * float(np.median(gts))
     sims_total = total * wl["sims"] * args.steps
     headline = args.workload == "cartpole_mlp_4096x50" and B == 4096 and not args.host_env and args.rng == "mt19937"
     single = getattr(mcts, "_single", None) is True
@@ -331,11 +388,13 @@ def main():
                         ("step-wise kernels" + ("" if args.no_graph else ", one HIP graph per env step")),
               "stream_groups": G, "heads": type(groups[0].heads).__name__,
               "env": ("host, compiled step (envs.HostCartPoleVec: pinned-memory action download + observation upload per step)" if args.host_env == "native"
+                      else "host, Python envs rendering 400x600x3 uint8 frames (envs.HostImageVecEnv: pinned-memory frame upload + smz_frames_resize_u8 per step)" if (args.host_env and wl["env"] == "image")
                       else "host, Python envs (envs.HostVecEnv, pinned-memory action download + observation upload per step)" if args.host_env else "device"),
               "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}
     if world > 1:
         config["collective_backend"] = "nccl (RCCL)" if backend == "nccl" else f"{backend} ({world} ranks share {n_dev} GPU(s))"
         config["ranks"] = world
+        config["ranks_seen_by_collective"] = ranks_seen
         config["gpus_visible"] = n_dev
     out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs x 50 sims" if headline else
                      f"MCTS simulations/sec (whole node), {args.workload} at {B} envs/GPU" + (" (host-resident envs)" if args.host_env else "")
@@ -352,6 +411,9 @@ def main():
                               "synchronize pairs, max over ranks"}}
     if per_rank_rate is not None:
         out["per_rank_simulations_per_s"] = per_rank_rate
+        out["timing"]["gather_ms_median"] = gather_ms
+        out["timing"]["gather_bytes_per_rank"] = int(sum(c.data[:args.steps].numel() * 8 + (c.obs[:args.steps].numel() * 4 if c.obs is not None else 0)
+                                                         for c in chunks))
 
     # ---- roofline (rank 0) --------------------------------------------------------------------------------------
     if rank == 0 and not args.no_roofline:
@@ -439,15 +501,20 @@ def main():
             ms, mean_us, bytes_launch = tms, tree_us, tree_bytes
         achieved = bytes_launch / (mean_us * 1e-6) / 1e9
         # HBM bytes per launch from the TCC counters, when a PMC pass of this workload/kernel has been committed
+        # ... of the kernel instantiation that actually ran (smz_last_kernel), same workload, same kernel sources
         traffic, traffic_note = None, None
-        tfile = os.path.join(ROOT, "profiles", TRAFFIC_FILES.get(args.workload, "-"))
-        if single and Bg == wl["envs"] and os.path.exists(tfile):
-            tj = json.load(open(tfile))
-            traffic = tj["hbm_bytes_per_launch_raw"]
-            traffic_note = ("(FETCH_SIZE + WRITE_SIZE) x 1024 per launch from " + os.path.basename(tfile) +
-                            "; read side may be under-counted up to 2x on gfx950 (upper bound %.0f)" % tj["hbm_bytes_per_launch_read_x2"])
+        launched = eng.last_kernel() if single else ""
+        if single and Bg == wl["envs"]:
+            tj, tname = find_traffic(args.workload + ("" if args.rng == "mt19937" else "+philox"), launched)
+            if tj is not None:
+                traffic = tj["hbm_bytes_per_launch_raw"]
+                traffic_note = ("(FETCH_SIZE + WRITE_SIZE) x 1024 per launch from " + tname +
+                                "; read side may be under-counted up to 2x on gfx950 (upper bound %.0f)" % tj["hbm_bytes_per_launch_read_x2"])
+            else:
+                traffic_note = tname
         out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                           "kernel_launched": launched or None, "kernel_source_sha16": kernel_source_sha16(),
                            "bytes_per_launch": bytes_launch,
                            "mean_launch_us": mean_us, "median_launch_us": float(np.median(ms) * 1e3),
                            "launches_timed": int(ms.size) * (PER_PAIR if single else 1), "bytes_per_tree_select": k2,

@@ -285,6 +285,13 @@ int smz_vision_layout(smz_vision_desc *desc);
  * channels), policy_out_dev [B,A] (softmax).  One 256-thread workgroup per frame. */
 int smz_vision_initial(const smz_vision_desc *desc, const float *weights_dev, const float *frames_dev,
                        float *hidden_out_dev, float *policy_out_dev, int B, smz_stream stream);
+/* Frame ingest: n_frames rendered frames [n][H][W][3] uint8 (as a host environment uploads them) -> the
+ * [*,3,out_h,out_w] float32 tensor smz_vision_initial reads: ToTensor (CHW, / 255) + bilinear Resize without antialias,
+ * align_corners = False -- Game.transform_rgb of the reference (game.py:82-89, 142-143), ATen's upsample_bilinear2d
+ * arithmetic in float32.  Frame i goes to output row rows_dev[i] (rows_dev NULL: row i), so a few frames can be patched into
+ * a full batch.  SMZ_ERR_TOO_LARGE for rows wider than ~10 000 pixels. */
+int smz_frames_resize_u8(const uint8_t *frames_dev, int n_frames, int H, int W, int out_h, int out_w, const int32_t *rows_dev,
+                         float *out_dev, smz_stream stream);
 /* recurrent step for all trees, one wavefront per leaf: parent_hidden_dev [B,ld] (first 147 floats of each row),
  * last_action_dev [B], branch_dev [B] as written by smz_select -> hidden_out_dev [B,147], reward_out_dev [B] (0 on the
  * afterstate branch), policy_out_dev [B,A], value_out_dev [B].  The action enters as the constant plane (a+1)/A
@@ -426,7 +433,9 @@ int smz_synthetic_obs(float *obs_dev, int B, int obs_dim, uint64_t seed, int64_t
  * smz_traj_floats(obs_dim, A) float64 values:
  *   [ observation AFTER the step (obs_dim) | reward | terminated | policy (A) | action one-hot (A) | root value |
  *     child_visits (A) ]
- * float64 keeps Game.policies / Game.child_visits exact; float32 fields widen exactly.  step t in [0,T). */
+ * float64 keeps Game.policies / Game.child_visits exact; float32 fields widen exactly.  step t in [0,T).
+ * obs_dim 0 (obs_dev may be NULL): the record without the observation -- image observations (28 812 floats per frame) are
+ * kept by the caller in a float32 buffer of their own (selfplay.TrajectoryChunk.obs) instead of being widened to float64. */
 int smz_traj_floats(int obs_dim, int A);
 int smz_traj_pack(double *traj_dev, int T, int t, int obs_dim, int A, const float *obs_dev, const float *reward_dev,
                   const uint8_t *terminated_dev, const int32_t *action_dev, const double *policy_dev, const double *child_visits_dev,
@@ -454,6 +463,11 @@ int smz_traj_targets_games(const double *traj_dev, int T, int obs_dim, int A, in
                            int32_t *game_end_dev, double *value_target_dev, double *abs_td_error_dev, smz_stream stream);
 
 /* ---- inspection ------------------------------------------------------------------------------------------------ */
+/* Name of the single-launch search kernel instantiation this handle launched last, spelled as rocprofv3 prints it (e.g.
+ * "k_search_mlp<2, 2, 1, false, true, false, false>"; "" before the first launch): measurement code attaches profiler
+ * evidence to the kernel that actually ran.  Returns the length. */
+int smz_last_kernel(const smz_handle *h, char *buf, int cap);
+
 /* [sync] Copies one tree to the host: up to `cap` nodes into `nodes`; minmax_out[2] = {min, max} (may be NULL);
  * path_out (cap_path entries) / path_len_out = the last recorded search path; root_priors_out [A] f64.
  * Returns the number of allocated nodes (>= 0) or a negative status. */

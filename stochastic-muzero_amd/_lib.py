@@ -67,6 +67,7 @@ SIGNATURES = {
     "smz_build_features": (C.c_int, []),
     "smz_last_error": (C.c_char_p, []),
     "smz_node_capacity": (C.c_int, [_P]),
+    "smz_last_kernel": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "smz_set_pb_c_table": (C.c_int, [_P, _P, C.c_int]),
     "smz_seed": (C.c_int, [_P, _P, _P]),
     "smz_set_rng_state": (C.c_int, [_P, C.c_int, _P, C.c_int]),
@@ -97,6 +98,7 @@ SIGNATURES = {
     "smz_search_mlp_act_cartpole": (C.c_int, [_P, C.POINTER(MlpDesc), _P, C.c_int, C.c_double, _P, _P, _P, _P, _P,
                                               C.POINTER(CartPoleEnv), _P]),
     "smz_search_mlp": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, _P]),
+    "smz_frames_resize_u8": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "smz_search_vision": (C.c_int, [_P, C.POINTER(VisionDesc), _P, _P, _P, C.c_int, _P]),
     "smz_search_vision_act": (C.c_int, [_P, C.POINTER(VisionDesc), _P, _P, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
     "smz_cartpole_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),

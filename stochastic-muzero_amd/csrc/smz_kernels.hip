@@ -1221,6 +1221,7 @@ struct smz_handle {
     uint32_t *d_block_backup;
     bool has_backup;
     std::vector<void *> allocs;
+    char last_kernel[96];      // the single-launch search instantiation launched last, as rocprofv3 prints it (smz_last_kernel)
 };
 
 // the last-error text is shared by the translation units this file is compiled into (SMZ_PART)
@@ -1335,6 +1336,11 @@ int smz_build_features(void) {
 #endif
 }
 int smz_node_capacity(const smz_handle *h) { return h ? h->N : SMZ_ERR_INVALID; }
+int smz_last_kernel(const smz_handle *h, char *buf, int cap) {
+    if (!h || !buf || cap < 1) return fail(SMZ_ERR_INVALID, "smz_last_kernel: bad argument%s");
+    snprintf(buf, (size_t)cap, "%s", h->last_kernel);
+    return (int)strlen(h->last_kernel);
+}
 
 int smz_create(const smz_config *cfg, smz_handle **out) {
     if (!cfg || !out) return fail(SMZ_ERR_INVALID, "smz_create: null argument%s");
@@ -1425,6 +1431,7 @@ int smz_create(const smz_config *cfg, smz_handle **out) {
     }
     P.philox = cfg->rng_mode == SMZ_RNG_PHILOX ? 1 : 0;
     h->has_backup = false;
+    h->last_kernel[0] = 0;
     if (rc != SMZ_OK) { smz_destroy(h); return rc; }
     P.pbc_sqrt = h->d_pbc;
     P.pow_table = nullptr;
@@ -1727,6 +1734,8 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
         }                                                                                                              \
         hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR, AEX, MSK, PHX>), dim3(blocks), dim3(kWaves * kWave), lds,  \
                            (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act, a.env);                    \
+        snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<%d, %d, %d, %s, %s, %s, %s>", MA, KS, UU,       \
+                 INSTR ? "true" : "false", AEX ? "true" : "false", MSK ? "true" : "false", PHX ? "true" : "false");     \
     })
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
     // when level statistics are enabled (smz_enable_stats) or a SMZ_DEBUG_SKIP switch is set.
@@ -1738,6 +1747,7 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
         constexpr int MA = 2, KS = 2;
         hipLaunchKernelGGL((k_search_mlp<MA, KS, 1, true, true>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream,
                            P, *desc, weights_dev, obs_dev, train, act, a.env);
+        snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<2, 2, 1, true, true, true, false>");
     } else
 #endif
     if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false, true, false); }
@@ -1975,8 +1985,8 @@ int smz_traj_floats(int obs_dim, int A) { return obs_dim + 3 * A + 3; }
 int smz_traj_pack(double *traj_dev, int T, int t, int obs_dim, int A, const float *obs_dev, const float *reward_dev,
                   const uint8_t *terminated_dev, const int32_t *action_dev, const double *policy_dev, const double *child_visits_dev,
                   const float *root_value_dev, int B, smz_stream stream) {
-    if (!traj_dev || !obs_dev || !action_dev || !policy_dev || !child_visits_dev || !root_value_dev || t < 0 || t >= T ||
-        B < 1 || A < 1 || obs_dim < 1)
+    if (!traj_dev || (!obs_dev && obs_dim > 0) || !action_dev || !policy_dev || !child_visits_dev || !root_value_dev || t < 0 ||
+        t >= T || B < 1 || A < 1 || obs_dim < 0)
         return fail(SMZ_ERR_INVALID, "smz_traj_pack: bad argument%s");
     const size_t slab = (size_t)B * (obs_dim + 3 * A + 3);
     const unsigned blocks = (unsigned)std::min<size_t>((slab + 255) / 256, 256 * 32);
@@ -1988,7 +1998,7 @@ int smz_traj_pack(double *traj_dev, int T, int t, int obs_dim, int A, const floa
 int smz_traj_targets(const double *traj_dev, int T, int obs_dim, int A, int B, int td_steps, const double *discount_pow_dev,
                      int ignore_termination, int32_t *length_dev, double *value_target_dev, double *abs_td_error_dev,
                      smz_stream stream) {
-    if (!traj_dev || !discount_pow_dev || !length_dev || !value_target_dev || T < 1 || B < 1 || A < 1 || obs_dim < 1 ||
+    if (!traj_dev || !discount_pow_dev || !length_dev || !value_target_dev || T < 1 || B < 1 || A < 1 || obs_dim < 0 ||
         td_steps < 0)
         return fail(SMZ_ERR_INVALID, "smz_traj_targets: bad argument%s");
     hipLaunchKernelGGL(k_traj_lengths, row_grid(B), dim3(256), 0, (hipStream_t)stream, traj_dev, T, obs_dim, A, B,
@@ -2003,7 +2013,7 @@ int smz_traj_targets(const double *traj_dev, int T, int obs_dim, int A, int B, i
 int smz_traj_targets_games(const double *traj_dev, int T, int obs_dim, int A, int B, int td_steps,
                            const double *discount_pow_dev, int ignore_termination, int new_game, int32_t *length_dev,
                            int32_t *game_end_dev, double *value_target_dev, double *abs_td_error_dev, smz_stream stream) {
-    if (!traj_dev || !discount_pow_dev || !game_end_dev || !value_target_dev || T < 1 || B < 1 || A < 1 || obs_dim < 1 ||
+    if (!traj_dev || !discount_pow_dev || !game_end_dev || !value_target_dev || T < 1 || B < 1 || A < 1 || obs_dim < 0 ||
         td_steps < 0)
         return fail(SMZ_ERR_INVALID, "smz_traj_targets_games: bad argument%s");
     hipLaunchKernelGGL(k_traj_game_ends, row_grid(B), dim3(256), 0, (hipStream_t)stream, traj_dev, T, obs_dim, A, B,

@@ -539,6 +539,7 @@ int search_vision_launch(smz_handle *h, const smz_vision_desc *desc, const float
         }                                                                                                              \
         hipLaunchKernelGGL((k_search_vision<MA, EQ>), dim3(blocks), dim3(kVW * kWave), lds, (hipStream_t)stream, P,    \
                            *desc, weights_dev, hidden0_dev, policy0_dev, train, act);                                  \
+        snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_vision<%d, %s>", MA, EQ ? "true" : "false");        \
     }
     if (h->maxa == 2 && P.A == 2) SMZ_LAUNCH_VS(2, true)
     else if (h->maxa == 2) SMZ_LAUNCH_VS(2, false)

@@ -272,6 +272,12 @@ class SearchEngine:
         out.update(n_nodes=n, minmax=minmax, path=path[:plen.value].copy(), root_priors=rp)
         return out
 
+    def last_kernel(self):
+        """Name of the single-launch search kernel instantiation launched last (as rocprofv3 prints it), "" if none."""
+        buf = C.create_string_buffer(128)
+        _lib.check(self.lib.smz_last_kernel(self.h, buf, 128))
+        return buf.value.decode()
+
     def enable_stats(self, on=True):
         _lib.check(self.lib.smz_enable_stats(self.h, int(bool(on))))
 

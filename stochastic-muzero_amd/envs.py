@@ -219,7 +219,7 @@ class HostVecEnv:
       * flags as smz_cartpole_step_ctl: 1 terminated, 2 stopped by `limit` (game.py:270-271), 3 no step (switched off);
       * on_end "mask": a finished env is switched off (`active`, handed to the search); "reset": it is reset at once and
         the NEXT search sees the fresh observation while the record keeps the post-step one (`record_obs`).
-    Observations are flattened float32 vectors (game.py:145-167); image observations go through `transform`."""
+    Observations are flattened float32 vectors (game.py:145-167); rendered RGB frames: HostImageVecEnv."""
 
     def __init__(self, envs, obs_dim, num_actions, device, action_map=None, env_seed=0, limit=0, on_end="reset", first_env=0,
                  transform=None):
@@ -230,16 +230,12 @@ class HostVecEnv:
         self.action_map = list(action_map) if action_map is not None else list(range(self.num_actions))
         self.env_seed, self.limit, self.on_end, self.first_env = int(env_seed), int(limit), on_end, int(first_env)
         self.transform = transform
-        B, o = self.B, self.obs_dim
+        B = self.B
         pin = dict(pin_memory=torch.cuda.is_available())
-        self._h_obs = torch.zeros(B, o, dtype=torch.float32, **pin)          # next search's input
-        self._h_rec = torch.zeros(B, o, dtype=torch.float32, **pin)          # post-step observation (the record's)
         self._h_reward = torch.zeros(B, dtype=torch.float32, **pin)
         self._h_flag = torch.zeros(B, dtype=torch.uint8, **pin)
         self._h_active = torch.ones(B, dtype=torch.uint8, **pin)
         self._h_action = torch.zeros(B, dtype=torch.int32, **pin)
-        self.obs = torch.zeros(B, o, dtype=torch.float32, device=self.device)
-        self.record_obs = torch.zeros(B, o, dtype=torch.float32, device=self.device)
         self.reward = torch.zeros(B, dtype=torch.float32, device=self.device)
         self.terminated = torch.zeros(B, dtype=torch.uint8, device=self.device)
         self.active = torch.ones(B, dtype=torch.uint8, device=self.device) if on_end == "mask" else None
@@ -247,16 +243,40 @@ class HostVecEnv:
         self.episode = np.zeros(B, np.int64)
         self.done = np.zeros(B, bool)
         self.transfer_seconds = 0.0            # host time spent waiting for the action download (diagnostic)
+        self._alloc_observations(pin)
 
-    def _flat(self, obs):
+    # ---- observation storage (vector observations; HostImageVecEnv overrides these four) -------------------------------
+    def _alloc_observations(self, pin):
+        B, o = self.B, self.obs_dim
+        self._h_obs = torch.zeros(B, o, dtype=torch.float32, **pin)          # next search's input
+        self._h_rec = torch.zeros(B, o, dtype=torch.float32, **pin)          # post-step observation (the record's)
+        self.obs = torch.zeros(B, o, dtype=torch.float32, device=self.device)
+        self.record_obs = torch.zeros(B, o, dtype=torch.float32, device=self.device)
+
+    def _observe(self, env, obs):
+        """What the agent sees after env.reset / env.step returned `obs`."""
         obs = obs[0] if isinstance(obs, tuple) else obs
         if self.transform is not None:
             obs = self.transform(obs)
         return np.asarray(obs, dtype=np.float32).reshape(-1)
 
+    def _store(self, i, seen, after_step):
+        """Keeps env i's observation: after a step it is both the record's and (until a reset replaces it) the next
+        search's input; after a reset only the latter."""
+        row = torch.from_numpy(seen)
+        self._h_obs[i] = row
+        if after_step:
+            self._h_rec[i] = row
+
+    def _upload_observations(self, after_step):
+        self.obs.copy_(self._h_obs, non_blocking=True)
+        if after_step:
+            self.record_obs.copy_(self._h_rec, non_blocking=True)
+
+    # ---- the loop's interface --------------------------------------------------------------------------------------------
     def _reset_one(self, i):
         seed = self.env_seed + self.first_env + i + 1000003 * int(self.episode[i])
-        self._h_obs[i] = torch.from_numpy(self._flat(self.envs[i].reset(seed=seed)))
+        self._store(i, self._observe(self.envs[i], self.envs[i].reset(seed=seed)), after_step=False)
         self.step_count[i] = 0
         self.done[i] = False
 
@@ -265,7 +285,7 @@ class HostVecEnv:
         for i in range(self.B):
             self._reset_one(i)
         self._h_active.fill_(1)
-        self.obs.copy_(self._h_obs, non_blocking=True)
+        self._upload_observations(after_step=False)
         if self.active is not None:
             self.active.copy_(self._h_active, non_blocking=True)
         return self.obs
@@ -280,30 +300,30 @@ class HostVecEnv:
         ev.synchronize()                                  # the search of this step has to finish before the env can move
         self.transfer_seconds += time.perf_counter() - t0
         acts = self._h_action.numpy()
-        rec, nxt, rew, flag, act_h = self._h_rec.numpy(), self._h_obs.numpy(), self._h_reward.numpy(), self._h_flag.numpy(), self._h_active.numpy()
+        rew, flag, act_h = self._h_reward.numpy(), self._h_flag.numpy(), self._h_active.numpy()
         for i, env in enumerate(self.envs):
             if not act_h[i]:
                 flag[i], rew[i] = 3, 0.0
                 continue
             try:
                 out = env.step(self.action_map[int(acts[i])])
-                obs_i, r, term = self._flat(out[0]), float(out[1]), bool(out[2])
-            except Exception:                             # illegal move (game.py:123-131)
+                seen, r, term = self._observe(env, out[0]), float(out[1]), bool(out[2])
+            except Exception:                             # illegal move (game.py:123-131): the observation stays
                 limit = self.limit if self.limit > 0 else float("inf")          # Game's default limit_of_game_play
-                obs_i, r, term = nxt[i].copy(), float(min(-int(self.step_count[i]), -limit, -1)), bool(self.done[i])
+                seen, r, term = None, float(min(-int(self.step_count[i]), -limit, -1)), bool(self.done[i])
             self.step_count[i] += 1
             f = 2 if (self.limit > 0 and self.step_count[i] == self.limit) else (1 if term else 0)
             self.done[i] = term and f != 2
-            rec[i], rew[i], flag[i] = obs_i, r, f
-            nxt[i] = obs_i
+            rew[i], flag[i] = r, f
+            if seen is not None:
+                self._store(i, seen, after_step=True)
             if f:
                 if self.on_end == "reset":
                     self.episode[i] += 1
                     self._reset_one(i)
                 else:
                     act_h[i] = 0
-        self.obs.copy_(self._h_obs, non_blocking=True)
-        self.record_obs.copy_(self._h_rec, non_blocking=True)
+        self._upload_observations(after_step=True)
         self.reward.copy_(self._h_reward, non_blocking=True)
         self.terminated.copy_(self._h_flag, non_blocking=True)
         if self.active is not None:
@@ -313,6 +333,123 @@ class HostVecEnv:
     def close(self):
         for e in self.envs:
             e.close()
+
+
+class HostImageVecEnv(HostVecEnv):
+    """HostVecEnv for environments observed through rendered RGB frames (the reference's rgb_observation games:
+    game.py:82-89, 105-107, 142-143 -- every frame through ToTensor + Resize(98, 98), one at a time on the CPU).
+
+    Per env step the B uint8 frames [H][W][3] go up through ONE pinned buffer as they are (3 bytes per pixel instead of 12)
+    and one launch of smz_frames_resize_u8 on the engine's stream turns them into the [B,3,98,98] float32 tensor the vision
+    heads read.  frame_source "render": the frame is env.render() (what the reference's Game.render shows the agent);
+    "obs": the env's observation itself is the frame.  With on_end="reset" the few envs that finished a game this step have
+    two frames -- the post-step one for the record and the reset one for the next search: the post-step ones travel in a
+    small side buffer and are resized into `record_obs` rows by a second, indexed launch."""
+    frame = (3, 98, 98)
+
+    def __init__(self, envs, frame_hw, num_actions, device, out_hw=(98, 98), frame_source="render", **kw):
+        assert frame_source in ("render", "obs")
+        self.H, self.W = int(frame_hw[0]), int(frame_hw[1])
+        self.out_h, self.out_w = int(out_hw[0]), int(out_hw[1])
+        self.frame = (3, self.out_h, self.out_w)
+        self.frame_source = frame_source
+        self.lib = _lib.load()
+        super().__init__(envs, 3 * self.out_h * self.out_w, num_actions, device, **kw)
+
+    def _alloc_observations(self, pin):
+        B, H, W = self.B, self.H, self.W
+        self._h_frames = torch.zeros(B, H, W, 3, dtype=torch.uint8, **pin)        # next search's frames
+        self._d_frames = torch.zeros(B, H, W, 3, dtype=torch.uint8, device=self.device)
+        self.obs = torch.zeros((B,) + self.frame, dtype=torch.float32, device=self.device)
+        self.record_obs = torch.zeros((B,) + self.frame, dtype=torch.float32, device=self.device) if self.on_end == "reset" else None
+        self._side_cap = 0
+        self._ended = []                                                          # (env, post-step frame) of this step
+        self.upload_bytes = 0                                                     # diagnostic: PCIe bytes of frames so far
+
+    def _observe(self, env, obs):
+        frame = env.render() if self.frame_source == "render" else (obs[0] if isinstance(obs, tuple) else obs)
+        frame = np.asarray(frame)
+        assert frame.shape == (self.H, self.W, 3), f"frame {frame.shape}, expected {(self.H, self.W, 3)}"
+        return frame.astype(np.uint8, copy=False)          # (the reference: x.copy().astype(np.uint8), game.py:84)
+
+    def _store(self, i, seen, after_step):
+        if not after_step and self._stepping:
+            # a reset inside step(): the frame in the main buffer is this env's post-step one -- the record needs it
+            self._ended.append((i, self._h_frames[i].clone()))
+        self._h_frames[i] = torch.from_numpy(np.ascontiguousarray(seen))
+
+    _stepping = False
+
+    def step(self, action):
+        self._stepping, self._ended = True, []
+        try:
+            return super().step(action)
+        finally:
+            self._stepping = False
+
+    def _resize(self, frames_dev, n, rows_dev, out):
+        P = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        _lib.check(self.lib.smz_frames_resize_u8(P(frames_dev), n, self.H, self.W, self.out_h, self.out_w, P(rows_dev), P(out),
+                                                 C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def _upload_observations(self, after_step):
+        self._d_frames.copy_(self._h_frames, non_blocking=True)
+        self.upload_bytes += self._h_frames.numel()
+        self._resize(self._d_frames, self.B, None, self.obs)
+        if not after_step or self.record_obs is None:
+            return
+        self.record_obs.copy_(self.obs)
+        n = len(self._ended)
+        if n == 0:
+            return
+        if n > self._side_cap:                         # grows to the largest number of simultaneous game ends seen
+            pin = dict(pin_memory=torch.cuda.is_available())
+            self._side_cap = max(n, 2 * self._side_cap, 8)
+            self._h_side = torch.zeros(self._side_cap, self.H, self.W, 3, dtype=torch.uint8, **pin)
+            self._h_rows = torch.zeros(self._side_cap, dtype=torch.int32, **pin)
+            self._d_side = torch.zeros(self._side_cap, self.H, self.W, 3, dtype=torch.uint8, device=self.device)
+            self._d_rows = torch.zeros(self._side_cap, dtype=torch.int32, device=self.device)
+        else:
+            torch.cuda.current_stream(self.device).synchronize()      # the side buffers of the previous use have been read
+        for k, (i, fr) in enumerate(self._ended):
+            self._h_side[k] = fr
+            self._h_rows[k] = i
+        self._d_side[:n].copy_(self._h_side[:n], non_blocking=True)
+        self._d_rows[:n].copy_(self._h_rows[:n], non_blocking=True)
+        self.upload_bytes += n * self.H * self.W * 3
+        self._resize(self._d_side, n, self._d_rows, self.record_obs)
+
+
+class HostCartPoleRender(HostCartPole):
+    """HostCartPole with a render(): an H x W x 3 uint8 picture of the cart and the pole (white background, black cart,
+    brown pole, a track line) -- a stand-in for CartPole-v1's pygame renderer (400 x 600 frames), which is not part of this
+    image.  Drawn with numpy slices: cheap enough to feed a thousand envs from Python."""
+
+    def __init__(self, frame_hw=(400, 600)):
+        super().__init__()
+        self.H, self.W = int(frame_hw[0]), int(frame_hw[1])
+        self._img = None
+
+    def render(self):
+        """The frame buffer is reused from call to call (a fresh 720 KB array costs 0.5 ms of page faults): copy it to keep it."""
+        H, W = self.H, self.W
+        if self._img is None:
+            self._img = np.empty((H, W, 3), np.uint8)
+            dy, dx = np.meshgrid([-1, 0, 1], [-1, 0, 1], indexing="ij")
+            self._dy, self._dx, self._col = dy.ravel(), dx.ravel(), np.array((202, 152, 101), np.uint8)
+        img = self._img
+        img[...] = 255
+        x, _, th, _ = (float(v) for v in self.state)
+        cy = int(H * 0.75)
+        img[cy + H // 40:cy + H // 40 + 1, :, :] = 0                                       # track
+        cx = int(np.clip((x / 4.8 + 0.5) * W, 0, W - 1))
+        cw, ch = W // 12, H // 13
+        img[max(0, cy - ch // 2):cy + ch // 2, max(0, cx - cw // 2):min(W, cx + cw // 2)] = 0
+        k = np.arange(0, H // 4, 2)                                                         # pole: a run of 3x3 dots
+        px, py = (cx + k * np.sin(th)).astype(np.int64), (cy - ch // 2 - k * np.cos(th)).astype(np.int64)
+        ok = (px >= 1) & (px < W - 1) & (py >= 1) & (py < H - 1)
+        img[(py[ok][:, None] + self._dy).ravel(), (px[ok][:, None] + self._dx).ravel()] = self._col
+        return img
 
 
 class HostCartPoleVec:

@@ -48,17 +48,26 @@ def temperature_scheduler(epoch=1, actual_epoch=1, mode="static_temperature"):
 
 
 class TrajectoryChunk:
-    """[T][B][F] float64 device buffer + the field offsets of smz_traj_pack's record."""
+    """[T][B][F] float64 device buffer + the field offsets of smz_traj_pack's record.
+
+    Image observations (obs_dim > SPLIT_OBS: a 98x98x3 frame is 28 812 floats) are NOT widened into the float64 record: they
+    are kept as float32 -- what the heads consume and what the reference's Game stores (game.py:264) -- in `obs`
+    [T][B][obs_dim], and the record carries the other fields only (`rec_obs_dim` = 0).  Vector observations stay inside the
+    record (`obs` is None, `rec_obs_dim` = obs_dim)."""
+    SPLIT_OBS = 64
 
     def __init__(self, T, B, obs_dim, A, device):
         self.T, self.B, self.obs_dim, self.A = int(T), int(B), int(obs_dim), int(A)
-        self.F = _lib.load().smz_traj_floats(self.obs_dim, self.A)
+        self.rec_obs_dim = 0 if self.obs_dim > self.SPLIT_OBS else self.obs_dim
+        self.F = _lib.load().smz_traj_floats(self.rec_obs_dim, self.A)
         self.data = torch.zeros(self.T, self.B, self.F, dtype=torch.float64, device=device)
+        self.obs = None if self.rec_obs_dim else torch.zeros(self.T, self.B, self.obs_dim, dtype=torch.float32, device=device)
 
     def fields(self, data=None):
         d = self.data if data is None else data
-        o, A = self.obs_dim, self.A
-        return dict(observation=d[..., :o], reward=d[..., o], terminated=d[..., o + 1], policy=d[..., o + 2:o + 2 + A],
+        o, A = self.rec_obs_dim, self.A
+        return dict(observation=d[..., :o] if self.obs is None else self.obs, reward=d[..., o], terminated=d[..., o + 1],
+                    policy=d[..., o + 2:o + 2 + A],
                     action_onehot=d[..., o + 2 + A:o + 2 + 2 * A], root_value=d[..., o + 2 + 2 * A],
                     child_visits=d[..., o + 3 + 2 * A:o + 3 + 3 * A])
 
@@ -95,17 +104,22 @@ def chunk_targets(chunk_data, obs_dim, A, discount, td_steps, ignore_termination
 
 
 def chunk_to_games(chunk_data, obs_dim, A, discount, priority_scale=1, limit_of_game_play=float("inf"),
-                   ignore_termination=False, keep_partial=True, after_end="drop"):
+                   ignore_termination=False, keep_partial=True, after_end="drop", observations=None, observation_shape=None):
     """[T][B][F] (host or device) -> list of GameRecord, env-major.  The record's flag slot cuts the games: 1 = terminated
     (Game.done True), 2 = stopped by limit_of_game_play (done False, game.py:270-271), 3 = no step (env switched off).
     after_end: what the rows behind an env's finished game are -- "drop": nothing (an env that is stepped on past its end,
     the fixed-length episodes of on_end="continue"), "new_game": its next game (on_end="reset": several games per env and
     chunk).  The rows behind the last finished game form an unfinished one, kept when keep_partial (a chunk without any
-    end flag is then one game per env)."""
+    end flag is then one game per env).  `observations` [T][B][n] float32 (TrajectoryChunk.obs): the observations live outside
+    the record (obs_dim is then 0), each stored as [1, *observation_shape] like the reference's frames ([1,3,98,98])."""
     assert after_end in ("drop", "new_game")
     d = chunk_data.detach().cpu().numpy() if torch.is_tensor(chunk_data) else np.asarray(chunk_data)
     T, B, F = d.shape
     o = obs_dim
+    if observations is not None:
+        assert o == 0 and F == 3 * A + 3
+        observations = observations.detach().cpu() if torch.is_tensor(observations) else torch.as_tensor(np.asarray(observations))
+        observations = observations.to(torch.float32)
     games = []
     for e in range(B):
         g = None
@@ -116,7 +130,11 @@ def chunk_to_games(chunk_data, obs_dim, A, discount, priority_scale=1, limit_of_
                 continue
             if g is None:
                 g = GameRecord(discount, A, priority_scale, limit_of_game_play)
-            g.observations.append(torch.from_numpy(r[:o].astype(np.float32))[None, ...])   # game.py:145-167 shape [1,obs]
+            if observations is None:
+                g.observations.append(torch.from_numpy(r[:o].astype(np.float32))[None, ...])   # game.py:145-167 shape [1,obs]
+            else:
+                frame = observations[t, e].clone()
+                g.observations.append(frame.reshape((1,) + tuple(observation_shape)) if observation_shape else frame[None, ...])
             g.rewards.append(float(r[o]))
             g.policies.append(r[o + 2:o + 2 + A].copy())
             g.action_history.append(r[o + 2 + A:o + 2 + 2 * A].copy())
@@ -154,9 +172,13 @@ def _play_step(env, heads, mcts, chunk, t, temperature, train=True):
         return
     obs, reward, terminated = env.step(action)
     rec_obs = getattr(env, "record_obs", None)   # post-step observation when `obs` already is the next game's reset one
+    rec_obs = obs if rec_obs is None else rec_obs
     P = lambda x: C.c_void_p(x.data_ptr())
-    _lib.check(_lib.load().smz_traj_pack(P(chunk.data), chunk.T, t, env.obs_dim, env.num_actions,
-                                         P(obs if rec_obs is None else rec_obs), P(reward), P(terminated), P(action),
+    split = getattr(chunk, "obs", None) is not None
+    if split:                                    # image observations stay float32, outside the float64 record
+        chunk.obs[t].copy_(rec_obs.reshape(env.B, -1))
+    _lib.check(_lib.load().smz_traj_pack(P(chunk.data), chunk.T, t, 0 if split else env.obs_dim, env.num_actions,
+                                         None if split else P(rec_obs), P(reward), P(terminated), P(action),
                                          P(policy), P(child_visits), P(root_value), env.B,
                                          C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)))
 
@@ -317,18 +339,21 @@ def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None
     heads = model.heads(env.device)
     env.reset()
     chunk = play_games(env, heads, mcts, temperature, steps)
-    data = chunk.data
+    data, frames = chunk.data, chunk.obs
     if gather is not None:
         parts = gather(data)
+        fparts = gather(frames) if frames is not None else None      # image observations: a float32 message of their own
         if parts is None:
             return None, None
         data = torch.cat([p for p in parts], dim=1)
+        frames = torch.cat([p for p in fparts], dim=1) if fparts is not None else None
     torch.cuda.synchronize(env.device)
     on_end = getattr(env, "on_end", "continue")
     limit = limit_of_game_play if limit_of_game_play is not None else (getattr(env, "limit", 0) or steps)
-    games = chunk_to_games(data, env.obs_dim, env.num_actions, mcts.discount, priority_scale,
+    games = chunk_to_games(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, priority_scale,
                            limit_of_game_play=limit, ignore_termination=ignore_termination,
-                           keep_partial=on_end != "reset", after_end="new_game" if on_end == "reset" else "drop")
+                           keep_partial=on_end != "reset", after_end="new_game" if on_end == "reset" else "drop",
+                           observations=frames, observation_shape=getattr(env, "frame", None))
     rewards = []
     for g in games:
         if replay_buffer is not None:

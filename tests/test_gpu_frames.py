@@ -1,0 +1,135 @@
+"""Frame ingest of the vision family (game.py:82-89, 105-107, 142-143): smz_frames_resize_u8 against torch's own
+CPU bilinear interpolate on the same uint8 frames, and envs.HostImageVecEnv -- host environments observed through rendered
+RGB frames, uploaded as uint8 through pinned memory and resized on the engine's stream -- driving the vision heads.
+
+Parity note: the reference resizes with torchvision 0.14's transforms.Resize, which for tensors is
+torch.nn.functional.interpolate(mode="bilinear", align_corners=False, antialias=False).  torchvision (and gymnasium) are not
+part of this image, so the kernel is pinned to torch's interpolate, not to torchvision itself: "unpinned vs torchvision".
+"""
+import ctypes as C
+import os
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+# float32 results in [0, 1]: one ulp is <= 1.19e-7 there.  ATen's CPU kernel may contract a * b + c * d into fused
+# multiply-adds (build dependent); the HIP kernel rounds every product and sum (-ffp-contract=off).
+ONE_ULP = 1.1920929e-07
+
+
+def _pkg(name):
+    import stochastic_muzero_amd  # noqa: F401
+    return import_module("stochastic-muzero_amd." + name)
+
+
+def _torch_resize(frames_u8, out_hw):
+    x = torch.from_numpy(frames_u8).permute(0, 3, 1, 2).to(torch.float32) / 255                 # ToTensor
+    return torch.nn.functional.interpolate(x, size=tuple(out_hw), mode="bilinear", align_corners=False)
+
+
+def _resize(frames_dev, out_hw, rows=None, out=None):
+    lib = _pkg("_lib")
+    n, H, W, _ = frames_dev.shape
+    if out is None:
+        out = torch.full((n, 3) + tuple(out_hw), -1.0, dtype=torch.float32, device="cuda")
+    P = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+    lib.check(lib.load().smz_frames_resize_u8(P(frames_dev), n, H, W, out_hw[0], out_hw[1], P(rows), P(out),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
+
+
+@pytest.mark.parametrize("n,H,W,out_hw", [(5, 400, 600, (98, 98)),       # CartPole-v1's rendered frames (game.py:142-143)
+                                          (3, 210, 160, (98, 98)),       # Atari-shaped
+                                          (4, 97, 133, (98, 98)),        # odd row length (rows start at any byte offset), up-scaling in y
+                                          (2, 98, 98, (98, 98)),         # identity size
+                                          (2, 33, 47, (96, 24)),         # up in y, down in x, non-square output
+                                          (1, 1, 1, (7, 5))])            # a single pixel
+def test_resize_kernel_equals_torch_cpu_bilinear(n, H, W, out_hw):
+    g = np.random.RandomState(H * 1000 + W)
+    frames = g.randint(0, 256, size=(n, H, W, 3)).astype(np.uint8)
+    frames[0, :, : W // 2] = 255                                         # flat areas and an edge
+    want = _torch_resize(frames, out_hw).numpy()
+    got = _resize(torch.from_numpy(frames).cuda(), out_hw)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    print(f"[{H}x{W} -> {out_hw}] max |hip - torch cpu| = {err.max():.3e} ({err.max() / ONE_ULP:.2f} ulp at 1.0); "
+          f"bit-identical {100.0 * (got == want).mean():.2f} %")
+    assert got.min() >= 0.0 and got.max() <= 1.0
+    assert err.max() <= ONE_ULP
+    if (H, W) == tuple(out_hw):
+        assert np.array_equal(got, want)                                 # identity size: every weight is 0 or 1
+
+
+def test_resize_into_selected_rows_of_a_batch():
+    """rows_dev: frame i -> output row rows[i]; the other rows stay untouched (how the post-step frames of the few envs that
+    ended a game are patched into the record's batch)."""
+    g = np.random.RandomState(0)
+    frames = g.randint(0, 256, size=(3, 120, 90, 3)).astype(np.uint8)
+    out = torch.full((8, 3, 98, 98), 7.0, dtype=torch.float32, device="cuda")
+    rows = torch.tensor([6, 0, 3], dtype=torch.int32, device="cuda")
+    _resize(torch.from_numpy(frames).cuda(), (98, 98), rows=rows, out=out)
+    dense = _resize(torch.from_numpy(frames).cuda(), (98, 98))
+    torch.cuda.synchronize()
+    for i, r in enumerate((6, 0, 3)):
+        assert torch.equal(out[r], dense[i])
+    assert all(bool((out[r] == 7.0).all()) for r in (1, 2, 4, 5, 7))
+    lib = _pkg("_lib")
+    with pytest.raises(lib.SmzError):
+        lib.check(lib.load().smz_frames_resize_u8(None, 1, 4, 4, 2, 2, None, C.c_void_p(out.data_ptr()), None))
+
+
+@pytest.mark.parametrize("on_end", ["reset", "mask"])
+def test_host_envs_observed_through_rendered_frames_drive_the_vision_heads(on_end):
+    """envs.HostImageVecEnv over host CartPoles with a renderer: every recorded observation is the resize of the frame the env
+    showed AFTER the recorded action (a pure host replay of the recorded actions reproduces all of them), the search of the
+    next step sees the reset frame when a game ended, and the float32 frames are stored outside the float64 record."""
+    envs_mod, sp, mcts_mod, model_mod = (_pkg(m) for m in ("envs", "selfplay", "mcts", "model"))
+    B, T, sims, limit, hw = 12, 7, 6, 3, (80, 120)
+    model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L1_seed0.npz"))
+    heads = model.heads("cuda:0")
+    env = envs_mod.HostImageVecEnv([envs_mod.HostCartPoleRender(hw) for _ in range(B)], hw, 2, "cuda:0", env_seed=11,
+                                   limit=limit, on_end=on_end, first_env=5)
+    env.reset()
+    first = env.obs.cpu().numpy().copy()
+    m = mcts_mod.BatchedMCTS(B, num_simulations=sims, discount=0.999, root_exploration_fraction=0.1, use_graph=False)
+    m.seed(np.arange(B, dtype=np.uint64))
+    chunk = sp.play_games(env, heads, m, 1.0, T)
+    torch.cuda.synchronize()
+    assert chunk.obs is not None and chunk.rec_obs_dim == 0 and tuple(chunk.obs.shape) == (T, B, 3 * 98 * 98)
+    assert tuple(chunk.data.shape) == (T, B, 9) and chunk.obs.dtype == torch.float32
+    data, frames = chunk.data.cpu().numpy(), chunk.obs.cpu().numpy().reshape(T, B, 3, 98, 98)
+    flags, actions = data[..., 1], data[..., 4:6].argmax(-1)
+    n_checked = n_ends = 0
+    for e in range(B):
+        twin, episode = envs_mod.HostCartPoleRender(hw), 0
+        twin.reset(seed=11 + 5 + e)
+        assert np.abs(first[e] - _torch_resize(twin.render()[None].copy(), (98, 98)).numpy()[0]).max() <= ONE_ULP
+        for t in range(T):
+            if flags[t, e] == 3:                       # switched off: no step, the row's frame means nothing
+                assert on_end == "mask"
+                continue
+            twin.step(int(actions[t, e]))
+            want = _torch_resize(twin.render()[None].copy(), (98, 98)).numpy()[0]
+            assert np.abs(frames[t, e] - want).max() <= ONE_ULP, (e, t)
+            n_checked += 1
+            if flags[t, e] != 0:
+                n_ends += 1
+                if on_end == "reset":
+                    episode += 1
+                    twin.reset(seed=11 + 5 + e + 1000003 * episode)
+        if on_end == "reset":          # what the NEXT search would see: the twin's current frame (a reset frame if a game just ended)
+            want = _torch_resize(twin.render()[None].copy(), (98, 98)).numpy()[0]
+            assert np.abs(env.obs[e].cpu().numpy() - want).max() <= ONE_ULP
+    assert n_ends >= B and n_checked >= (B * limit if on_end == "mask" else B * T)
+    games = sp.chunk_to_games(chunk.data, 0, 2, 0.999, limit_of_game_play=limit, observations=chunk.obs,
+                              observation_shape=(3, 98, 98), after_end="new_game" if on_end == "reset" else "drop",
+                              keep_partial=False)
+    assert len(games) == n_ends and all(tuple(g.observations[0].shape) == (1, 3, 98, 98) for g in games)
+    assert env.upload_bytes >= (T + 1) * B * hw[0] * hw[1] * 3

@@ -121,7 +121,7 @@ def test_finished_games_stop_consuming_simulations(single_launch):
 class _OneRow:
     """A view of a TrajectoryChunk that makes play_games(…, steps=1) write row t."""
     def __init__(self, chunk, t):
-        self.T, self.B, self.data = 1, chunk.B, chunk.data[t:t + 1]
+        self.T, self.B, self.data, self.obs = 1, chunk.B, chunk.data[t:t + 1], None
 
 
 def test_restarting_envs_play_game_after_game_inside_a_chunk():
