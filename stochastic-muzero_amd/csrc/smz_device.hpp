@@ -709,7 +709,8 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, Tr
             nb4[0] = make_uint4(0u, 0u, 0u, 0u);                                              // visit, value_sum
             nb4[1] = make_uint4(0u, 0u, __float_as_uint(pj[0]), __float_as_uint(pj[1]));      // reward, prior
             nb4[2] = make_uint4(0u, 0u, (uint32_t)picks[0], (uint32_t)picks[1]);              // child, action
-            nb4[3] = make_uint4(0u, 0u, 0u, 0u);                                              // (padding: the block leaves as one whole 64-byte line)
+            if (P.eb_words >= 16) nb4[3] = make_uint4(0u, 0u, 0u, 0u);                        // (padding: the block leaves as one whole 64-byte line;
+                                                                                              //  LDS-resident trees pack blocks at 12 words)
         } else {
             for (int j = 0; j < K; j++) {
                 nb[2 * j] = 0u;                              // visit

@@ -8,8 +8,10 @@
 //
 // Arithmetic = ATen's upsample_bilinear2d (align_corners = False, no antialias: what torchvision 0.14's Resize calls for
 // tensors), float32 throughout:
-//   scale = in / out;  src = scale * (dst + 0.5) - 0.5, clamped at 0;  i0 = min(int(src), in - 1);  i1 = min(i0 + 1, in - 1);
-//   l1 = clamp(src - i0, 0, 1), l0 = 1 - l1;  out = l0y * (l0x * v00 + l1x * v01) + l1y * (l0x * v10 + l1x * v11),
+//   scale = in / out;  src = fma(scale, dst + 0.5, -0.5), clamped at 0;  i0 = min(int(src), in - 1);  i1 = min(i0 + 1, in - 1);
+//   l1 = clamp(src - i0, 0, 1), l0 = 1 - l1;  row_y = fma(v_y0, l0x, v_y1 * l1x);  out = fma(row_0, l0y, row_1 * l1y)
+//   (UpSampleKernel.cpp's Interpolate<n>::eval: `out = t0 * w0; out += t1 * w1`; which product is fused is ATen's compiler's
+//   choice -- this is the form torch 2.10 (AVX-512 CPU dispatch) computes for 98-wide outputs; any other choice is within 1 ulp),
 //   v = uint8 / 255 (IEEE division, a 256-entry table in LDS).
 // torchvision / gymnasium are not part of this build, so parity is unpinned against torchvision itself; the test holds the
 // kernel to torch's own CPU interpolate on the same frames (tests/test_gpu_frames.py).
@@ -32,7 +34,7 @@ namespace {
 extern __shared__ uint32_t smz_frames_lds[];
 
 __device__ inline void src_index(int dst, float scale, int in, int &i0, int &i1, float &l0, float &l1) {
-    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    float src = fmaf(scale, (float)dst + 0.5f, -0.5f);     // (ATen's build contracts scale * (dst + 0.5) - 0.5 into one fma)
     if (src < 0.f) src = 0.f;
     i0 = min((int)src, in - 1);
     i1 = min(i0 + 1, in - 1);
@@ -76,8 +78,11 @@ __global__ void __launch_bounds__(128) k_frames_resize_u8(const uint8_t *frames,
         for (int c = 0; c < 3; c++) {
             const float v00 = lut[b0[x0 * 3 + c]], v01 = lut[b0[x1 * 3 + c]];
             const float v10 = lut[b1[x0 * 3 + c]], v11 = lut[b1[x1 * 3 + c]];
-            const float top = lx0 * v00 + lx1 * v01, bot = lx0 * v10 + lx1 * v11;
-            dst[(size_t)c * OH * OW + ox] = ly0 * top + ly1 * bot;
+            // ATen's generic linear kernel: `out = t0 * w0; out += t1 * w1` per dimension, x inside y.  Its optimised build fuses
+            // one product of each line into an fma and leaves the association to the compiler; the form below is what
+            // torch 2.10's CPU kernel (AVX-512 dispatch) produces for 98-pixel-wide outputs, bit for bit (tests/test_gpu_frames.py)
+            const float top = fmaf(v00, lx0, v01 * lx1), bot = fmaf(v10, lx0, v11 * lx1);
+            dst[(size_t)c * OH * OW + ox] = fmaf(top, ly0, bot * ly1);
         }
     }
 }

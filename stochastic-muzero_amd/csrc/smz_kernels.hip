@@ -13,6 +13,9 @@
 // kernel for the action buckets 2 and 4 with smz_search_mlp(_act), 4 = the search kernel for the buckets 8-32,
 // 3 = only smz_expand_backup_select, 5 = nothing but the shared helpers and the handle (included by smz_vision_search.hip)
 // -- the template instantiations behind those are most of the compile time, and the parts build in parallel.
+#ifndef SMZ_SEARCH_THREADS
+#define SMZ_SEARCH_THREADS 512   // threads per workgroup the single-launch search is register-allocated for (8 waves: 2 per SIMD, 256 VGPRs)
+#endif
 #ifndef SMZ_EB_WAVES
 #define SMZ_EB_WAVES 4   // waves per SIMD the step-wise tree kernels are register-allocated for
 #endif
@@ -634,17 +637,21 @@ extern __shared__ float4 smz_search_lds4[];
 struct MegaLds {
     int pbc_off, wave_off, per_wave;                       // float offsets from the LDS base
     int x_off, pv_off, rng_off, out_off;                   // float offsets inside a wave's region
+    int trees_off, tree_words;                             // TLDS: the workgroup's trees (words per tree, blocks packed at 6 K words)
 };
 __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
-__host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params &P, int tpw) {
+// tlds: the instantiation that keeps the workgroup's trees in LDS for the search (and the weights in the compact image)
+__host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params &P, int tpw, bool tlds = false, int waves = 8) {
     MegaLds m;
-    m.pbc_off = r4(d.total_floats - smz_mlp::rep_floats(d));
+    m.pbc_off = r4(tlds ? smz_mlp::compact_total_floats(d) : d.total_floats - smz_mlp::rep_floats(d));
     m.wave_off = m.pbc_off + r4(2 * 2 * (P.sims + 2));     // pb_c table + reciprocal table (div_by_count)
     m.x_off = r4(2 * smz_mlp::row_scratch_floats(d));     // two rows' scratch: a same-branch pair is evaluated together
     m.pv_off = m.x_off + tpw * smz_mlp::up4(P.S + P.A);
     m.rng_off = m.pv_off + tpw * P.P * 4;
     m.out_off = m.rng_off + r4(tpw * kRngStride);
     m.per_wave = m.out_off + r4(tpw * (P.A + 2));
+    m.tree_words = P.rb_words + P.sims * 6 * P.K;
+    m.trees_off = m.wave_off + waves * m.per_wave;
     return m;
 }
 
@@ -669,8 +676,12 @@ constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
 // that is recomputed where needed; with one it is state that stays live through the search loop -- in the specialised
 // instantiation that costs scalar registers it does not have (35 -> 45 spilled, -3 % measured), so it exists both ways.
 // PHX: the specialised instantiation for SMZ_RNG_PHILOX handles (counter streams: no state words to load or store).
-template <int MAXA, int KS, int U, bool INSTR, bool AEX, bool MSK = true, bool PHX = false>
-__global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
+// TLDS (specialised instantiation, when it fits: ~60 simulations at 2 actions): the workgroup's 16 trees live in LDS for the
+// search -- a descent level is an LDS round trip instead of an L2 one, the backup's stores stay on the CU -- and go to their
+// place in global memory once, at the end.  LDS room comes from the compact weight image (smz_mlp::mat_op) and from packing
+// expansion blocks at 6 K words instead of 64-byte granules.
+template <int MAXA, int KS, int U, bool INSTR, bool AEX, bool MSK = true, bool PHX = false, bool TLDS = false>
+__global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train, ActOut act, EnvStep env) {
     Params P = Pin;
     P.tree0 = 0;
@@ -680,11 +691,24 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
     fix_layout(P, AEX, KS > 0);
     if (AEX) P.hs = (kFastS + 15) & ~15;
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
-    const smz_mlp_desc dl = smz_mlp::lds_desc_without_rep(d);      // LDS copy: everything but the representation matrices
-    smz_mlp::stage_weights_without_rep(lds, weights, d);
+    static_assert(!TLDS || (AEX && KS > 0 && !MSK), "LDS-resident trees: the specialised unmasked instantiations only");
+    // LDS copy: everything but the representation matrices (TLDS: in the compact image)
+    const smz_mlp_desc dl = TLDS ? smz_mlp::lds_desc_compact(d) : smz_mlp::lds_desc_without_rep(d);
+    if (TLDS) smz_mlp::stage_weights_compact(lds, weights, d);
+    else smz_mlp::stage_weights_without_rep(lds, weights, d);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, waves = blockDim.x / kWave;
     const int A = P.A, S = P.S, tpw = P.tpw;
-    const MegaLds ml = mega_lds(d, P, tpw);
+    const MegaLds ml = mega_lds(d, P, tpw, TLDS, waves);
+    uint32_t *const nodes_global = P.nodes;
+    const int gl_eb_words = P.eb_words;
+    if (TLDS) {       // (compile-time block geometry: every tree access below becomes a ds_* instruction)
+        uint32_t *nodes_lds = reinterpret_cast<uint32_t *>(lds + ml.trees_off);
+        for (int i = threadIdx.x; i < waves * tpw * ml.tree_words; i += blockDim.x) nodes_lds[i] = 0u;
+        P.nodes = nodes_lds;
+        P.tree0 = blockIdx.x * waves * tpw;
+        P.eb_words = 6 * KS;
+        P.tree_words = ml.tree_words;
+    }
     double *pbc_lds = reinterpret_cast<double *>(lds + ml.pbc_off);
     const int n_pbc = P.sims + 2;
     for (int i = threadIdx.x; i < n_pbc; i += blockDim.x) {
@@ -716,8 +740,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         const int row = tree0 + t;
         if (row >= P.B) break;                                   // wave-uniform
         if (MSK && !__shfl((int)valid, t)) continue;             // wave-uniform: the tree is switched off
-        smz_mlp::initial_row<U>(lds, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * P.hs,
-                                nullptr, outs + t * slot);
+        smz_mlp::initial_row<U, TLDS>(lds, dl, weights, d, scratch, obs + (size_t)row * d.obs, P.hidden + (size_t)row * P.N * P.hs,
+                                      nullptr, outs + t * slot);
     }
     constexpr bool PHC = !AEX || PHX;   // the specialised instantiations are compiled for one word source each
     int packed = wave_stage_rng<PHC>(P, tree, valid, rng_tile);
@@ -845,8 +869,8 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
                 for (int r = 0; r < 2; r++)
                     dh[r] = P.hidden + ((size_t)(tree0 + r) * P.N + __builtin_amdgcn_readlane(L.leaf_id, r)) * P.hs;
                 const bool live[2] = {MSK ? (vmask & 1) != 0 : true, MSK ? (vmask & 2) != 0 : true};
-                if (b0 == b1) smz_mlp::recurrent_rows<U, 2, true>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
-                else smz_mlp::recurrent_rows<U, 2, false>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
+                if (b0 == b1) smz_mlp::recurrent_rows<U, 2, true, TLDS>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
+                else smz_mlp::recurrent_rows<U, 2, false, TLDS>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
                 if (lane == 0) {
                     outs[A] = value[0]; outs[A + 1] = reward[0];
                     outs[slot + A] = value[1]; outs[slot + A + 1] = reward[1];
@@ -873,7 +897,7 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
                 dh[r] = P.hidden + ((size_t)row * P.N + leaf) * P.hs;
                 dp[r] = outs + tt * slot;
             }
-            if (!(dbg & 1)) smz_mlp::recurrent_rows<U, R>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
+            if (!(dbg & 1)) smz_mlp::recurrent_rows<U, R, false, TLDS>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
 #pragma unroll
             for (int r = 0; r < R; r++)
                 if (live[r] && lane == 0) { outs[(t + r) * slot + A] = value[r]; outs[(t + r) * slot + A + 1] = reward[r]; }
@@ -908,6 +932,22 @@ __global__ void __launch_bounds__(512) k_search_mlp(Params Pin, smz_mlp_desc d, 
         }
         P.rng_pos[tree] = packed;
         rng.save(P, tree);
+    }
+    if constexpr (TLDS) {
+        // the wave's finished trees back to their place in global memory (64-byte granules there: words 12..15 of a block are
+        // padding).  Each wave moves its own trees: no other wave has touched them.
+        smz_mlp::lds_sync();
+        const int n_blk = 1 + P.sims;                                    // root block + one expansion block per simulation
+        for (int t = 0; t < tpw; t++) {
+            if (tree0 + t >= P.B) break;
+            const uint32_t *src = P.nodes + (size_t)(wave * tpw + t) * P.tree_words;
+            uint32_t *dst = nodes_global + (size_t)(tree0 + t) * (P.rb_words + (size_t)P.sims * gl_eb_words);
+            for (int i = lane; i < P.rb_words; i += kWave) dst[i] = src[i];
+            for (int i = lane; i < (n_blk - 1) * gl_eb_words; i += kWave) {
+                const int b = i / gl_eb_words, w = i - b * gl_eb_words;
+                dst[P.rb_words + i] = w < P.eb_words ? src[P.rb_words + b * P.eb_words + w] : 0u;
+            }
+        }
     }
     // smz_search_mlp_act_cartpole: the env step + trajectory record of this tree's env in the same lane (it reads back
     // the action / policy / child_visits / root value it has just written); a switched-off tree of a live wave gets its
@@ -1699,7 +1739,7 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     }
 #endif
     int kWaves = 8;
-    if (const char *e = getenv("SMZ_SEARCH_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) kWaves = v; }
+    if (const char *e = getenv("SMZ_SEARCH_WAVES")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4 || v == 8 || v == 12 || v == 16) && v * kWave <= SMZ_SEARCH_THREADS) kWaves = v; }
     Params P = h->P;
     if (act.action && pow_table_host && act.temperature >= 0.3) {       // as smz_act: the power table of this temperature
         if (!h->pow_valid || h->pow_T != act.temperature) {
@@ -1734,7 +1774,7 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
         }                                                                                                              \
         hipLaunchKernelGGL((k_search_mlp<MA, KS, UU, INSTR, AEX, MSK, PHX>), dim3(blocks), dim3(kWaves * kWave), lds,  \
                            (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act, a.env);                    \
-        snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<%d, %d, %d, %s, %s, %s, %s>", MA, KS, UU,       \
+        snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<%d, %d, %d, %s, %s, %s, %s, false>", MA, KS, UU, \
                  INSTR ? "true" : "false", AEX ? "true" : "false", MSK ? "true" : "false", PHX ? "true" : "false");     \
     })
     // smz_mlp_layout only accepts OP == 64 (one output neuron per lane): U = 1.  The instrumented instantiation runs
@@ -1742,12 +1782,43 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     // (the specialised instantiation is the parity-mode path: a Philox handle runs the generic one)
     const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL;
 #if SMZ_PART != 4
+    {   // LDS-resident trees (k_search_mlp<..., TLDS>): the specialised, unmasked, MT19937 instantiation when the workgroup's
+        // trees fit next to the compact weight image (checkpoint-421 shape, 2 actions: up to 73 simulations); SMZ_SEARCH_TLDS=0
+        // keeps the trees in global memory (A/B runs)
+        const MegaLds mt = mega_lds(*desc, P, tpw, true, kWaves);
+        const size_t lds_t = ((size_t)mt.trees_off + (size_t)kWaves * tpw * mt.tree_words) * sizeof(float);
+        const char *te = getenv("SMZ_SEARCH_TLDS");
+        const bool tlds = fast && !P.active && !P.philox && !(P.stats || P.dbg) && h->K == 2 && h->maxa <= 4 &&
+                          lds_t <= 160 * 1024 && !(te && atoi(te) == 0);
+        if (tlds) {
+#define SMZ_LAUNCH_TLDS(MA)                                                                                            \
+            {                                                                                                          \
+                static size_t granted_dev[64] = {};                                                                    \
+                size_t &granted = granted_dev[h->cfg.device & 63];                                                     \
+                if (lds_t > granted) {                                                                                 \
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, 2, 1, false, true, false, false, true>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t) != hipSuccess)     \
+                        return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                    \
+                    granted = lds_t;                                                                                   \
+                }                                                                                                      \
+                hipLaunchKernelGGL((k_search_mlp<MA, 2, 1, false, true, false, false, true>), dim3(blocks),            \
+                                   dim3(kWaves * kWave), lds_t, (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, \
+                                   act, a.env);                                                                        \
+                snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<%d, 2, 1, false, true, false, false, true>", MA); \
+            }
+            if (h->maxa == 2) SMZ_LAUNCH_TLDS(2) else SMZ_LAUNCH_TLDS(4)
+#undef SMZ_LAUNCH_TLDS
+            h->root_ready = true;
+            h->selected = false;
+            return launch_check();
+        }
+    }
     if ((P.stats || P.dbg) && fast && !P.philox && (P.dbg & 32) && h->maxa == 2 && h->K == 2) {
         // phase stamps of the specialised instantiation itself (SMZ_DEBUG_SKIP=48), for the headline geometry only
         constexpr int MA = 2, KS = 2;
         hipLaunchKernelGGL((k_search_mlp<MA, KS, 1, true, true>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream,
                            P, *desc, weights_dev, obs_dev, train, act, a.env);
-        snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<2, 2, 1, true, true, true, false>");
+        snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<2, 2, 1, true, true, true, false, false>");
     } else
 #endif
     if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false, true, false); }

@@ -30,9 +30,11 @@ __device__ inline v2f pk_fma(float wx, float wy, float ax, float ay, v2f c) {
     return __builtin_elementwise_fma(w, a, c);
 }
 // SAME: every row uses row 0's matrix -- the weights are read from LDS once and applied to all R activation vectors
+// OP[r]: floats / 4 between consecutive 4-input groups of row r's matrix = its row width (64 in the packed buffer; the
+// compact LDS image of the search kernel stores narrow output layers narrower: see mat_op)
 template <int U, int R, bool SAME = false>
 __device__ inline void dense(const float *const (&W)[R], const float *const (&bias)[R], const float *const (&act)[R], int K4,
-                             int OP, int lane, float (&acc)[R][U]) {
+                             const int (&OP)[R], int lane, float (&acc)[R][U]) {
     const float4 *a4[R], *w4[R];
     v2f acc2[R][U];
 #pragma unroll
@@ -52,7 +54,7 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
             for (int j = 0; j < 4; j++) {
                 a[r][j] = a4[r][q + j];
 #pragma unroll
-                for (int u = 0; u < U; u++) w[r][u][j] = (SAME && r > 0) ? w[0][u][j] : w4[r][(size_t)(q + j) * OP + kWave * u];
+                for (int u = 0; u < U; u++) w[r][u][j] = (SAME && r > 0) ? w[0][u][j] : w4[r][(size_t)(q + j) * OP[r] + kWave * u];
             }
         }
 #pragma unroll
@@ -75,7 +77,7 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
             const float4 av = a4[r][q];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const float4 wv = w4[SAME ? 0 : r][(size_t)q * OP + kWave * u];
+                const float4 wv = w4[SAME ? 0 : r][(size_t)q * OP[SAME ? 0 : r] + kWave * u];
                 v2f t = acc2[r][u];
                 t = pk_fma(wv.x, wv.y, av.x, av.y, t);
                 t = pk_fma(wv.z, wv.w, av.z, av.w, t);
@@ -87,6 +89,15 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int u = 0; u < U; u++) acc[r][u] = acc2[r][u].x + acc2[r][u].y;
+}
+
+template <int U, int R, bool SAME = false>
+__device__ inline void dense(const float *const (&W)[R], const float *const (&bias)[R], const float *const (&act)[R], int K4,
+                             int OP, int lane, float (&acc)[R][U]) {
+    int op[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) op[r] = OP;
+    dense<U, R, SAME>(W, bias, act, K4, op, lane, acc);
 }
 
 // exp for the heads: the hardware exponential (v_exp_f32 on x log2 e, ~1 ulp) -- the network outputs are held to the
@@ -319,25 +330,38 @@ __device__ inline float decode_scale_lanes(const float (&v)[U], int S, int lane,
 // memory and turns every layer's set-up into a global-memory round trip (measured: the dominant stall of a leaf
 // evaluation).  pick() selects between two constant-index entries instead.
 struct MatOff {
-    int w, b;
+    int w, b, op;
 };
+// CP ("compact", the LDS image of the single-launch search kernel when it also keeps its trees in LDS): a matrix is stored only
+// as wide as its outputs need, rounded up to 4 -- the afterstate-dynamics output layer 32 instead of 64, the two prediction
+// output layers 36 (A + S = 33 or 35 outputs) -- which frees 22 KB of the 100 KB the 64-wide image takes.  A lane beyond a
+// matrix's width reads the next group's weights and computes a value nobody uses (the tails mask by output index).
+template <bool CP = false>
+__device__ __host__ inline int mat_op(const smz_mlp_desc &d, int m) {
+    if (!CP) return d.OP;
+    const int o = (m == M_ADY_OUT) ? up4(d.S) : ((m == M_PRE_OUT || m == M_APR_OUT) ? up4(d.A + d.S) : ((m == M_DYN_OUT) ? up4(2 * d.S) : up4(d.H)));
+    return o < d.OP ? o : d.OP;
+}
 // Offset of matrix m computed from the dimensions (the formula smz_mlp_layout fills off[] with: matrices in enum order,
 // up4(K_m) * OP floats each), so that the search loop keeps S, A, H, L, OP and one bias base live instead of thirty
 // table entries (the kernel is short of scalar registers: spilled SGPRs cost a v_readlane each time they are needed).
 // m is a compile-time constant at every call site, so the sum folds to a few scalar operations.
-__device__ inline int mat_off(const smz_mlp_desc &d, int m) {
+template <bool CP = false>
+__device__ __host__ inline int mat_off(const smz_mlp_desc &d, int m) {
     const int kin = up4(d.S + d.A), kmid = d.L > 0 ? up4(d.H) : 0, kh = up4(d.H), ks = up4(d.S), ko = up4(d.obs);
     const int K[M_COUNT] = {kin, kin, kmid, kmid, kh, kh, ks, ks, kmid, kmid, kh, kh, ko, kmid, kh};
-    int rows = 0;
+    int floats = 0;
 #pragma unroll
-    for (int j = 0; j < M_COUNT; j++) rows += j < m ? K[j] : 0;
-    return rows * d.OP;
+    for (int j = 0; j < M_COUNT; j++) floats += j < m ? K[j] * mat_op<CP>(d, j) : 0;
+    return floats;
 }
+template <bool CP = false>
 __device__ inline MatOff pick(const smz_mlp_desc &d, bool first, int ma, int mb) {   // ma, mb: constants at every call site
     MatOff o;
     const int bias0 = d.off[M_COUNT];            // (moved down in the LDS copy that leaves the representation out)
-    o.w = first ? mat_off(d, ma) : mat_off(d, mb);
+    o.w = first ? mat_off<CP>(d, ma) : mat_off<CP>(d, mb);
     o.b = bias0 + (first ? ma : mb) * d.OP;
+    o.op = first ? mat_op<CP>(d, ma) : mat_op<CP>(d, mb);
     return o;
 }
 
@@ -348,9 +372,10 @@ __device__ inline void trunk(const float *lds, const smz_mlp_desc &d, const MatO
                              const float *const (&act_in)[R], int K4in, float *const (&tA)[R], int lane) {
     float acc[R][U];
     const float *W[R], *Bv[R];
+    int op[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) { W[r] = lds + o_in[r].w; Bv[r] = lds + o_in[r].b; }
-    dense<U, R, SAME>(W, Bv, act_in, K4in, d.OP, lane, acc);
+    for (int r = 0; r < R; r++) { W[r] = lds + o_in[r].w; Bv[r] = lds + o_in[r].b; op[r] = o_in[r].op; }
+    dense<U, R, SAME>(W, Bv, act_in, K4in, op, lane, acc);
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
@@ -358,9 +383,10 @@ __device__ inline void trunk(const float *lds, const smz_mlp_desc &d, const MatO
     lds_sync();
     for (int l = 0; l < d.L; l++) {
         const float *Wm[R], *Bm[R], *Am[R];
+        int opm[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) { Wm[r] = lds + o_mid[r].w; Bm[r] = lds + o_mid[r].b; Am[r] = tA[r]; }
-        dense<U, R, SAME>(Wm, Bm, Am, up4(d.H), d.OP, lane, acc);
+        for (int r = 0; r < R; r++) { Wm[r] = lds + o_mid[r].w; Bm[r] = lds + o_mid[r].b; Am[r] = tA[r]; opm[r] = o_mid[r].op; }
+        dense<U, R, SAME>(Wm, Bm, Am, up4(d.H), opm, lane, acc);
         lds_sync();   // every lane has issued its reads of tA (LDS is in order per wave) before it is overwritten
 #pragma unroll
         for (int r = 0; r < R; r++)
@@ -407,7 +433,7 @@ __host__ __device__ inline int scratch_floats(const smz_mlp_desc &d) { return kR
 // [hidden | one-hot], K4in floats, zero padded, in LDS.  dyn[r]: the row's branch.  live[r] = false suppresses the
 // row's global stores (odd tail).  Writes hidden' to dst_hidden[r] (S floats), the policy to dst_policy[r]; reward and
 // value are returned in every lane.
-template <int U, int R, bool SAME = false>
+template <int U, int R, bool SAME = false, bool CP = false>
 __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, float *scratch, const float *const (&xin)[R],
                                       const bool (&dyn)[R], const bool (&live)[R], float *const (&dst_hidden)[R],
                                       float *const (&dst_policy)[R], float (&reward)[R], float (&value)[R]) {
@@ -420,20 +446,21 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
     for (int r = 0; r < R; r++) {
         tA[r] = scratch + r * rs + kin;
         hbuf[r] = tA[r] + K4h;
-        m1[r] = pick(d, dyn[r], M_DYN_IN, M_ADY_IN);   m1m[r] = pick(d, dyn[r], M_DYN_MID, M_ADY_MID);
-        m3[r] = pick(d, dyn[r], M_PRE_IN, M_APR_IN);   m3m[r] = pick(d, dyn[r], M_PRE_MID, M_APR_MID);
+        m1[r] = pick<CP>(d, dyn[r], M_DYN_IN, M_ADY_IN);   m1m[r] = pick<CP>(d, dyn[r], M_DYN_MID, M_ADY_MID);
+        m3[r] = pick<CP>(d, dyn[r], M_PRE_IN, M_APR_IN);   m3m[r] = pick<CP>(d, dyn[r], M_PRE_MID, M_APR_MID);
         for (int k = lane; k < K4s; k += kWave) hbuf[r][k] = 0.f;
     }
     trunk<U, R, SAME>(lds, d, m1, m1m, xin, K4in, tA, lane);
     float acc[R][U];
     {
         const float *W[R], *Bv[R], *Ac[R];
+        int op[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const MatOff m = pick(d, dyn[r], M_DYN_OUT, M_ADY_OUT);
-            W[r] = lds + m.w; Bv[r] = lds + m.b; Ac[r] = tA[r];
+            const MatOff m = pick<CP>(d, dyn[r], M_DYN_OUT, M_ADY_OUT);
+            W[r] = lds + m.w; Bv[r] = lds + m.b; Ac[r] = tA[r]; op[r] = m.op;
         }
-        dense<U, R, SAME>(W, Bv, Ac, K4h, d.OP, lane, acc);
+        dense<U, R, SAME>(W, Bv, Ac, K4h, op, lane, acc);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -451,12 +478,13 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         for (int r = 0; r < R; r++) Hc[r] = hbuf[r];
         trunk<U, R, SAME>(lds, d, m3, m3m, Hc, K4s, tA, lane);
         const float *W[R], *Bv[R], *Ac[R];
+        int op[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const MatOff m = pick(d, dyn[r], M_PRE_OUT, M_APR_OUT);
-            W[r] = lds + m.w; Bv[r] = lds + m.b; Ac[r] = tA[r];
+            const MatOff m = pick<CP>(d, dyn[r], M_PRE_OUT, M_APR_OUT);
+            W[r] = lds + m.w; Bv[r] = lds + m.b; Ac[r] = tA[r]; op[r] = m.op;
         }
-        dense<U, R, SAME>(W, Bv, Ac, K4h, d.OP, lane, acc);
+        dense<U, R, SAME>(W, Bv, Ac, K4h, op, lane, acc);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -468,7 +496,7 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
 // representation + root prediction for one observation row by one wavefront (muzero_model.py:802-841)
 // `rep`/`drep`: where the representation matrices live (LDS, or the packed buffer in global memory: they are used once
 // per search, so the whole-search kernel does not spend LDS on them); `lds`/`d`: the prediction matrices.
-template <int U>
+template <int U, bool CP = false>
 __device__ inline void initial_row(const float *lds, const smz_mlp_desc &d, const float *rep, const smz_mlp_desc &drep,
                                    float *scratch, const float *obs_row, float *dst_hidden0, float *dst_hidden1,
                                    float *dst_policy) {
@@ -491,12 +519,13 @@ __device__ inline void initial_row(const float *lds, const smz_mlp_desc &d, cons
     }
     scale_lanes<U>(acc[0], 0, S, lane, hbuf, dst_hidden0, dst_hidden1);
     lds_sync();
-    const MatOff pi[1] = {pick(d, true, M_PRE_IN, M_PRE_IN)}, pm[1] = {pick(d, true, M_PRE_MID, M_PRE_MID)};
+    const MatOff pi[1] = {pick<CP>(d, true, M_PRE_IN, M_PRE_IN)}, pm[1] = {pick<CP>(d, true, M_PRE_MID, M_PRE_MID)};
     const float *hi[1] = {hbuf};
     trunk<U, 1>(lds, d, pi, pm, hi, K4s, tA, lane);
     {
-        const float *W[1] = {lds + d.off[M_PRE_OUT]}, *Bv[1] = {lds + d.off[M_COUNT + M_PRE_OUT]}, *Ac[1] = {tA[0]};
-        dense<U, 1>(W, Bv, Ac, K4h, d.OP, lane, acc);
+        const MatOff po = pick<CP>(d, true, M_PRE_OUT, M_PRE_OUT);
+        const float *W[1] = {lds + po.w}, *Bv[1] = {lds + po.b}, *Ac[1] = {tA[0]};
+        dense<U, 1>(W, Bv, Ac, K4h, po.op, lane, acc);
     }
     softmax_lanes<U>(acc[0], A, lane, dst_policy);
     lds_sync();
@@ -527,6 +556,38 @@ __device__ inline void stage_weights_without_rep(float *lds, const float *weight
             for (int u = 0; u < UB; u++) { const int i = i0 + u * blockDim.x * 4; if (i < cnt) *reinterpret_cast<float4 *>(dst + i) = v[u]; }
         }
     }
+    __syncthreads();
+}
+
+// The compact LDS image (mat_op<true>): matrices 0..11 at mat_off<true>, every 4-input group mat_op floats x 4 wide instead of
+// OP x 4; the bias block (64 wide per matrix, unchanged) right behind them.  Only off[M_COUNT] (the bias base pick() uses) and
+// total_floats of the returned descriptor are meaningful.
+__host__ __device__ inline int compact_matrix_floats(const smz_mlp_desc &d) { return mat_off<true>(d, M_REP_IN); }
+__host__ __device__ inline int compact_total_floats(const smz_mlp_desc &d) { return compact_matrix_floats(d) + (d.total_floats - d.off[M_COUNT]); }
+__device__ inline smz_mlp_desc lds_desc_compact(const smz_mlp_desc &d) {
+    smz_mlp_desc l = d;
+    l.off[M_COUNT] = compact_matrix_floats(d);
+    l.total_floats = compact_total_floats(d);
+    return l;
+}
+__device__ inline void stage_weights_compact(float *lds, const float *weights, const smz_mlp_desc &d) {
+    const int kin = up4(d.S + d.A), kmid = d.L > 0 ? up4(d.H) : 0, kh = up4(d.H), ks = up4(d.S);
+    const int K[M_REP_IN] = {kin, kin, kmid, kmid, kh, kh, ks, ks, kmid, kmid, kh, kh};
+    int dst = 0;
+#pragma unroll
+    for (int m = 0; m < M_REP_IN; m++) {
+        const int op = mat_op<true>(d, m), groups = K[m] >> 2, per = op;            // `per` float4 per group
+        const float4 *src = reinterpret_cast<const float4 *>(weights + d.off[m]);
+        float4 *out = reinterpret_cast<float4 *>(lds + dst);
+        for (int i = threadIdx.x; i < groups * per; i += blockDim.x) {
+            const int g = i / per, o = i - g * per;
+            out[i] = src[g * d.OP + o];
+        }
+        dst += K[m] * op;
+    }
+    const int n_bias = d.total_floats - d.off[M_COUNT];
+    for (int i = threadIdx.x * 4; i < n_bias; i += blockDim.x * 4)
+        *reinterpret_cast<float4 *>(lds + dst + i) = *reinterpret_cast<const float4 *>(weights + d.off[M_COUNT] + i);
     __syncthreads();
 }
 

@@ -359,6 +359,7 @@ class HostImageVecEnv(HostVecEnv):
     def _alloc_observations(self, pin):
         B, H, W = self.B, self.H, self.W
         self._h_frames = torch.zeros(B, H, W, 3, dtype=torch.uint8, **pin)        # next search's frames
+        self._h_frames_np = self._h_frames.numpy()
         self._d_frames = torch.zeros(B, H, W, 3, dtype=torch.uint8, device=self.device)
         self.obs = torch.zeros((B,) + self.frame, dtype=torch.float32, device=self.device)
         self.record_obs = torch.zeros((B,) + self.frame, dtype=torch.float32, device=self.device) if self.on_end == "reset" else None
@@ -376,7 +377,7 @@ class HostImageVecEnv(HostVecEnv):
         if not after_step and self._stepping:
             # a reset inside step(): the frame in the main buffer is this env's post-step one -- the record needs it
             self._ended.append((i, self._h_frames[i].clone()))
-        self._h_frames[i] = torch.from_numpy(np.ascontiguousarray(seen))
+        np.copyto(self._h_frames_np[i], seen)          # (a numpy view of the pinned buffer: no tensor-indexing overhead per env)
 
     _stepping = False
 

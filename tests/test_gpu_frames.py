@@ -18,8 +18,11 @@ import golden_util as gu
 
 pytestmark = pytest.mark.gpu
 
-# float32 results in [0, 1]: one ulp is <= 1.19e-7 there.  ATen's CPU kernel may contract a * b + c * d into fused
-# multiply-adds (build dependent); the HIP kernel rounds every product and sum (-ffp-contract=off).
+# float32 results in [0, 1]: one ulp is <= 1.19e-7 there.  ATen's generic linear kernel computes `out = t0 * w0; out += t1 * w1`
+# per dimension and its build lets the compiler fuse one product of each line into an fma, in an association of the compiler's
+# choosing (it differs between the vector body and the scalar remainder of ATen's own loop).  The HIP kernel uses the form
+# torch 2.10's CPU kernel produces for 98-pixel-wide outputs -- the frame size of the reference's model -- so those cases are
+# held to bit identity; any other association is within one ulp.
 ONE_ULP = 1.1920929e-07
 
 
@@ -63,8 +66,8 @@ def test_resize_kernel_equals_torch_cpu_bilinear(n, H, W, out_hw):
           f"bit-identical {100.0 * (got == want).mean():.2f} %")
     assert got.min() >= 0.0 and got.max() <= 1.0
     assert err.max() <= ONE_ULP
-    if (H, W) == tuple(out_hw):
-        assert np.array_equal(got, want)                                 # identity size: every weight is 0 or 1
+    if out_hw[1] == 98:
+        assert np.array_equal(got, want)                                 # the model's frame width: bit for bit
 
 
 def test_resize_into_selected_rows_of_a_batch():
@@ -110,14 +113,14 @@ def test_host_envs_observed_through_rendered_frames_drive_the_vision_heads(on_en
     for e in range(B):
         twin, episode = envs_mod.HostCartPoleRender(hw), 0
         twin.reset(seed=11 + 5 + e)
-        assert np.abs(first[e] - _torch_resize(twin.render()[None].copy(), (98, 98)).numpy()[0]).max() <= ONE_ULP
+        assert np.array_equal(first[e], _torch_resize(twin.render()[None].copy(), (98, 98)).numpy()[0])
         for t in range(T):
             if flags[t, e] == 3:                       # switched off: no step, the row's frame means nothing
                 assert on_end == "mask"
                 continue
             twin.step(int(actions[t, e]))
             want = _torch_resize(twin.render()[None].copy(), (98, 98)).numpy()[0]
-            assert np.abs(frames[t, e] - want).max() <= ONE_ULP, (e, t)
+            assert np.array_equal(frames[t, e], want), (e, t)
             n_checked += 1
             if flags[t, e] != 0:
                 n_ends += 1
@@ -126,7 +129,7 @@ def test_host_envs_observed_through_rendered_frames_drive_the_vision_heads(on_en
                     twin.reset(seed=11 + 5 + e + 1000003 * episode)
         if on_end == "reset":          # what the NEXT search would see: the twin's current frame (a reset frame if a game just ended)
             want = _torch_resize(twin.render()[None].copy(), (98, 98)).numpy()[0]
-            assert np.abs(env.obs[e].cpu().numpy() - want).max() <= ONE_ULP
+            assert np.array_equal(env.obs[e].cpu().numpy(), want)
     assert n_ends >= B and n_checked >= (B * limit if on_end == "mask" else B * T)
     games = sp.chunk_to_games(chunk.data, 0, 2, 0.999, limit_of_game_play=limit, observations=chunk.obs,
                               observation_shape=(3, 98, 98), after_end="new_game" if on_end == "reset" else "drop",
