@@ -500,6 +500,48 @@ def main():
         if not single:
             ms, mean_us, bytes_launch = tms, tree_us, tree_bytes
         achieved = bytes_launch / (mean_us * 1e-6) / 1e9
+        # ---- what actually bounds the launch (profiles/r03_ceiling.md) -------------------------------------------------------
+        # At 4096 trees there are 16 trees per CU: a launch is a chain of num_simulations dependent rounds per wavefront
+        # (descent levels, network layers, expansion and backup each wait for the one before), not a stream of bytes.  The
+        # chain's own duration is measured live: the same kernel on HALF the trees with ONE wavefront per SIMD (4-wave
+        # workgroups) -- nothing to contend with, every latency exposed.  frac = chain / launch says how much of the launch the
+        # dependent chain alone explains; the second wavefront per SIMD then adds its whole work for the remaining 1 - frac.
+        bound_actual = None
+        if single and wl["env"] != "image" and Bg % 2 == 0 and Bg // 2 >= 1024:
+            os.environ["SMZ_SEARCH_WAVES"] = "4"
+            try:
+                Bh = Bg // 2
+                m_h = mcts_mod.BatchedMCTS(Bh, num_simulations=wl["sims"], maxium_action_sample=wl["K"], discount=0.999,
+                                           root_dirichlet_alpha=0.25, root_exploration_fraction=0.1, device=local_rank,
+                                           use_graph=False, fused=True, single_launch=True,
+                                           rng_mode=smz._lib.RNG_PHILOX if args.rng == "philox" else smz._lib.RNG_MT19937_NUMPY)
+                m_h.seed(np.arange(Bh, dtype=np.uint64))
+                obs_h = env.obs[:Bh].clone()
+                eng_h = m_h.run(obs_h, heads, train=True, act_temperature=args.temperature)
+                hd = []
+                for _ in range(reps + 1):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda._sleep(2_000_000)
+                    e0.record()
+                    for _k in range(PER_PAIR):
+                        eng_h.search_mlp(heads.desc, heads.weights, obs_h, train=True, act_temperature=args.temperature)
+                    e1.record()
+                    hd.append((e0, e1))
+                torch.cuda.synchronize(dev)
+                chain_us = float(np.mean([a.elapsed_time(b) for a, b in hd[1:]]) / PER_PAIR * 1e3)
+                bound_actual = {"kind": "latency: dependent chain of one wavefront's simulation rounds",
+                                "chain_us": chain_us, "launch_us": mean_us, "frac": chain_us / mean_us,
+                                "how": f"{eng_h.last_kernel()} on {Bh} trees in 4-wave workgroups (one wavefront per SIMD, same "
+                                       "trees per wavefront): its launch time is the chain; the production launch runs two "
+                                       "wavefronts per SIMD"}
+                eng_h.close()
+            finally:
+                del os.environ["SMZ_SEARCH_WAVES"]
+        elif single and wl["env"] == "image":
+            # k_search_vision runs ONE wavefront per SIMD (4 trees per CU at 1024 trees): the launch is its own dependent chain
+            bound_actual = {"kind": "latency: dependent chain of one wavefront's simulation rounds (one wavefront per SIMD)",
+                            "chain_us": mean_us, "launch_us": mean_us, "frac": 1.0,
+                            "how": "1024 trees = 4 per CU = one 4-wave workgroup per CU: nothing overlaps a wavefront's own chain"}
         # HBM bytes per launch from the TCC counters, when a PMC pass of this workload/kernel has been committed
         # ... of the kernel instantiation that actually ran (smz_last_kernel), same workload, same kernel sources
         traffic, traffic_note = None, None
@@ -512,7 +554,25 @@ def main():
                                 "; read side may be under-counted up to 2x on gfx950 (upper bound %.0f)" % tj["hbm_bytes_per_launch_read_x2"])
             else:
                 traffic_note = tname
+        compute = None
+        if single and wl["env"] == "image":
+            # f32 multiply-adds of one leaf evaluation (neural_network_vision_model.py:41-515 at 3x7x7): 3x3 convolutions (49 pixels,
+            # 3 output channels), 1x1 mixes, the 147 -> H -> [H ->] S / A towers; dynamics leaves also evaluate the reward tower
+            Hh, Lh, Ss, Ah = heads.H, heads.L, heads.Ssup, heads.A
+            conv = lambda cin: 49 * 3 * cin * 9
+            tower = lambda n_out: 147 * Hh + Lh * Hh * Hh + Hh * n_out
+            common = conv(4) + Lh * 3 * conv(3) + Lh * 3 * conv(3) + 2 * 49 * 3 * 3 + tower(Ss) + tower(Ah)
+            macs_dyn, macs_aft = common + 49 * 3 * 4 + tower(Ss), common
+            macs = 0.5 * (macs_dyn + macs_aft)
+            flops_launch = 2.0 * macs * Bg * wl["sims"]
+            tf = flops_launch / (mean_us * 1e-6) / 1e12
+            compute = {"bound": "compute", "unit": "TFLOP/s", "achieved": tf, "peak": 157.3, "frac": tf / 157.3,
+                       "flops_per_launch": flops_launch, "macs_per_leaf": {"dynamics": macs_dyn, "afterstate": macs_aft},
+                       "note": "f32 multiply-adds of the leaf networks (mean of the two branches) x leaves per launch / launch "
+                               "time against the 157.3 TFLOP/s f32 vector peak (MI355X_MICROARCH.md); the launch is latency-bound "
+                               "(bound_actual), neither figure is a ceiling it approaches"}
         out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "bound_actual": bound_actual, "compute": compute,
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                            "kernel_launched": launched or None, "kernel_source_sha16": kernel_source_sha16(),
                            "bytes_per_launch": bytes_launch,
@@ -528,6 +588,14 @@ def main():
                                      "around 4 back-to-back launches of the search kernel alone (elapsed / 4), around each "
                                      "launch for the step-wise tree kernel; bytes = SURVEY 8d formula on this run's level "
                                      "histogram"}
+    if rank == 0 and out.get("roofline", {}).get("compute"):
+        # vision family: the leaf networks are arithmetic, not byte movement -- the headline fraction is the f32 one; the
+        # bytes-based figures (SURVEY 8d formula) stay beside it
+        r = out["roofline"]
+        c = r.pop("compute")
+        r["hbm"] = {k: r[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_note", "bytes_per_launch")}
+        r.update(bound="compute", achieved=c["achieved"], peak=c["peak"], unit=c["unit"], frac=c["frac"],
+                 flops_per_launch=c["flops_per_launch"], macs_per_leaf=c["macs_per_leaf"], compute_note=c["note"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:                                # N=1 only (contract)
         out["cpu_baseline"] = cpu_baseline_vision(wl, model) if wl["env"] == "image" else cpu_baseline_mlp(wl, wpath)
     if rank == 0:

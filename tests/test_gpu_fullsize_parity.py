@@ -240,6 +240,45 @@ def test_philox_mode_equals_the_oracle_drawing_from_the_same_counter_stream(wnam
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("A,K,B,sims", [(32, 2, 512, 20), (32, 7, 300, 12), (17, 17, 200, 10)])
+def test_the_widest_action_bucket_equals_the_oracle_on_every_tree(A, K, B, sims):
+    """SMZ_MAX_ACTIONS = 32 is a limit this build claims, so it is exercised: the MAXA = 32 instantiations of the step-wise
+    kernels (root block of 32 children, numpy `choice` without replacement over up to 32 actions, K up to A) and of the
+    single-launch kernel against the oracle on every tree, with a random-init mlp_model of that action count (reference init
+    rule).  Prints the launch time of the fused tree kernel for the record (evidence hygiene: the generic
+    MAXA = 32 instantiation is register-heavy -- one wavefront per SIMD)."""
+    mcts_mod, model_mod = _mods()
+    torch.manual_seed(A * 100 + K)
+    model = model_mod.Muzero(model_structure="mlp_model", observation_space_dimensions=8, action_space_dimensions=A,
+                             state_space_dimensions=31, hidden_layer_dimensions=64, number_of_hidden_layer=0, random_tag=1)
+    obs = np.random.RandomState(A).standard_normal((B, 8)).astype(np.float32)
+    seeds = np.arange(B, dtype=np.uint64) + 31
+    eng, trees, tape = stepwise_tape(model, obs, seeds, sims, K)
+    oracle_replay(trees, tape)
+    assert_engine_equals_oracle(eng, trees, sims, prior_rtol=0)
+    eng.close()
+    heads = model.heads("cuda:0", backend="hip")
+    m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=K, discount=DISCOUNT, root_dirichlet_alpha=ALPHA,
+                             root_exploration_fraction=FRAC, use_graph=False, single_launch=True)
+    m.seed(seeds)
+    e = m.run(torch.from_numpy(obs).cuda(), heads, train=True, act_temperature=1.0)
+    action = e.act(1.0)[0].clone()
+    torch.cuda.synchronize()
+    oa = [trees[i].act(1.0) for i in range(B)]
+    assert_engine_equals_oracle(e, trees, sims, prior_rtol=1e-12)
+    assert np.array_equal(action.cpu().numpy(), np.array([a[0] for a in oa], np.int32))
+    # timing of the step-wise fused tree kernel at this width (events around one search's launches)
+    m2 = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=K, discount=DISCOUNT, root_dirichlet_alpha=ALPHA,
+                              root_exploration_fraction=FRAC, use_graph=False, single_launch=False)
+    m2.seed(seeds)
+    m2.run(torch.from_numpy(obs).cuda(), heads, train=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); m2.run(torch.from_numpy(obs).cuda(), heads, train=True); e1.record()
+    torch.cuda.synchronize()
+    print(f"[A={A} K={K}] {B} trees x {sims} sims == oracle on every tree (single launch: {m._single is True}); step-wise search "
+          f"{e0.elapsed_time(e1) * 1e3 / max(sims, 1):.1f} us per simulation round")
+
+
 def test_vision_search_kernel_equals_oracle_on_every_tree():
     """The same chain for the `vision_model` family at the size bench.py times (1024 trees x 50 simulations, 98x98x3
     frames, hidden state 3x7x7): the step-wise kernels with the hand-written vision heads (smz_vision_initial /
