@@ -341,12 +341,13 @@ int smz_mlp_recurrent_rows(const smz_mlp_desc *desc, const float *weights_dev, f
                            int row_stride, const int32_t *ids_dev, const int32_t *last_action_dev, const uint8_t *branch_dev,
                            float *reward_out_dev, float *policy_out_dev, float *value_out_dev, int B, smz_stream stream);
 
-/* mlp_model networks too wide for LDS residency (number_of_hidden_layer 0 with H <= 128, 2 S <= 128, A + S <= 128: e.g. the
- * reference's config/experiment_434_config.json, S 61 / H 126).  smz_mlp_layout_wide fills the same descriptor for a
- * 128-outputs-wide packed image (matrix m: rows padded to a multiple of 8 inputs, element (k, o) at
- * off[m] + ((k / 4) * 128 + o) * 4 + k % 4; biases at off[15 + m]); SMZ_ERR_TOO_LARGE beyond those limits, SMZ_ERR_INVALID
- * for number_of_hidden_layer > 0.  smz_mlp_recurrent_wide = smz_mlp_recurrent on such a buffer: 16-leaf tiles on the matrix
- * cores, weights streamed from L2.  neural_network_mlp_model.py:5-250, muzero_model.py:844-909. */
+/* mlp_model networks too wide for LDS residency (H <= 128, 2 S <= 128, A + S <= 128, any number_of_hidden_layer: the
+ * reference's config/experiment_434_config.json, S 61 / H 126 / L 0, and its shipped checkpoint 450, S 61 / H 126 / L 4).
+ * smz_mlp_layout_wide fills the same descriptor for a 128-outputs-wide packed image (matrix m: rows padded to a multiple of
+ * 8 inputs, element (k, o) at off[m] + ((k / 4) * 128 + o) * 4 + k % 4; biases at off[15 + m]; with number_of_hidden_layer
+ * > 0 each trunk's ONE shared Linear(H, H) is matrix *_MID, applied L times); SMZ_ERR_TOO_LARGE beyond those limits.
+ * smz_mlp_recurrent_wide = smz_mlp_recurrent on such a buffer: 16-leaf tiles on the matrix cores, weights streamed from L2.
+ * neural_network_mlp_model.py:5-250, muzero_model.py:844-909. */
 int smz_mlp_layout_wide(smz_mlp_desc *desc);
 int smz_mlp_recurrent_wide(const smz_mlp_desc *desc, const float *weights_dev, const float *mlp_input_dev,
                            const uint8_t *branch_dev, float *hidden_out_dev, float *reward_out_dev, float *policy_out_dev,

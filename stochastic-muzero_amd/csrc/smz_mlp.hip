@@ -405,7 +405,8 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
 
 // -------------------------------------------------------------------------------------------------------------------
 // Networks too wide for LDS residency (the reference's config/experiment_434_config.json: state_space_dimensions 61,
-// hidden_layer_dimensions 126; any number_of_hidden_layer 0 shape with H <= 128, 2 S <= 128, A + S <= 128): the same
+// hidden_layer_dimensions 126, and its checkpoint 450 with number_of_hidden_layer 4; any shape with H <= 128, 2 S <= 128,
+// A + S <= 128 -- hidden layers are the same Linear(H, H) applied L times, neural_network_mlp_model.py:122-142): the same
 // 16-leaf tiles with the weights streamed from L2 -- A operands as 8-byte global loads of a 128-wide packed image
 // (smz_mlp_layout_wide), prefetched one input group ahead of the MFMAs that consume them; layers are 8 tiles of 16
 // neurons, dimensions are run-time values.  Outputs agree with the torch-GEMM heads / the reference's tapes within the
@@ -492,6 +493,8 @@ __global__ void __launch_bounds__(kWideWaves *kWave) k_mlp_recurrent_wide(smz_ml
             const int w_out = ady ? d.off[M_ADY_OUT] : d.off[M_DYN_OUT], b_out = ady ? d.off[M_COUNT + M_ADY_OUT] : d.off[M_COUNT + M_DYN_OUT];
             const int wp_in = ady ? d.off[M_APR_IN] : d.off[M_PRE_IN], bp_in = ady ? d.off[M_COUNT + M_APR_IN] : d.off[M_COUNT + M_PRE_IN];
             const int wp_out = ady ? d.off[M_APR_OUT] : d.off[M_PRE_OUT], bp_out = ady ? d.off[M_COUNT + M_APR_OUT] : d.off[M_COUNT + M_PRE_OUT];
+            const int w_mid = ady ? d.off[M_ADY_MID] : d.off[M_DYN_MID], b_mid = ady ? d.off[M_COUNT + M_ADY_MID] : d.off[M_COUNT + M_DYN_MID];
+            const int wp_mid = ady ? d.off[M_APR_MID] : d.off[M_PRE_MID], bp_mid = ady ? d.off[M_COUNT + M_APR_MID] : d.off[M_COUNT + M_PRE_MID];
             v4f y[kWideTiles];
             auto trunk_store = [&]() {
 #pragma unroll
@@ -505,6 +508,12 @@ __global__ void __launch_bounds__(kWideWaves *kWave) k_mlp_recurrent_wide(smz_ml
             lds_sync();
             trunk_store();
             lds_sync();
+            for (int l = 0; l < d.L; l++) {          // the SAME Linear(H, H) + ELU applied L times (neural_network_mlp_model.py:122-142)
+                wide_layer(weights + w_mid, weights + b_mid, tile, K8h, lane, y);
+                lds_sync();
+                trunk_store();
+                lds_sync();
+            }
             wide_layer(weights + w_out, weights + b_out, tile, K8h, lane, y);
             float reward = 0.f;
             {   // dynamics: [reward logits 0..S-1 | next state S..2S-1]; afterstate dynamics: next state 0..S-1
@@ -555,6 +564,12 @@ __global__ void __launch_bounds__(kWideWaves *kWave) k_mlp_recurrent_wide(smz_ml
             lds_sync();
             trunk_store();
             lds_sync();
+            for (int l = 0; l < d.L; l++) {
+                wide_layer(weights + wp_mid, weights + bp_mid, tile, K8h, lane, y);
+                lds_sync();
+                trunk_store();
+                lds_sync();
+            }
             wide_layer(weights + wp_out, weights + bp_out, tile, K8h, lane, y);
             {   // [policy logits 0..A-1 | value logits A..A+S-1]
                 float mp = -__builtin_inff(), mv = -__builtin_inff();
@@ -741,10 +756,11 @@ int smz_mlp_recurrent_rows(const smz_mlp_desc *d, const float *weights_dev, floa
 }
 
 int smz_mlp_layout_wide(smz_mlp_desc *d) {
-    if (!d || d->obs < 1 || d->A < 1 || d->S < 1 || d->H < 1 || d->L != 0) return SMZ_ERR_INVALID;
+    if (!d || d->obs < 1 || d->A < 1 || d->S < 1 || d->H < 1 || d->L < 0) return SMZ_ERR_INVALID;
     if (d->H > kWideOP || 2 * d->S > kWideOP || d->A + d->S > kWideOP) return SMZ_ERR_TOO_LARGE;
     d->OP = kWideOP;
-    const int K[M_COUNT] = {d->S + d->A, d->S + d->A, 0, 0, d->H, d->H, d->S, d->S, 0, 0, d->H, d->H, d->obs, 0, d->H};
+    const int mid = d->L > 0 ? d->H : 0;     // one shared Linear(H, H) per trunk, applied L times
+    const int K[M_COUNT] = {d->S + d->A, d->S + d->A, mid, mid, d->H, d->H, d->S, d->S, mid, mid, d->H, d->H, d->obs, mid, d->H};
     int off = 0;
     // every matrix padded to a multiple of 8 input rows: the tile kernel consumes inputs in groups of eight
     for (int m = 0; m < M_COUNT; m++) { d->off[m] = off; off += ((K[m] + 7) & ~7) * d->OP; }

@@ -229,8 +229,8 @@ class HipMlpHeads:
 
 
 class HipMlpTileHeads(FusedMlpHeads):
-    """`mlp_model` heads too wide for the LDS-resident kernels (number_of_hidden_layer 0, H <= 128, 2 S <= 128: the
-    reference's config 434, S 61 / H 126): the recurrent networks as ONE hand-written kernel per simulation round
+    """`mlp_model` heads too wide for the LDS-resident kernels (H <= 128, 2 S <= 128, any number_of_hidden_layer: the
+    reference's config 434, S 61 / H 126 / L 0, and its checkpoint 450, L 4): the recurrent networks as ONE hand-written kernel per simulation round
     (smz_mlp_recurrent_wide: 16-leaf tiles on the matrix cores, weights streamed from L2 in the 128-wide packed layout of
     smz_mlp_layout_wide) instead of ten library launches; the root evaluation stays on the torch GEMMs of FusedMlpHeads
     (once per search).  Raises ValueError outside the kernel's limits."""
@@ -246,7 +246,7 @@ class HipMlpTileHeads(FusedMlpHeads):
         buf = np.zeros(d.total_floats, np.float32)
         OP = d.OP
         for m, (_, parts) in enumerate(HipMlpHeads._MATS):
-            if "_mid" in parts[0]:
+            if "_mid" in parts[0] and self.L == 0:
                 continue
             W = np.concatenate([np.asarray(weights[p + "_w"], np.float32) for p in parts], 0)      # [O, K] (torch layout)
             b = np.concatenate([np.asarray(weights[p + "_b"], np.float32) for p in parts], 0)

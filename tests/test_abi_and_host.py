@@ -143,7 +143,7 @@ def test_checkpoint_surface_roundtrip(tmp_path):
 
 
 @pytest.mark.parametrize("name,wname", [("ckpt421_sims50", "weights_ckpt421"), ("lunarL2_K3_sims24", "weights_lunar_L2"),
-                                        ("wideA11_K9_sims24", "weights_wide_A11")])
+                                        ("wideA11_K9_sims24", "weights_wide_A11"), ("ckpt450_sims11", "weights_ckpt450")])
 def test_batch1_inference_api_reproduces_reference_outputs(name, wname):
     """The five *_inference methods (muzero_model.py:802-909) on CPU against the reference's recorded outputs.
     Same torch build, same float32 operations -> the hidden states and policies agree to 1e-6."""

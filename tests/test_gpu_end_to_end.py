@@ -753,6 +753,70 @@ def test_vision_single_launch_search_with_more_actions_equals_stepwise(A, L, B, 
         assert np.array_equal(ka, kb) and pa == pb
 
 
+def test_checkpoint_450_deep_wide_networks_run_on_the_tile_kernel():
+    """the reference's shipped checkpoint 450 (config/experiment_450_config.json:18-20: state_space_dimensions 61,
+    hidden_layer_dimensions 126, number_of_hidden_layer 4 -- one of its trained CartPole runs) is too wide for LDS residency and
+    used to fall to the torch-GEMM heads because the wide tile kernel refused hidden layers.  Now smz_mlp_recurrent_wide applies
+    each trunk's shared Linear(H, H) + ELU L times on the matrix cores: the heads must reproduce the head outputs the
+    REFERENCE recorded with that checkpoint (goldens ckpt450_sims11 + weights_ckpt450, oracle/gen_golden_r3.py), agree with the
+    GEMM heads, and a batched search from the fixture's seeds must reproduce the reference's visit counts on every case."""
+    mcts_mod, model_mod, _, _ = _mods()
+    cfg, data = gu.load("ckpt450_sims11")
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_ckpt450.npz"))
+    assert (model.state_dimension, model.hidden_layer_dimension, model.number_of_hidden_layer) == (61, 126, 4)
+    with pytest.raises(ValueError):
+        model.heads("cuda:0", backend="hip")
+    heads = model.heads("cuda:0")
+    assert type(heads).__name__ == "HipMlpTileHeads" and heads.L == 4 and heads.wide_desc.L == 4
+    gemm = model.heads("cuda:0", backend="torch")
+    ncase, sims = data["tape_branch"].shape
+    hid, pol = heads.initial(torch.from_numpy(data["obs"]).cuda())
+    torch.testing.assert_close(hid.cpu(), torch.from_numpy(data["root_hidden"]), rtol=0, atol=2e-6)
+    torch.testing.assert_close(pol.cpu(), torch.from_numpy(data["root_policy"]), rtol=0, atol=1e-6)
+    fe = _FakeEngine()
+    hin = torch.from_numpy(data["tape_hidden_in"].reshape(ncase * sims, -1))
+    onehot = torch.eye(2)[torch.from_numpy(data["tape_action"].reshape(-1)).long()]
+    fe.mlp_input = torch.cat([hin, onehot], 1).cuda().contiguous()
+    fe.branch = torch.from_numpy(data["tape_branch"].reshape(-1).astype(np.uint8)).cuda()
+    worst = {}
+    for name, hd in (("tile", heads), ("gemm", gemm)):
+        h2, rw, p2, v2 = (t.clone() for t in hd.recurrent(fe))
+        torch.cuda.synchronize()
+        worst[name] = (float((h2.cpu() - torch.from_numpy(data["tape_hidden_out"].reshape(ncase * sims, -1))).abs().max()),
+                       float((p2.cpu() - torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1))).abs().max()))
+        torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(ncase * sims, -1)), rtol=0, atol=4e-6)
+        torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1)), rtol=0, atol=2e-6)
+        torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=5e-5, atol=4e-4)
+        torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=5e-5, atol=4e-4)
+    print("checkpoint 450 heads vs the reference's tape, max |hidden|, |policy| error:", worst)
+    m = mcts_mod.BatchedMCTS(ncase, num_simulations=int(cfg["num_simulations"]), maxium_action_sample=2,
+                             discount=float(cfg["discount"]), root_dirichlet_alpha=float(cfg["root_dirichlet_alpha"]),
+                             root_exploration_fraction=float(cfg["root_exploration_fraction"]), use_graph=True)
+    m.seed(np.asarray(data["seed"], np.uint64))
+    e = m.run(torch.from_numpy(data["obs"]).cuda(), heads, train=True)
+    visits = e.root_stats()[0]
+    torch.cuda.synchronize()
+    assert np.array_equal(visits.cpu().numpy(), data["root_visits"])
+    # a larger batch: tile heads == GEMM heads on the visit counts of (nearly) every tree, and faster
+    B = 4096
+    obs = torch.from_numpy(np.random.RandomState(1).uniform(-0.05, 0.05, (B, 4)).astype(np.float32)).cuda()
+    got = []
+    for hd in (heads, gemm):
+        mb = mcts_mod.BatchedMCTS(B, num_simulations=20, discount=0.997, root_exploration_fraction=0.25, use_graph=True)
+        mb.seed(np.arange(B, dtype=np.uint64))
+        mb.run(obs, hd, train=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        mb.engine.seed(np.arange(B, dtype=np.uint64))
+        e0.record(); eb = mb.run(obs, hd, train=True); e1.record()
+        v = eb.root_stats()[0]
+        torch.cuda.synchronize()
+        got.append((v.cpu().numpy().copy(), e0.elapsed_time(e1)))
+    same = (got[0][0] == got[1][0]).all(axis=1).mean()
+    print(f"checkpoint 450 at {B} trees x 20 sims: tile heads {got[0][1]:.2f} ms, GEMM heads {got[1][1]:.2f} ms per search; "
+          f"{100 * same:.2f} % of trees with identical visit counts")
+    assert same >= 0.97 and (got[0][0].sum(1) == 20).all()
+
+
 def test_config434_network_shape_runs_on_the_gemm_heads():
     """The other network shape among the reference's configs (config/experiment_434_config.json: state_space_dimensions
     61, hidden_layer_dimensions 126) does not fit the LDS-resident kernels: model.heads() must hand out the torch-GEMM

@@ -76,7 +76,7 @@ def test_whole_game_tape_driven(name):
 WEIGHTED = [("ckpt421_sims10", "weights_ckpt421"), ("ckpt421_sims50", "weights_ckpt421"),
             ("ckpt421_sims100", "weights_ckpt421"), ("lunar_K2_sims50", "weights_lunar_L0"),
             ("lunar_K4_sims30", "weights_lunar_L0"), ("lunarL2_K3_sims24", "weights_lunar_L2"),
-            ("wideA11_K9_sims24", "weights_wide_A11")]
+            ("wideA11_K9_sims24", "weights_wide_A11"), ("ckpt450_sims11", "weights_ckpt450")]
 
 
 @pytest.mark.parametrize("name,wname", WEIGHTED)
