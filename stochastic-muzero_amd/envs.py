@@ -268,6 +268,10 @@ class HostVecEnv:
         if after_step:
             self._h_rec[i] = row
 
+    def _keep(self, i):
+        """A step that did not change env i's observation (illegal move, game.py:123-131): the record's row is the current one."""
+        self._h_rec[i] = self._h_obs[i]
+
     def _upload_observations(self, after_step):
         self.obs.copy_(self._h_obs, non_blocking=True)
         if after_step:
@@ -317,6 +321,8 @@ class HostVecEnv:
             rew[i], flag[i] = r, f
             if seen is not None:
                 self._store(i, seen, after_step=True)
+            else:
+                self._keep(i)                             # illegal move: the record shows the unchanged observation
             if f:
                 if self.on_end == "reset":
                     self.episode[i] += 1
@@ -378,6 +384,9 @@ class HostImageVecEnv(HostVecEnv):
             # a reset inside step(): the frame in the main buffer is this env's post-step one -- the record needs it
             self._ended.append((i, self._h_frames[i].clone()))
         np.copyto(self._h_frames_np[i], seen)          # (a numpy view of the pinned buffer: no tensor-indexing overhead per env)
+
+    def _keep(self, i):
+        pass                                               # the frame in the main buffer is still the current one
 
     _stepping = False
 
