@@ -1783,7 +1783,7 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL;
 #if SMZ_PART != 4
     {   // LDS-resident trees (k_search_mlp<..., TLDS>): the specialised, unmasked, MT19937 instantiation when the workgroup's
-        // trees fit next to the compact weight image (checkpoint-421 shape, 2 actions: up to 73 simulations); SMZ_SEARCH_TLDS=0
+        // trees fit next to the compact weight image (checkpoint-421 shape, 2 actions: up to ~62 simulations); SMZ_SEARCH_TLDS=0
         // keeps the trees in global memory (A/B runs)
         const MegaLds mt = mega_lds(*desc, P, tpw, true, kWaves);
         const size_t lds_t = ((size_t)mt.trees_off + (size_t)kWaves * tpw * mt.tree_words) * sizeof(float);

@@ -753,6 +753,42 @@ def test_vision_single_launch_search_with_more_actions_equals_stepwise(A, L, B, 
         assert np.array_equal(ka, kb) and pa == pb
 
 
+@pytest.mark.parametrize("wname,B,sims", [("weights_ckpt421", 2570, 50), ("weights_lunar_L0", 4096, 30), ("weights_ckpt421", 2049, 60)])
+def test_lds_resident_trees_equal_trees_in_global_memory(wname, B, sims, monkeypatch):
+    """k_search_mlp<..., TLDS> (round 3: the workgroup's trees live in LDS for the search, blocks packed at 48 bytes, weights in
+    the compact LDS image, written back to the 64-byte-granule layout at the end) against the same kernel with the trees in
+    global memory (SMZ_SEARCH_TLDS=0): ragged batches (the last workgroup partly empty), 4 actions, the largest simulation count
+    that still fits -- visits, priors, values, every dumped tree array of sampled trees, path, action outputs and stream
+    positions over two consecutive searches, bit for bit."""
+    mcts_mod, model_mod, _, _ = _mods()
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
+    heads = model.heads("cuda:0", backend="hip")
+    obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(5)).mul(0.3).cuda()
+    res = []
+    for tlds in ("1", "0"):
+        monkeypatch.setenv("SMZ_SEARCH_TLDS", tlds)
+        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997,
+                                 root_exploration_fraction=0.25, use_graph=False, single_launch=True)
+        m.seed(np.arange(B, dtype=np.uint64) + 3)
+        for rep in range(2):
+            e = m.run(obs, heads, train=True, act_temperature=1.0)
+        assert m._single is True and e.last_kernel().endswith("true>" if tlds == "1" else "false>"), e.last_kernel()
+        visits, priors, rv, cr = e.root_stats()
+        action, policy, cv, _ = e.act(1.0)
+        torch.cuda.synchronize()
+        out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr, action, policy, cv)]
+        picks = (0, 1, 15, 16, 17, B // 2, B - 2, B - 1)
+        res.append((out, [e.dump_tree(i) for i in picks], [e.get_rng_state(i) for i in picks]))
+    assert (res[0][0][0].sum(1) == sims).all()
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for da, db in zip(res[0][1], res[1][1]):
+        for k in da:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+    for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
+        assert np.array_equal(ka, kb) and pa == pb
+
+
 def test_checkpoint_450_deep_wide_networks_run_on_the_tile_kernel():
     """the reference's shipped checkpoint 450 (config/experiment_450_config.json:18-20: state_space_dimensions 61,
     hidden_layer_dimensions 126, number_of_hidden_layer 4 -- one of its trained CartPole runs) is too wide for LDS residency and
