@@ -30,42 +30,33 @@ __device__ inline const float *uniform_ptr(const float *base, int off) {
     return base + __builtin_amdgcn_readfirstlane(off);
 }
 
-// out[oc] = sum_{tap, ic} w[oc][ic][tap] * plane[pixel + tap][ic]; CIN = 3 or 4 (4th = action plane)
-// ROLL: the nine taps as a rolled loop (12 weights live at a time instead of up to 108: the single-launch vision search
-// keeps tree state and tower fragments in registers next to this code); same operations in the same order either way.
-template <int CIN, bool ROLL = false>
+// out[oc] = sum_{tap, ic} w[oc][ic][tap] * plane[pixel + tap][ic]; CIN = 3 or 4 (4th = action plane).
+// Association (round 3, every variant below rounds alike): each ROW of taps is one fma chain from zero (taps left to right,
+// input channels inside a tap), the three row sums are combined as (r0 + r1) + r2.  Three independent chains of 9 or 12 steps
+// instead of one of 27 or 36: on the matrix cores (conv3x3_m) a dependent v_mfma_f32_4x4x1 step costs ~2x the issue interval
+// of an independent one, and the vector-unit versions lose their s_nop wait states the same way.
+template <int CIN>
 __device__ inline void conv3x3(const float4 *plane, int pp, const float *__restrict__ w, float (&out)[kC]) {
+    float r[3][kC];
 #pragma unroll
-    for (int oc = 0; oc < kC; oc++) out[oc] = 0.f;
-    if constexpr (ROLL) {
-#pragma unroll 1
-        for (int ty = 0; ty < 3; ty++) {                    // one row of taps per trip: 27-36 weights live, three plane reads in flight
+    for (int ty = 0; ty < 3; ty++)
 #pragma unroll
-            for (int tx = 0; tx < 3; tx++) {
-                const int t = ty * 3 + tx;
-                const float4 v = plane[pp + (ty - 1) * kPad + (tx - 1)];
+        for (int oc = 0; oc < kC; oc++) r[ty][oc] = 0.f;
+    {
 #pragma unroll
-                for (int oc = 0; oc < kC; oc++) {
-                    out[oc] = fmaf(w[(oc * CIN + 0) * 9 + t], v.x, out[oc]);
-                    out[oc] = fmaf(w[(oc * CIN + 1) * 9 + t], v.y, out[oc]);
-                    out[oc] = fmaf(w[(oc * CIN + 2) * 9 + t], v.z, out[oc]);
-                    if (CIN == 4) out[oc] = fmaf(w[(oc * CIN + 3) * 9 + t], v.w, out[oc]);
-                }
+        for (int t = 0; t < 9; t++) {
+            const float4 v = plane[pp + (t / 3 - 1) * kPad + (t % 3 - 1)];
+#pragma unroll
+            for (int oc = 0; oc < kC; oc++) {
+                r[t / 3][oc] = fmaf(w[(oc * CIN + 0) * 9 + t], v.x, r[t / 3][oc]);
+                r[t / 3][oc] = fmaf(w[(oc * CIN + 1) * 9 + t], v.y, r[t / 3][oc]);
+                r[t / 3][oc] = fmaf(w[(oc * CIN + 2) * 9 + t], v.z, r[t / 3][oc]);
+                if (CIN == 4) r[t / 3][oc] = fmaf(w[(oc * CIN + 3) * 9 + t], v.w, r[t / 3][oc]);
             }
         }
-        return;
     }
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
-        const float4 v = plane[pp + (t / 3 - 1) * kPad + (t % 3 - 1)];
-#pragma unroll
-        for (int oc = 0; oc < kC; oc++) {
-            out[oc] = fmaf(w[(oc * CIN + 0) * 9 + t], v.x, out[oc]);
-            out[oc] = fmaf(w[(oc * CIN + 1) * 9 + t], v.y, out[oc]);
-            out[oc] = fmaf(w[(oc * CIN + 2) * 9 + t], v.z, out[oc]);
-            if (CIN == 4) out[oc] = fmaf(w[(oc * CIN + 3) * 9 + t], v.w, out[oc]);
-        }
-    }
+    for (int oc = 0; oc < kC; oc++) out[oc] = (r[0][oc] + r[1][oc]) + r[2][oc];
 }
 
 __device__ inline void bn_relu_store(float4 *plane, int pp, bool active, const float (&t)[kC], const float *__restrict__ bn) {
@@ -77,18 +68,17 @@ __device__ inline void bn_relu_store(float4 *plane, int pp, bool active, const f
 }
 
 // v2 residual block with ONE batch-norm and convA used twice (neural_network_vision_model.py:41-79)
-template <bool ROLL = false>
 __device__ inline void residual_block(float4 *plane, int pp, bool active, const float *__restrict__ wa,
                                       const float *__restrict__ wb, const float *__restrict__ bn, float (&t)[kC]) {
     float c[kC];
     bn_relu_store(plane, pp, active, t, bn);
-    conv3x3<kC, ROLL>(plane, pp, wa, c);
+    conv3x3<kC>(plane, pp, wa, c);
     lds_sync();                               // every lane has read its neighbours before the plane is rewritten
     bn_relu_store(plane, pp, active, c, bn);
-    conv3x3<kC, ROLL>(plane, pp, wb, c);
+    conv3x3<kC>(plane, pp, wb, c);
     lds_sync();
     bn_relu_store(plane, pp, active, c, bn);
-    conv3x3<kC, ROLL>(plane, pp, wa, c);
+    conv3x3<kC>(plane, pp, wa, c);
     lds_sync();
 #pragma unroll
     for (int k = 0; k < kC; k++) t[k] = c[k] + t[k];
@@ -107,10 +97,12 @@ template <int CIN>
 __device__ inline void conv3x3_t(const float4 *plane, int pp, const float4 *__restrict__ wt, float (&out)[kC]) {
     typedef float v2f __attribute__((ext_vector_type(2)));
     constexpr int NJ = 3 * CIN, NQ = (9 * CIN + 3) / 4;
-    v2f o01 = {0.f, 0.f};
-    float o2 = 0.f;
-#pragma unroll 1                    // (all nine taps in flight need ~150 more registers than the search kernel has)
-    for (int ty = 0; ty < 3; ty++) {
+    v2f r01[3];
+    float r2[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ty++) {   // (one chain per row of taps, combined as (r0 + r1) + r2: conv3x3's association)
+        v2f o01 = {0.f, 0.f};
+        float o2 = 0.f;
         float4 v[3], wq[NQ];
 #pragma unroll
         for (int tx = 0; tx < 3; tx++) v[tx] = plane[pp + (ty - 1) * kPad + (tx - 1)];
@@ -133,8 +125,12 @@ __device__ inline void conv3x3_t(const float4 *plane, int pp, const float4 *__re
                 o2 = fmaf(w[2 * NJ + j], vin[ic], o2);
             }
         }
+        r01[ty] = o01;
+        r2[ty] = o2;
     }
-    out[0] = o01.x; out[1] = o01.y; out[2] = o2;
+    out[0] = (r01[0].x + r01[1].x) + r01[2].x;
+    out[1] = (r01[0].y + r01[1].y) + r01[2].y;
+    out[2] = (r2[0] + r2[1]) + r2[2];
 }
 // packed copy of a [3][CIN][9] convolution weight piece (kTapFloats floats) in that layout
 template <int CIN>
@@ -158,6 +154,66 @@ __device__ inline void residual_block_t(float4 *plane, int pp, bool active, cons
     lds_sync();
     bn_relu_store(plane, pp, active, c, bn);
     conv3x3_t<kC>(plane, pp, wa, c);
+    lds_sync();
+#pragma unroll
+    for (int k = 0; k < kC; k++) t[k] = c[k] + t[k];
+}
+
+// The same convolutions on the MATRIX CORES (round 3), for the single-launch vision search where the pixel <-> lane layout is
+// exactly a v_mfma_f32_4x4x1_16B_f32 operand layout: block b = pixels 4b .. 4b+3 (B operand: the lane's own tap value), rows =
+// output channels 0..2 (+ an idle fourth row; A operand: the weight of channel lane % 4, the same in every block), D = four
+// registers per lane = the lane's pixel, channels 0..3.  One instruction per (tap, input channel) instead of three multiply-adds,
+// one 16-byte LDS read per four weights instead of 21 per layer, and an f32-input MFMA is one fused multiply-add with a single
+// rounding per step (tools/mfma4_probe.hip) -- per row of taps one chain (taps left to right, input channels inside a tap), rows
+// combined as (r0 + r1) + r2, as conv3x3: bit-identical.
+// Weight table of a piece in LDS: wm[4][kMmRow]: wm[i][t * CIN + ic] = w[(i * CIN + ic) * 9 + t] (i < 3), zeros in row 3.
+constexpr int kMmRow = 36, kMmFloats = 4 * kMmRow;
+template <int CIN>
+__device__ inline void mfma_table(float *dst, const float *src, int tid, int nthreads) {
+    for (int i = tid; i < kMmFloats; i += nthreads) {
+        const int row = i / kMmRow, k = i % kMmRow, t = k / CIN, ic = k % CIN;
+        dst[i] = (row < kC && k < 9 * CIN) ? src[(row * CIN + ic) * 9 + t] : 0.f;
+    }
+}
+template <int CIN>
+__device__ inline void conv3x3_m(const float4 *plane, int pp, const float *__restrict__ wm, int lane, float (&out)[kC]) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    constexpr int K = 9 * CIN, NQ = (K + 3) / 4;
+    const float4 *wr = reinterpret_cast<const float4 *>(wm + (lane & 3) * kMmRow);
+    float4 wq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) wq[q] = wr[q];
+    float4 v[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) v[t] = plane[pp + (t / 3 - 1) * kPad + (t % 3 - 1)];
+    float w[4 * NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { w[4 * q] = wq[q].x; w[4 * q + 1] = wq[q].y; w[4 * q + 2] = wq[q].z; w[4 * q + 3] = wq[q].w; }
+    v4f acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // one chain per row of taps
+#pragma unroll
+    for (int tx = 0; tx < 3; tx++)
+#pragma unroll
+        for (int ic = 0; ic < CIN; ic++)
+#pragma unroll
+            for (int ty = 0; ty < 3; ty++) {       // (the three chains advance in turn: no step waits for its own predecessor)
+                const int t = ty * 3 + tx;
+                const float vin[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+                acc[ty] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[t * CIN + ic], vin[ic], acc[ty], 0, 0, 0);
+            }
+#pragma unroll
+    for (int oc = 0; oc < kC; oc++) out[oc] = (acc[0][oc] + acc[1][oc]) + acc[2][oc];
+}
+__device__ inline void residual_block_m(float4 *plane, int pp, bool active, const float *__restrict__ wa,
+                                        const float *__restrict__ wb, const float *__restrict__ bn, int lane, float (&t)[kC]) {
+    float c[kC];
+    bn_relu_store(plane, pp, active, t, bn);
+    conv3x3_m<kC>(plane, pp, wa, lane, c);
+    lds_sync();
+    bn_relu_store(plane, pp, active, c, bn);
+    conv3x3_m<kC>(plane, pp, wb, lane, c);
+    lds_sync();
+    bn_relu_store(plane, pp, active, c, bn);
+    conv3x3_m<kC>(plane, pp, wa, lane, c);
     lds_sync();
 #pragma unroll
     for (int k = 0; k < kC; k++) t[k] = c[k] + t[k];

@@ -44,6 +44,11 @@ using smz_vision::uniform_ptr;
 
 namespace {
 
+#ifndef SMZ_VISION_CONV_MFMA
+#define SMZ_VISION_CONV_MFMA 1                       // 3x3 convolutions as v_mfma_f32_4x4x1 chains (smz_vision_device.hpp conv3x3_m)
+#endif
+constexpr bool kConvMfma = SMZ_VISION_CONV_MFMA != 0;
+constexpr int kConvTab = kConvMfma ? smz_vision::kMmFloats : smz_vision::kTapFloats;     // floats per convolution piece in LDS
 constexpr int kVW = 4;                               // wavefronts = trees = leaf slots of a workgroup
 constexpr int kTowers = 5;                           // 0 dyn reward | 1 pre value | 2 pre policy | 3 apr value | 4 apr policy
 constexpr int kP1 = 40;                              // inputs per quarter of the 147-input layer (10 groups of four)
@@ -58,7 +63,7 @@ struct VisLds {                                      // float offsets from the d
 __host__ __device__ inline VisLds vis_lds(const Params &P, int A) {
     VisLds m;
     m.small = 0;
-    m.pbc = kSmallMax + 10 * smz_vision::kTapFloats;                                 // (+ tap-major copies of the ten 3x3 convolution pieces)
+    m.pbc = kSmallMax + 10 * kConvTab;                                               // (+ the ten 3x3 convolution pieces in the layout their kernel code wants)
     m.wave = m.pbc + r4(2 * 2 * (P.sims + 2));
     m.plane = 0;                                                  // float4 plane[81] -> 324 floats
     m.pv = r4(kPad * kPad * 4);
@@ -222,11 +227,19 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
     float *tm = lds + kSmallMax;
     for (int n = 0; n < 2; n++) {
         const int32_t *o = d.off + SMZ_V_TRANS_BASE + n * SMZ_V_TRANS_STRIDE, *q = d.off + SMZ_V_PRED_BASE + n * SMZ_V_PRED_STRIDE;
-        smz_vision::tap_major<4>(tm + (n * 3 + 0) * smz_vision::kTapFloats, weights + o[SMZ_VT_CONV_IN], threadIdx.x, blockDim.x);
-        smz_vision::tap_major<3>(tm + (n * 3 + 1) * smz_vision::kTapFloats, weights + o[SMZ_VT_RES_A], threadIdx.x, blockDim.x);
-        smz_vision::tap_major<3>(tm + (n * 3 + 2) * smz_vision::kTapFloats, weights + o[SMZ_VT_RES_B], threadIdx.x, blockDim.x);
-        smz_vision::tap_major<3>(tm + (6 + n * 2 + 0) * smz_vision::kTapFloats, weights + q[SMZ_VP_RES_A], threadIdx.x, blockDim.x);
-        smz_vision::tap_major<3>(tm + (6 + n * 2 + 1) * smz_vision::kTapFloats, weights + q[SMZ_VP_RES_B], threadIdx.x, blockDim.x);
+        if (kConvMfma) {
+            smz_vision::mfma_table<4>(tm + (n * 3 + 0) * kConvTab, weights + o[SMZ_VT_CONV_IN], threadIdx.x, blockDim.x);
+            smz_vision::mfma_table<3>(tm + (n * 3 + 1) * kConvTab, weights + o[SMZ_VT_RES_A], threadIdx.x, blockDim.x);
+            smz_vision::mfma_table<3>(tm + (n * 3 + 2) * kConvTab, weights + o[SMZ_VT_RES_B], threadIdx.x, blockDim.x);
+            smz_vision::mfma_table<3>(tm + (6 + n * 2 + 0) * kConvTab, weights + q[SMZ_VP_RES_A], threadIdx.x, blockDim.x);
+            smz_vision::mfma_table<3>(tm + (6 + n * 2 + 1) * kConvTab, weights + q[SMZ_VP_RES_B], threadIdx.x, blockDim.x);
+        } else {
+            smz_vision::tap_major<4>(tm + (n * 3 + 0) * kConvTab, weights + o[SMZ_VT_CONV_IN], threadIdx.x, blockDim.x);
+            smz_vision::tap_major<3>(tm + (n * 3 + 1) * kConvTab, weights + o[SMZ_VT_RES_A], threadIdx.x, blockDim.x);
+            smz_vision::tap_major<3>(tm + (n * 3 + 2) * kConvTab, weights + o[SMZ_VT_RES_B], threadIdx.x, blockDim.x);
+            smz_vision::tap_major<3>(tm + (6 + n * 2 + 0) * kConvTab, weights + q[SMZ_VP_RES_A], threadIdx.x, blockDim.x);
+            smz_vision::tap_major<3>(tm + (6 + n * 2 + 1) * kConvTab, weights + q[SMZ_VP_RES_B], threadIdx.x, blockDim.x);
+        }
     }
     // convolution / batch-norm / 1x1 weights from the workgroup's LDS copy (as the wave-per-leaf kernel: through the scalar
     // cache a convolution measured 2x slower here too)
@@ -384,7 +397,8 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
             lds_sync();
             float t[kC];
             const int ni = dyn ? 0 : 1;
-            smz_vision::conv3x3_t<4>(plane, pp, reinterpret_cast<const float4 *>(tm + (ni * 3 + 0) * smz_vision::kTapFloats), t);
+            if (kConvMfma) smz_vision::conv3x3_m<4>(plane, pp, tm + (ni * 3 + 0) * kConvTab, lane, t);
+            else smz_vision::conv3x3_t<4>(plane, pp, reinterpret_cast<const float4 *>(tm + (ni * 3 + 0) * kConvTab), t);
             lds_sync();
             {
                 const float *bn = uniform_ptr(small, o[SMZ_VT_BN_IN]);
@@ -392,9 +406,13 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
                 for (int c = 0; c < kC; c++) t[c] = fmaxf(t[c] * bn[c] + bn[kC + c], 0.f);
             }
             {
-                const float4 *wa = reinterpret_cast<const float4 *>(tm + (ni * 3 + 1) * smz_vision::kTapFloats), *wb = reinterpret_cast<const float4 *>(tm + (ni * 3 + 2) * smz_vision::kTapFloats);
+                const float *ta = tm + (ni * 3 + 1) * kConvTab, *tb = tm + (ni * 3 + 2) * kConvTab;
+                const float4 *wa = reinterpret_cast<const float4 *>(ta), *wb = reinterpret_cast<const float4 *>(tb);
                 const float *bn = uniform_ptr(small, o[SMZ_VT_RES_BN]);
-                for (int i = 0; i < d.L; i++) smz_vision::residual_block_t(plane, pp, active, wa, wb, bn, t);
+                for (int i = 0; i < d.L; i++) {
+                    if (kConvMfma) smz_vision::residual_block_m(plane, pp, active, ta, tb, bn, lane, t);
+                    else smz_vision::residual_block_t(plane, pp, active, wa, wb, bn, t);
+                }
             }
 #pragma unroll
             for (int c = 0; c < kC; c++) t[c] = fmaxf(t[c], 0.f);
@@ -407,9 +425,13 @@ __global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vi
             SMZ_VSTAMP(2)
             const int32_t *q = d.off + SMZ_V_PRED_BASE + (dyn ? 0 : SMZ_V_PRED_STRIDE);
             {
-                const float4 *wa = reinterpret_cast<const float4 *>(tm + (6 + ni * 2 + 0) * smz_vision::kTapFloats), *wb = reinterpret_cast<const float4 *>(tm + (6 + ni * 2 + 1) * smz_vision::kTapFloats);
+                const float *ta = tm + (6 + ni * 2 + 0) * kConvTab, *tb = tm + (6 + ni * 2 + 1) * kConvTab;
+                const float4 *wa = reinterpret_cast<const float4 *>(ta), *wb = reinterpret_cast<const float4 *>(tb);
                 const float *bn = uniform_ptr(small, q[SMZ_VP_RES_BN]);
-                for (int i = 0; i < d.L; i++) smz_vision::residual_block_t(plane, pp, active, wa, wb, bn, t);
+                for (int i = 0; i < d.L; i++) {
+                    if (kConvMfma) smz_vision::residual_block_m(plane, pp, active, ta, tb, bn, lane, t);
+                    else smz_vision::residual_block_t(plane, pp, active, wa, wb, bn, t);
+                }
             }
             const float xs[4] = {t[0], t[1], t[2], 0.f};
             mix_to_tile<kC>(F + kVW * kFS, leaf, p, active, xs, uniform_ptr(small, q[SMZ_VP_VMIX_W]), uniform_ptr(small, q[SMZ_VP_VMIX_B]));

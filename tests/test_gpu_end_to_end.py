@@ -439,7 +439,7 @@ def test_vision_family_heads_on_gpu_match_the_reference_tape(backend):
     """a22: the reference's ResNet-v2 family on the GPU -- the hand-written HIP kernels (HipVisionHeads:
     smz_vision_initial / smz_vision_recurrent) and the torch-ROCm module path (ModuleHeads) -- vs every network call the
     reference (torch CPU) recorded in vision_sims50.npz.  Accumulation orders differ from ATen's CPU kernels; tolerances
-    follow the measured errors (profiles/r02_head_errors.json): 1e-5 on hidden planes, 1e-6 on policies, 3e-5 relative
+    follow the measured errors (profiles/r02_head_errors.json; round 3: 1.2e-5): 2e-5 on hidden planes, 1e-6 on policies, 3e-5 relative
     + 2e-4 absolute on decoded scalars (inverse-transform cancellation)."""
     _, model_mod, _, _ = _mods()
     cfg, data = gu.load("vision_sims50")
@@ -458,7 +458,9 @@ def test_vision_family_heads_on_gpu_match_the_reference_tape(backend):
     fe.branch = torch.from_numpy(data["tape_branch"].reshape(-1).astype(np.uint8)).cuda()
     h2, rw, p2, v2 = heads.recurrent(fe)
     torch.cuda.synchronize()
-    torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(fe.B, -1)), rtol=0, atol=1e-5)
+    # (round 3: the 3x3 convolutions sum each row of taps as its own chain, (r0 + r1) + r2 -- one more association that is not
+    #  ATen's; measured 1.21e-5 on one of 29 400 hidden values, where the per-pixel min-max scaling divides by a small range)
+    torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(fe.B, -1)), rtol=0, atol=2e-5)
     torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(fe.B, -1)), rtol=0, atol=1e-6)
     torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=3e-5, atol=2e-4)
     torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=3e-5, atol=2e-4)
