@@ -80,7 +80,7 @@ __host__ __device__ inline RowGeom row_geom(int width) {
 }
 
 // numpy `seed(int)`: init_genrand (numpy/random/src/mt19937/mt19937.c mt19937_seed); pos = 624.
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 __global__ void __launch_bounds__(kWave) k_seed(Params P, const uint64_t *seeds) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
     if (tree >= P.B) return;
@@ -418,7 +418,7 @@ __device__ inline uint32_t *rng_tile_ptr(const Params &P) {
     return reinterpret_cast<uint32_t *>(smz_dyn_lds + n);
 }
 
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_root_init(Params P, const float *hidden, const float *policy,
                                                      const double *noise_override, int train) {
@@ -472,7 +472,7 @@ __device__ inline void fix_layout(Params &P, bool a_const, bool k_const) {
 
 // AEX (instantiated for the MAXA 2 and 4 buckets): the action count equals the bucket, so A (and K when KS > 0) are
 // compile-time constants in everything inlined below (see k_search_mlp).
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 template <int MAXA, int KS, bool AEX>
 __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_hidden, int32_t *last_action,
                                                   uint8_t *branch, float *mlp_input) {
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 template <int MAXA, int KS, bool FUSE_SELECT, bool AEX>
 __global__ void __launch_bounds__(kWave, MAXA > 16 ? 1 : SMZ_EB_WAVES) k_expand_backup(Params Pin, const float *hidden, const float *reward,
                                                          const float *policy, const float *value,
@@ -671,7 +671,7 @@ struct ActOut {              // smz_search_mlp_act: Game.policy_step folded into
     float *root_value;
 };
 constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
-#if SMZ_PART == 0 || SMZ_PART == 2 || SMZ_PART == 4
+#if SMZ_PART == 0 || SMZ_PART == 2 || SMZ_PART == 4 || SMZ_PART == 6
 // MSK: the handle has a per-tree on / off array (smz_set_active).  Without one the validity of a tree slot is a comparison
 // that is recomputed where needed; with one it is state that stays live through the search loop -- in the specialised
 // instantiation that costs scalar registers it does not have (35 -> 45 spilled, -3 % measured), so it exists both ways.
@@ -691,7 +691,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
     fix_layout(P, AEX, KS > 0);
     if (AEX) P.hs = (kFastS + 15) & ~15;
     float *lds = reinterpret_cast<float *>(smz_search_lds4);
-    static_assert(!TLDS || (AEX && KS > 0 && !MSK), "LDS-resident trees: the specialised unmasked instantiations only");
+    static_assert(!TLDS || (AEX && KS > 0), "LDS-resident trees: the specialised instantiations only");
     // LDS copy: everything but the representation matrices (TLDS: in the compact image)
     const smz_mlp_desc dl = TLDS ? smz_mlp::lds_desc_compact(d) : smz_mlp::lds_desc_without_rep(d);
     if (TLDS) smz_mlp::stage_weights_compact(lds, weights, d);
@@ -940,6 +940,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         const int n_blk = 1 + P.sims;                                    // root block + one expansion block per simulation
         for (int t = 0; t < tpw; t++) {
             if (tree0 + t >= P.B) break;
+            if (MSK && !__shfl((int)valid, t)) continue;             // a switched-off tree keeps what its last search left in HBM
             const uint32_t *src = P.nodes + (size_t)(wave * tpw + t) * P.tree_words;
             uint32_t *dst = nodes_global + (size_t)(tree0 + t) * (P.rb_words + (size_t)P.sims * gl_eb_words);
             for (int i = lane; i < P.rb_words; i += kWave) dst[i] = src[i];
@@ -958,7 +959,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits, double *priors, float *root_value,
                                                       float *child_reward) {
     const int tree = blockIdx.x * kWave + threadIdx.x;
@@ -977,7 +978,7 @@ __global__ void __launch_bounds__(kWave) k_root_stats(Params P, int32_t *visits,
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 template <int MAXA>
 __global__ void __launch_bounds__(kWave) k_act(Params P, double temperature, int32_t *action, double *policy,
                                                double *child_visits, float *root_value) {
@@ -1036,7 +1037,7 @@ __device__ inline void softmax_group(const float *row, int A, float *out, int li
     for (int i = li; i < A; i += lpr) out[i] = expf(row[i] - m) / den;
 }
 
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 __global__ void __launch_bounds__(256) k_support_decode(const float *logits, int S, float *out, int B, int lpr) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
     const int row = gid < B ? gid : B - 1;     // surplus groups recompute the last row (keeps shuffles convergent)
@@ -1045,7 +1046,7 @@ __global__ void __launch_bounds__(256) k_support_decode(const float *logits, int
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 __global__ void __launch_bounds__(256) k_policy_softmax(const float *logits, int A, float *out, int B, int lpr) {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpr, li = threadIdx.x % lpr;
     if (gid < B) softmax_group(logits + (size_t)gid * A, A, out + (size_t)gid * A, li, lpr);
@@ -1053,7 +1054,7 @@ __global__ void __launch_bounds__(256) k_policy_softmax(const float *logits, int
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 __global__ void __launch_bounds__(256) k_dynamics_epilogue(const float *state_dyn, const float *state_after,
                                                            const float *reward_logits, int ld, const uint8_t *branch,
                                                            int S, float *hidden_out, float *reward_out, int B, int lpr) {
@@ -1077,7 +1078,7 @@ __global__ void __launch_bounds__(256) k_dynamics_epilogue(const float *state_dy
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pred, const float *val_pred,
                                                              const float *pol_after, const float *val_after,
                                                              int ld, const uint8_t *branch, int A, int S,
@@ -1100,7 +1101,7 @@ __global__ void __launch_bounds__(256) k_prediction_epilogue(const float *pol_pr
 #endif
 
 // ---- synthetic env + trajectory record ---------------------------------------------------------------------------
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 // one thread per env; traj != nullptr: also appends the step's record -- one launch less per env step
 __global__ void __launch_bounds__(256) k_cartpole_step_env(EnvStep E, const int32_t *action, int B, const double *policy,
                                                            const double *child_visits, const float *root_value) {
@@ -1110,7 +1111,7 @@ __global__ void __launch_bounds__(256) k_cartpole_step_env(EnvStep E, const int3
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 // N(0,1) float32 observations of a stand-in env (Box-Muller on two counter-based uniforms), env-major [B][obs_dim]
 __global__ void __launch_bounds__(256) k_synthetic_obs(float *obs, int B, int obs_dim, uint64_t seed, long long first_env,
                                                        long long t) {
@@ -1126,7 +1127,7 @@ __global__ void __launch_bounds__(256) k_synthetic_obs(float *obs, int B, int ob
 //   [obs(obs_dim) | reward | terminated | policy(A) | action one-hot(A) | root_value | child_visits(A)]
 // One thread per float64 of the step's [B][F] slab: writes are contiguous across the whole slab and the observation
 // reads are contiguous per row, whatever obs_dim is (4 for CartPole, 28812 for a 98x98x3 frame).
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, int obs_dim, int A, const float *obs,
                                                    const float *reward, const uint8_t *terminated, const int32_t *action,
                                                    const double *policy, const double *child_visits,
@@ -1154,7 +1155,7 @@ __global__ void __launch_bounds__(256) k_traj_pack(double *traj, int T, int t, i
 
 // Game length of every env of a chunk: steps up to and including the first terminated one (chunk_to_games'/play_game's
 // cut, self_play.py:79-94), or T.
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T, int obs_dim, int A, int B, int ignore_term,
                                                       int32_t *length) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1172,7 +1173,7 @@ __global__ void __launch_bounds__(256) k_traj_lengths(const double *traj, int T,
 // last row of the game that row t of env e belongs to -- the row of its end flag (1 terminated / 2 step limit) + 1, or T
 // for the unfinished game at the end of the chunk; -1 for a row without a step (flag 3).  new_game == 0: rows behind the
 // first finished game belong to no game (the cut of k_traj_lengths).  length[e] = end of the env's first game.
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 __global__ void __launch_bounds__(256) k_traj_game_ends(const double *traj, int T, int obs_dim, int A, int B, int ignore_term,
                                                         int new_game, int32_t *length, int32_t *game_end) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1198,7 +1199,7 @@ __global__ void __launch_bounds__(256) k_traj_game_ends(const double *traj, int 
 // float32 -- f32(root_value) * f32(discount^td), then one f32 add per reward of the f64 product reward * discount^i
 // rounded to f32 -- and a chain past the end of the game starts from a Python 0 and stays float64.
 // abs_td = |float64(root_value[t]) - target| (make_priority before ** priority_scale).  Positions t >= length are 0.
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 __global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T, int obs_dim, int A, int B, int td,
                                                       const double *disc_pow, const int32_t *length, double *target,
                                                       double *abs_td, const int32_t *game_end = nullptr) {
@@ -1228,7 +1229,7 @@ __global__ void __launch_bounds__(256) k_traj_targets(const double *traj, int T,
 }
 #endif
 
-#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5
+#if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
 // div_by_count against the IEEE division, element-wise (inspection: tests pin the table-based quotients)
 __global__ void __launch_bounds__(256) k_debug_div_by_count(const double *x, const int32_t *n, int count, int N, double *out) {
     for (int i = threadIdx.x; i < N; i += blockDim.x) smz_dyn_lds[i] = i > 0 ? 1.0 / (double)i : 0.0;
@@ -1667,9 +1668,9 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
 
 #endif  // SMZ_PART != 2
 
-#if SMZ_PART == 0 || SMZ_PART == 2 || SMZ_PART == 4
-// The instantiations are split over two translation units by action bucket (compile time): SMZ_PART 2 holds the
-// buckets 2 and 4 and the ABI entry points, SMZ_PART 4 the buckets 8, 16 and 32.
+#if SMZ_PART == 0 || SMZ_PART == 2 || SMZ_PART == 4 || SMZ_PART == 6
+// The instantiations are split over three translation units (compile time): SMZ_PART 2 holds the action buckets 2 and 4 and
+// the ABI entry points, SMZ_PART 4 the buckets 8, 16 and 32, SMZ_PART 6 the instantiations with the trees in LDS.
 #if SMZ_PART == 4
 #define SMZ_SEARCH_LAUNCH smz_internal_search_launch_wide
 #define SMZ_SEARCH_DISPATCH(maxa, ...)                                        \
@@ -1704,10 +1705,44 @@ int smz_internal_search_launch_narrow(smz_handle *h, const smz_mlp_desc *desc, c
                                       int train, SearchActArgs a, const double *pow_table_host, smz_stream stream);
 int smz_internal_search_launch_wide(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
                                     int train, SearchActArgs a, const double *pow_table_host, smz_stream stream);
+// SMZ_PART 6: the instantiations that keep the workgroup's trees in LDS (P, geometry and LDS size come from the caller)
+int smz_internal_search_launch_tlds(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
+                                    int train, SearchActArgs a, Params P, int kWaves, int blocks, size_t lds_t, smz_stream stream);
 // smz_search_reg.hip: the register-resident / matrix-core kernel for the shipped network shape
 int smz_internal_search_launch_reg(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
                                    int train, double temperature, int32_t *action, double *policy, double *child_visits,
                                    float *root_value, const double *pow_table_host, smz_stream stream);
+#if SMZ_PART == 0 || SMZ_PART == 6
+// k_search_mlp<MA, 2, 1, false, true, MSK, PHX, TLDS = true>: plain | masked (smz_set_active) | Philox handles.  The caller
+// (SMZ_SEARCH_LAUNCH of SMZ_PART 2) has validated everything and computed the geometry.
+int smz_internal_search_launch_tlds(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
+                                    int train, SearchActArgs a, Params P, int kWaves, int blocks, size_t lds_t, smz_stream stream) {
+    const ActOut act = {a.temperature, a.action, a.policy, a.child_visits, a.root_value};
+#define SMZ_LAUNCH_TLDS(MA, MSK, PHX)                                                                                  \
+    {                                                                                                                  \
+        static size_t granted_dev[64] = {};                                                                            \
+        size_t &granted = granted_dev[h->cfg.device & 63];                                                             \
+        if (lds_t > granted) {                                                                                         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, 2, 1, false, true, MSK, PHX, true>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t) != hipSuccess)             \
+                return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                            \
+            granted = lds_t;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_search_mlp<MA, 2, 1, false, true, MSK, PHX, true>), dim3(blocks), dim3(kWaves * kWave),  \
+                           lds_t, (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act, a.env);             \
+        snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<%d, 2, 1, false, true, %s, %s, true>", MA,      \
+                 MSK ? "true" : "false", PHX ? "true" : "false");                                                      \
+    }
+    if (h->maxa == 2) {
+        if (P.philox) SMZ_LAUNCH_TLDS(2, true, true) else if (P.active) SMZ_LAUNCH_TLDS(2, true, false) else SMZ_LAUNCH_TLDS(2, false, false)
+    } else {
+        if (P.philox) SMZ_LAUNCH_TLDS(4, true, true) else if (P.active) SMZ_LAUNCH_TLDS(4, true, false) else SMZ_LAUNCH_TLDS(4, false, false)
+    }
+#undef SMZ_LAUNCH_TLDS
+    return SMZ_OK;
+}
+#endif
+#if SMZ_PART != 6
 int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
                       SearchActArgs a, const double *pow_table_host, smz_stream stream) {
     const ActOut act = {a.temperature, a.action, a.policy, a.child_visits, a.root_value};
@@ -1782,32 +1817,17 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     // (the specialised instantiation is the parity-mode path: a Philox handle runs the generic one)
     const bool fast = P.A == h->maxa && tpw == kFastTpw && desc->S == kFastS && desc->H == kFastH && desc->L == kFastL;
 #if SMZ_PART != 4
-    {   // LDS-resident trees (k_search_mlp<..., TLDS>): the specialised, unmasked, MT19937 instantiation when the workgroup's
-        // trees fit next to the compact weight image (checkpoint-421 shape, 2 actions: up to ~62 simulations); SMZ_SEARCH_TLDS=0
-        // keeps the trees in global memory (A/B runs)
+    {   // LDS-resident trees (k_search_mlp<..., TLDS>, compiled in their own translation unit, SMZ_PART 6): the specialised
+        // instantiations -- plain, masked (smz_set_active) and Philox -- when the workgroup's trees fit next to the compact
+        // weight image (checkpoint-421 shape, 2 actions: up to ~62 simulations); SMZ_SEARCH_TLDS=0 keeps the trees in global
+        // memory (A/B runs)
         const MegaLds mt = mega_lds(*desc, P, tpw, true, kWaves);
         const size_t lds_t = ((size_t)mt.trees_off + (size_t)kWaves * tpw * mt.tree_words) * sizeof(float);
         const char *te = getenv("SMZ_SEARCH_TLDS");
-        const bool tlds = fast && !P.active && !P.philox && !(P.stats || P.dbg) && h->K == 2 && h->maxa <= 4 &&
-                          lds_t <= 160 * 1024 && !(te && atoi(te) == 0);
+        const bool tlds = fast && !(P.stats || P.dbg) && h->K == 2 && h->maxa <= 4 && lds_t <= 160 * 1024 && !(te && atoi(te) == 0);
         if (tlds) {
-#define SMZ_LAUNCH_TLDS(MA)                                                                                            \
-            {                                                                                                          \
-                static size_t granted_dev[64] = {};                                                                    \
-                size_t &granted = granted_dev[h->cfg.device & 63];                                                     \
-                if (lds_t > granted) {                                                                                 \
-                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, 2, 1, false, true, false, false, true>), \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t) != hipSuccess)     \
-                        return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                    \
-                    granted = lds_t;                                                                                   \
-                }                                                                                                      \
-                hipLaunchKernelGGL((k_search_mlp<MA, 2, 1, false, true, false, false, true>), dim3(blocks),            \
-                                   dim3(kWaves * kWave), lds_t, (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, \
-                                   act, a.env);                                                                        \
-                snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<%d, 2, 1, false, true, false, false, true>", MA); \
-            }
-            if (h->maxa == 2) SMZ_LAUNCH_TLDS(2) else SMZ_LAUNCH_TLDS(4)
-#undef SMZ_LAUNCH_TLDS
+            const int rc = smz_internal_search_launch_tlds(h, desc, weights_dev, obs_dev, train, a, P, kWaves, blocks, lds_t, stream);
+            if (rc != SMZ_OK) return rc;
             h->root_ready = true;
             h->selected = false;
             return launch_check();
@@ -1831,9 +1851,10 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     h->selected = false;
     return launch_check();
 }
+#endif  // SMZ_PART != 6
 
 extern "C" {
-#if SMZ_PART != 4
+#if SMZ_PART != 4 && SMZ_PART != 6
 int smz_search_mlp(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev, int train,
                    smz_stream stream) {
     return smz_internal_search_launch_narrow(h, desc, weights_dev, obs_dev, train,
@@ -1874,7 +1895,7 @@ int smz_search_mlp_act_cartpole(smz_handle *h, const smz_mlp_desc *desc, const f
                                              SearchActArgs{temperature, action_dev, policy_dev, child_visits_dev, root_value_dev, E},
                                              pow_table_host, stream);
 }
-#endif  // SMZ_PART != 4
+#endif  // SMZ_PART != 4 && SMZ_PART != 6
 
 #endif  // SMZ_PART != 1
 

@@ -755,8 +755,10 @@ def test_vision_single_launch_search_with_more_actions_equals_stepwise(A, L, B, 
         assert np.array_equal(ka, kb) and pa == pb
 
 
-@pytest.mark.parametrize("wname,B,sims", [("weights_ckpt421", 2570, 50), ("weights_lunar_L0", 4096, 30), ("weights_ckpt421", 2049, 60)])
-def test_lds_resident_trees_equal_trees_in_global_memory(wname, B, sims, monkeypatch):
+@pytest.mark.parametrize("wname,B,sims,mode", [("weights_ckpt421", 2570, 50, "plain"), ("weights_lunar_L0", 4096, 30, "plain"),
+                                               ("weights_ckpt421", 2049, 60, "plain"), ("weights_ckpt421", 4096, 40, "mask"),
+                                               ("weights_lunar_L0", 3000, 25, "mask"), ("weights_ckpt421", 4096, 40, "philox")])
+def test_lds_resident_trees_equal_trees_in_global_memory(wname, B, sims, mode, monkeypatch):
     """k_search_mlp<..., TLDS> (round 3: the workgroup's trees live in LDS for the search, blocks packed at 48 bytes, weights in
     the compact LDS image, written back to the 64-byte-granule layout at the end) against the same kernel with the trees in
     global memory (SMZ_SEARCH_TLDS=0): ragged batches (the last workgroup partly empty), 4 actions, the largest simulation count
@@ -766,21 +768,34 @@ def test_lds_resident_trees_equal_trees_in_global_memory(wname, B, sims, monkeyp
     model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
     heads = model.heads("cuda:0", backend="hip")
     obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(5)).mul(0.3).cuda()
+    import stochastic_muzero_amd as smz
+    # mask: a third of the trees switched off for the second search (whole waves, single trees of a wave, the ragged tail)
+    active = torch.ones(B, dtype=torch.uint8, device="cuda")
+    active[torch.arange(B, device="cuda") % 3 == 1] = 0
+    active[64:128] = 0
     res = []
     for tlds in ("1", "0"):
         monkeypatch.setenv("SMZ_SEARCH_TLDS", tlds)
         m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997,
-                                 root_exploration_fraction=0.25, use_graph=False, single_launch=True)
+                                 root_exploration_fraction=0.25, use_graph=False, single_launch=True,
+                                 rng_mode=smz._lib.RNG_PHILOX if mode == "philox" else smz._lib.RNG_MT19937_NUMPY)
         m.seed(np.arange(B, dtype=np.uint64) + 3)
+        if mode == "mask":
+            m.set_active(torch.ones(B, dtype=torch.uint8, device="cuda"))
         for rep in range(2):
+            if mode == "mask" and rep == 1:
+                m.set_active(active)             # the switched-off trees must keep the first search's trees
             e = m.run(obs, heads, train=True, act_temperature=1.0)
         assert m._single is True and e.last_kernel().endswith("true>" if tlds == "1" else "false>"), e.last_kernel()
+        want_flags = {"plain": "false, false", "mask": "true, false", "philox": "true, true"}[mode]
+        assert want_flags in e.last_kernel(), e.last_kernel()
         visits, priors, rv, cr = e.root_stats()
         action, policy, cv, _ = e.act(1.0)
         torch.cuda.synchronize()
         out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr, action, policy, cv)]
-        picks = (0, 1, 15, 16, 17, B // 2, B - 2, B - 1)
-        res.append((out, [e.dump_tree(i) for i in picks], [e.get_rng_state(i) for i in picks]))
+        picks = (0, 1, 15, 16, 17, 64, 65, 100, 127, 128, B // 2, B - 2, B - 1)
+        rng = [e.philox_position(i) for i in picks] if mode == "philox" else [e.get_rng_state(i) for i in picks]
+        res.append((out, [e.dump_tree(i) for i in picks], rng))
     assert (res[0][0][0].sum(1) == sims).all()
     for a, b in zip(res[0][0], res[1][0]):
         assert np.array_equal(a, b)
