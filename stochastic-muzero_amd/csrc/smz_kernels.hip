@@ -1713,7 +1713,7 @@ int smz_internal_search_launch_reg(smz_handle *h, const smz_mlp_desc *desc, cons
                                    int train, double temperature, int32_t *action, double *policy, double *child_visits,
                                    float *root_value, const double *pow_table_host, smz_stream stream);
 #if SMZ_PART == 0 || SMZ_PART == 6
-// k_search_mlp<MA, 2, 1, false, true, MSK, PHX, TLDS = true>: plain | masked (smz_set_active) | Philox handles.  The caller
+// k_search_mlp<MA, 2, 1, false, true, true, PHX, TLDS = true>: masked (smz_set_active) | Philox handles.  The caller
 // (SMZ_SEARCH_LAUNCH of SMZ_PART 2) has validated everything and computed the geometry.
 int smz_internal_search_launch_tlds(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
                                     int train, SearchActArgs a, Params P, int kWaves, int blocks, size_t lds_t, smz_stream stream) {
@@ -1734,9 +1734,9 @@ int smz_internal_search_launch_tlds(smz_handle *h, const smz_mlp_desc *desc, con
                  MSK ? "true" : "false", PHX ? "true" : "false");                                                      \
     }
     if (h->maxa == 2) {
-        if (P.philox) SMZ_LAUNCH_TLDS(2, true, true) else if (P.active) SMZ_LAUNCH_TLDS(2, true, false) else SMZ_LAUNCH_TLDS(2, false, false)
+        if (P.philox) SMZ_LAUNCH_TLDS(2, true, true) else SMZ_LAUNCH_TLDS(2, true, false)
     } else {
-        if (P.philox) SMZ_LAUNCH_TLDS(4, true, true) else if (P.active) SMZ_LAUNCH_TLDS(4, true, false) else SMZ_LAUNCH_TLDS(4, false, false)
+        if (P.philox) SMZ_LAUNCH_TLDS(4, true, true) else SMZ_LAUNCH_TLDS(4, true, false)
     }
 #undef SMZ_LAUNCH_TLDS
     return SMZ_OK;
@@ -1825,13 +1825,37 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
         const size_t lds_t = ((size_t)mt.trees_off + (size_t)kWaves * tpw * mt.tree_words) * sizeof(float);
         const char *te = getenv("SMZ_SEARCH_TLDS");
         const bool tlds = fast && !(P.stats || P.dbg) && h->K == 2 && h->maxa <= 4 && lds_t <= 160 * 1024 && !(te && atoi(te) == 0);
-        if (tlds) {
+        if (tlds && (P.active || P.philox)) {        // masked / Philox handles: SMZ_PART 6
             const int rc = smz_internal_search_launch_tlds(h, desc, weights_dev, obs_dev, train, a, P, kWaves, blocks, lds_t, stream);
             if (rc != SMZ_OK) return rc;
             h->root_ready = true;
             h->selected = false;
             return launch_check();
         }
+#if SMZ_PART == 0 || SMZ_PART == 2
+        if (tlds) {                                  // the plain instantiation (the headline's) stays in this translation unit
+#define SMZ_LAUNCH_TLDS(MA)                                                                                            \
+            {                                                                                                          \
+                static size_t granted_dev[64] = {};                                                                    \
+                size_t &granted = granted_dev[h->cfg.device & 63];                                                     \
+                if (lds_t > granted) {                                                                                 \
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<MA, 2, 1, false, true, false, false, true>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t) != hipSuccess)     \
+                        return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                    \
+                    granted = lds_t;                                                                                   \
+                }                                                                                                      \
+                hipLaunchKernelGGL((k_search_mlp<MA, 2, 1, false, true, false, false, true>), dim3(blocks),            \
+                                   dim3(kWaves * kWave), lds_t, (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, \
+                                   act, a.env);                                                                        \
+                snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<%d, 2, 1, false, true, false, false, true>", MA); \
+            }
+            if (h->maxa == 2) SMZ_LAUNCH_TLDS(2) else SMZ_LAUNCH_TLDS(4)
+#undef SMZ_LAUNCH_TLDS
+            h->root_ready = true;
+            h->selected = false;
+            return launch_check();
+        }
+#endif
     }
     if ((P.stats || P.dbg) && fast && !P.philox && (P.dbg & 32) && h->maxa == 2 && h->K == 2) {
         // phase stamps of the specialised instantiation itself (SMZ_DEBUG_SKIP=48), for the headline geometry only
