@@ -285,6 +285,12 @@ int smz_vision_layout(smz_vision_desc *desc);
  * channels), policy_out_dev [B,A] (softmax).  One 256-thread workgroup per frame. */
 int smz_vision_initial(const smz_vision_desc *desc, const float *weights_dev, const float *frames_dev,
                        float *hidden_out_dev, float *policy_out_dev, int B, smz_stream stream);
+/* ... which also appends the frames it reads to the trajectory record: frames_copy_dev [B,3,98,98] f32 (NULL: no copy)
+ * receives frames_dev, written by the threads of the stem convolution from the pixel pairs they have just loaded --
+ * Game.observations.append of the frame the search is about to run on (game.py:263-264: the observation after the previous
+ * action), without reading it from HBM a second time.  Both frame pointers 8-byte aligned (SMZ_ERR_INVALID otherwise). */
+int smz_vision_initial_record(const smz_vision_desc *desc, const float *weights_dev, const float *frames_dev,
+                              float *frames_copy_dev, float *hidden_out_dev, float *policy_out_dev, int B, smz_stream stream);
 /* Frame ingest: n_frames rendered frames [n][H][W][3] uint8 (as a host environment uploads them) -> the
  * [*,3,out_h,out_w] float32 tensor smz_vision_initial reads: ToTensor (CHW, / 255) + bilinear Resize without antialias,
  * align_corners = False -- Game.transform_rgb of the reference (game.py:82-89, 142-143), ATen's upsample_bilinear2d

@@ -93,6 +93,7 @@ SIGNATURES = {
     "smz_mlp_recurrent_wide": (C.c_int, [C.POINTER(MlpDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_vision_layout": (C.c_int, [C.POINTER(VisionDesc)]),
     "smz_vision_initial": (C.c_int, [C.POINTER(VisionDesc), _P, _P, _P, _P, C.c_int, _P]),
+    "smz_vision_initial_record": (C.c_int, [C.POINTER(VisionDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_vision_recurrent": (C.c_int, [C.POINTER(VisionDesc), _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "smz_search_mlp_act": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
     "smz_search_mlp_act_cartpole": (C.c_int, [_P, C.POINTER(MlpDesc), _P, C.c_int, C.c_double, _P, _P, _P, _P, _P,

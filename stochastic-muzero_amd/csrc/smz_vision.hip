@@ -143,6 +143,38 @@ struct RepLds {
     WaveLds head;          // root prediction (wave 0)
 };
 
+// Barrier between the representation's LDS stages: waits for the wave's LDS traffic only, so the frame-copy loads and stores
+// below stay in flight across it (__syncthreads also drains the vector-memory counter).
+__device__ inline void rep_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The trajectory record of the frame (smz_vision_initial_record), spread over the launch: all workgroups read their frames at
+// the same moment -- the stem runs at HBM speed -- so a copy issued there only queues behind it.  Each residual block moves a
+// few 16-byte pieces per thread instead: loaded before a convolution, stored after it, nothing waits in between.
+struct FrameCopy {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    static constexpr int kPieces = 3 * kFrame * kFrame / 4;
+    const v4f *src;
+    v4f *dst;            // nullptr: no record
+    int at;              // next piece of thread 0
+    template <int N> __device__ inline void load(v4f (&r)[N]) const {
+        if (!dst) return;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const int i = at + k * kRepThreads + (int)threadIdx.x;
+            if (i < kPieces) r[k] = __builtin_nontemporal_load(src + i);
+        }
+    }
+    template <int N> __device__ inline void store(const v4f (&r)[N]) {
+        if (!dst) return;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const int i = at + k * kRepThreads + (int)threadIdx.x;
+            if (i < kPieces) __builtin_nontemporal_store(r[k], dst + i);
+        }
+        at += N * kRepThreads;
+    }
+};
+
 // u <- border-padded f(src) for a [C][N][N] map; f = relu(bn(.)) when bn != nullptr, identity otherwise
 template <int C>
 __device__ inline void pad_store(float *u, const float *src, int N, const float *bn) {
@@ -156,7 +188,7 @@ __device__ inline void pad_store(float *u, const float *src, int N, const float 
         }
         u[i] = val;
     }
-    __syncthreads();
+    rep_barrier();
 }
 // zero border of a [C][N+2][N+2] buffer whose interior a convolution is about to fill
 template <int C>
@@ -215,7 +247,7 @@ __device__ inline void conv_map(float *dst, const float *u, int Nin, int Nout, i
             dst[j] = res ? acc[oc] + res[j] : acc[oc];
         }
     }
-    __syncthreads();
+    rep_barrier();
 }
 // the same convolution writing relu(bn(conv)) into the interior of the zero-bordered buffer `un` (same size, stride 1)
 template <int C>
@@ -228,18 +260,24 @@ __device__ inline void conv_bn_pad(float *un, const float *u, int N, const float
 #pragma unroll
         for (int oc = 0; oc < C; oc++) un[(oc * P + y + 1) * P + x + 1] = fmaxf(acc[oc] * bn[oc] + bn[C + oc], 0.f);
     }
-    __syncthreads();
+    rep_barrier();
 }
 
 // v2 residual block on a map: t += convA(f(convB(f(convA(f(t)))))), f = relu(bn(.)) with ONE batch-norm
 // (neural_network_vision_model.py:41-79).  `fresh`: the borders of l.v are not known to be zero for this N yet.
-template <int C>
-__device__ inline void residual_map(RepLds &l, int N, const float *wa, const float *wb, const float *bn, bool fresh) {
+// `fc`: NP pieces of the frame copy per thread ride along with each of the three convolutions.
+template <int C, int NP>
+__device__ inline void residual_map(RepLds &l, int N, const float *wa, const float *wb, const float *bn, bool fresh, FrameCopy &fc) {
+    FrameCopy::v4f r[NP];
     if (fresh) zero_border<C>(l.v, N);
+    fc.load(r);
     pad_store<C>(l.u, l.t, N, bn);                     // (its barrier also covers the border zeroing)
     conv_bn_pad<C>(l.v, l.u, N, wa, bn);
+    fc.store(r); fc.load(r);
     conv_bn_pad<C>(l.u, l.v, N, wb, bn);               // l.u's borders are zero from pad_store
+    fc.store(r); fc.load(r);
     conv_map<C, C>(l.t, l.u, N, N, 1, wa, l.t);        // each thread reads and writes only its own pixels of t
+    fc.store(r);
 }
 
 // AvgPool2d(3, stride 2, padding 1), count_include_pad: sum of the zero-padded window / 9
@@ -254,7 +292,7 @@ __device__ inline void pool_map(RepLds &l, int Nin, int Nout) {
         for (int t = 0; t < 9; t++) s += l.u[(c * P + 2 * y + t / 3) * P + 2 * x + t % 3];
         l.t[i] = s / 9.0f;
     }
-    __syncthreads();
+    rep_barrier();
 }
 
 // (4 workgroups per CU: the register cap costs a few spills but hides the barrier chain better: 223 -> 204 us)
@@ -263,6 +301,7 @@ __device__ inline void pool_map(RepLds &l, int Nin, int Nout) {
 #endif
 __global__ void __launch_bounds__(kRepThreads, SMZ_REP_WGS) k_vision_initial(smz_vision_desc d, const float *__restrict__ weights,
                                                                 const float *__restrict__ frames,
+                                                                float *__restrict__ frames_copy,
                                                                 float *__restrict__ hidden_out,
                                                                 float *__restrict__ policy_out) {
     __shared__ RepLds l;
@@ -270,8 +309,11 @@ __global__ void __launch_bounds__(kRepThreads, SMZ_REP_WGS) k_vision_initial(smz
     const float *f = frames + (size_t)row * 3 * kFrame * kFrame;
     const int32_t *o = d.off + SMZ_V_REP_BASE;
     SMZ_STAMP_INIT();
-    // stem: conv3x3 stride 2 pad 1, 3 -> 1 channels, 98 -> 49, straight from global memory
+    // stem: conv3x3 stride 2 pad 1, 3 -> 1 channels, 98 -> 49, straight from global memory (it runs at HBM speed: 118 MB of
+    // frames in ~16 us at 1024 frames).  Output pixel (y, x) reads its taps kx = 1, 2 as ONE aligned 8-byte load per (channel,
+    // row) -- consecutive lanes read consecutive 8 bytes -- and kx = 0 as a single float.
     {
+        typedef float v2f __attribute__((ext_vector_type(2)));
         const float *w = weights + o[SMZ_VR_STEM];
         for (int i = threadIdx.x; i < 49 * 49; i += kRepThreads) {       // (two pixels per trip measured slower: 60.7 k vs 54.8 k cycles)
             const int y = i / 49, x = i % 49;
@@ -279,20 +321,27 @@ __global__ void __launch_bounds__(kRepThreads, SMZ_REP_WGS) k_vision_initial(smz
 #pragma unroll
             for (int ic = 0; ic < 3; ic++)
 #pragma unroll
-                for (int t = 0; t < 9; t++) {
-                    const int yy = 2 * y - 1 + t / 3, xx = 2 * x - 1 + t % 3;
-                    const float val = (yy >= 0 && yy < kFrame && xx >= 0 && xx < kFrame) ? f[(ic * kFrame + yy) * kFrame + xx] : 0.f;
-                    acc = fmaf(w[ic * 9 + t], val, acc);
+                for (int ky = 0; ky < 3; ky++) {
+                    const int yy = 2 * y - 1 + ky, at = (ic * kFrame + yy) * kFrame + 2 * x;      // (yy <= 97, 2x + 1 <= 97)
+                    const bool in = ky > 0 || y > 0;
+                    const v2f c = in ? *reinterpret_cast<const v2f *>(f + at) : v2f{0.f, 0.f};
+                    const float lft = (in && x > 0) ? f[at - 1] : 0.f;
+                    acc = fmaf(w[ic * 9 + ky * 3 + 0], lft, acc);
+                    acc = fmaf(w[ic * 9 + ky * 3 + 1], c.x, acc);
+                    acc = fmaf(w[ic * 9 + ky * 3 + 2], c.y, acc);
                 }
             l.t[i] = acc;
         }
-        __syncthreads();
+        rep_barrier();
     }
+    // the frame's copy into the trajectory record: 30 pieces per thread over the residual blocks (6 + 12 + 9 + 3 >= 28.2)
+    FrameCopy fc{reinterpret_cast<const FrameCopy::v4f *>(f),
+                 frames_copy ? reinterpret_cast<FrameCopy::v4f *>(frames_copy + (size_t)row * 3 * kFrame * kFrame) : nullptr, 0};
     SMZ_RSTAMP(0);
     {
         const float *wa = weights + o[SMZ_VR_NARROW_A], *wb = weights + o[SMZ_VR_NARROW_B], *bn = weights + o[SMZ_VR_NARROW_BN];
-        residual_map<1>(l, 49, wa, wb, bn, true);
-        residual_map<1>(l, 49, wa, wb, bn, false);
+        residual_map<1, 1>(l, 49, wa, wb, bn, true, fc);
+        residual_map<1, 1>(l, 49, wa, wb, bn, false, fc);
     }
     SMZ_RSTAMP(1);
     // widen: conv3x3 stride 2, 1 -> 3 channels, 49 -> 25
@@ -301,19 +350,19 @@ __global__ void __launch_bounds__(kRepThreads, SMZ_REP_WGS) k_vision_initial(smz
     SMZ_RSTAMP(2);
     {
         const float *wa = weights + o[SMZ_VR_WIDE_A], *wb = weights + o[SMZ_VR_WIDE_B], *bn = weights + o[SMZ_VR_WIDE_BN];
-        residual_map<3>(l, 25, wa, wb, bn, true);
-        residual_map<3>(l, 25, wa, wb, bn, false);
+        residual_map<3, 2>(l, 25, wa, wb, bn, true, fc);
+        residual_map<3, 2>(l, 25, wa, wb, bn, false, fc);
         SMZ_RSTAMP(3);
         pool_map<3>(l, 25, 13);
         SMZ_RSTAMP(4);
-        residual_map<3>(l, 13, wa, wb, bn, true);
-        residual_map<3>(l, 13, wa, wb, bn, false);
-        residual_map<3>(l, 13, wa, wb, bn, false);
+        residual_map<3, 1>(l, 13, wa, wb, bn, true, fc);
+        residual_map<3, 1>(l, 13, wa, wb, bn, false, fc);
+        residual_map<3, 1>(l, 13, wa, wb, bn, false, fc);
         SMZ_RSTAMP(5);
         pool_map<3>(l, 13, 7);
         SMZ_RSTAMP(6);
     }
-    residual_map<3>(l, 7, weights + o[SMZ_VR_LAST_A], weights + o[SMZ_VR_LAST_B], weights + o[SMZ_VR_LAST_BN], true);
+    residual_map<3, 1>(l, 7, weights + o[SMZ_VR_LAST_A], weights + o[SMZ_VR_LAST_B], weights + o[SMZ_VR_LAST_BN], true, fc);
     SMZ_RSTAMP(7);
     // wave 0: per-pixel scaling, hidden state out, root policy (the root value is discarded, mcts:319-321)
     if (threadIdx.x < kWave) {
@@ -393,12 +442,18 @@ int smz_vision_layout(smz_vision_desc *d) {
     return fill_layout(d);
 }
 
+int smz_vision_initial_record(const smz_vision_desc *d, const float *weights_dev, const float *frames_dev, float *frames_copy_dev,
+                              float *hidden_out_dev, float *policy_out_dev, int B, smz_stream stream) {
+    if (vision_check(d, weights_dev) != SMZ_OK || !frames_dev || !hidden_out_dev || !policy_out_dev || B < 1) return SMZ_ERR_INVALID;
+    // (8-byte loads of pixel pairs; 16-byte pieces of the frame copy; a frame is 7203 of them)
+    if (((uintptr_t)frames_dev & 7) || (frames_copy_dev && (((uintptr_t)frames_dev | (uintptr_t)frames_copy_dev) & 15))) return SMZ_ERR_INVALID;
+    hipLaunchKernelGGL(k_vision_initial, dim3(B), dim3(kRepThreads), 0, (hipStream_t)stream, *d, weights_dev, frames_dev,
+                       frames_copy_dev, hidden_out_dev, policy_out_dev);
+    return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
+}
 int smz_vision_initial(const smz_vision_desc *d, const float *weights_dev, const float *frames_dev, float *hidden_out_dev,
                        float *policy_out_dev, int B, smz_stream stream) {
-    if (vision_check(d, weights_dev) != SMZ_OK || !frames_dev || !hidden_out_dev || !policy_out_dev || B < 1) return SMZ_ERR_INVALID;
-    hipLaunchKernelGGL(k_vision_initial, dim3(B), dim3(kRepThreads), 0, (hipStream_t)stream, *d, weights_dev, frames_dev,
-                       hidden_out_dev, policy_out_dev);
-    return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;
+    return smz_vision_initial_record(d, weights_dev, frames_dev, nullptr, hidden_out_dev, policy_out_dev, B, stream);
 }
 
 int smz_vision_recurrent(const smz_vision_desc *d, const float *weights_dev, const float *parent_hidden_dev, int ld,

@@ -274,6 +274,7 @@ class HipVisionHeads:
     packed once from the five modules into the layout documented at smz_vision_desc (include/smz.h)."""
     wants_mlp_input, wants_parent_hidden = False, True
     is_rgb = True
+    records_frames = True       # initial(obs, record=...) appends the frames to the trajectory record in the same launch
     # index constants of include/smz.h
     _T = dict(CONV_IN=0, BN_IN=1, RES_A=2, RES_B=3, RES_BN=4, MIX_W=5, MIX_B=6, TOWER=7, STRIDE=13, BASE=0)
     _P = dict(RES_A=0, RES_B=1, RES_BN=2, VMIX_W=3, VMIX_B=4, VTOWER=5, PMIX_W=11, PMIX_B=12, PTOWER=13, STRIDE=19, BASE=26)
@@ -363,12 +364,16 @@ class HipVisionHeads:
             t = self._buf[name] = torch.empty(*shape, dtype=dtype, device=self.device)
         return t
 
-    def initial(self, obs):
+    def initial(self, obs, record=None):
+        """`record` ([B, 3*98*98] or [B,3,98,98] float32, contiguous): the launch also copies the frames there -- the trajectory
+        record of the observation, written by the threads that read it (smz_vision_initial_record)."""
         B = obs.shape[0]
         assert obs.dtype == torch.float32 and obs.is_contiguous() and tuple(obs.shape[1:]) == (3, 98, 98)
+        assert record is None or (record.dtype == torch.float32 and record.is_contiguous() and record.numel() == obs.numel())
         hidden, policy = self._out("h0", (B, 147)), self._out("p0", (B, self.A))
-        _lib.check(self.lib.smz_vision_initial(C.byref(self.desc), _ptr(self.weights), _ptr(obs), _ptr(hidden),
-                                               _ptr(policy), B, _stream(self.device)))
+        _lib.check(self.lib.smz_vision_initial_record(C.byref(self.desc), _ptr(self.weights), _ptr(obs),
+                                                      None if record is None else _ptr(record), _ptr(hidden),
+                                                      _ptr(policy), B, _stream(self.device)))
         return hidden, policy
 
     def recurrent(self, engine):

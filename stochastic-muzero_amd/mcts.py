@@ -175,13 +175,21 @@ class BatchedMCTS(_Hyper):
             self._search(self._static_obs, heads, train)
         self._graph, self._graph_key = g, key
 
-    def run(self, observations, heads, train=True, act_temperature=None, env_step=None):
+    def run(self, observations, heads, train=True, act_temperature=None, env_step=None, record_obs=None):
         """observations: [B, ...] float32 tensor on the engine's device.  Returns the engine; the search has been
         enqueued on the current stream (read results with engine.root_stats() / engine.act()).
         With HipMlpHeads the whole search is ONE kernel launch (smz_search_mlp) when it fits in LDS; otherwise the
         step-wise kernels run, captured in a HIP graph unless use_graph is off.
         `env_step` (envs.CartPoleVec.fused_step): the single launch also steps the built-in env and appends the record;
-        `engine.env_stepped` says whether it did (any other path leaves the env to the caller)."""
+        `engine.env_stepped` says whether it did (any other path leaves the env to the caller).
+        `record_obs` (a float32 tensor the size of `observations`): the representation launch of the vision family copies the
+        frames it reads there (smz_vision_initial_record); `engine.obs_recorded` says whether that happened."""
+        eng = self._run(observations, heads, train, act_temperature, env_step, record_obs)
+        eng.obs_recorded = record_obs is not None and self._recorded
+        return eng
+
+    def _run(self, observations, heads, train, act_temperature, env_step, record_obs):
+        self._recorded = False
         # (single_launch_max_trees: where the step-wise kernels overtake the single launch)
         if (self.single_launch and isinstance(getattr(heads, "desc", None), _lib.MlpDesc) and self._single is not False
                 and self.num_trees <= self.single_launch_max_trees):
@@ -205,7 +213,8 @@ class BatchedMCTS(_Hyper):
         # vision_model heads: representation per frame (its own launch), then the whole search in one launch
         if (self.single_launch and isinstance(getattr(heads, "desc", None), _lib.VisionDesc) and self._single is not False
                 and self.num_trees <= self.single_launch_max_trees):
-            hidden, policy = heads.initial(observations)
+            hidden, policy = heads.initial(observations, **({} if record_obs is None else dict(record=record_obs)))
+            self._recorded = record_obs is not None
             eng = self._ensure_engine(policy.shape[1], hidden.shape[1])
             if getattr(self, "_pending_seed", None) is not None:
                 eng.seed(self._pending_seed)

@@ -62,6 +62,15 @@ class TrajectoryChunk:
         self.F = _lib.load().smz_traj_floats(self.rec_obs_dim, self.A)
         self.data = torch.zeros(self.T, self.B, self.F, dtype=torch.float64, device=device)
         self.obs = None if self.rec_obs_dim else torch.zeros(self.T, self.B, self.obs_dim, dtype=torch.float32, device=device)
+        self.owed_obs = None        # (slot, tensor): frames of step `slot` that the next representation launch will copy
+
+    def flush_obs(self):
+        """Copies frames whose record was left to a representation launch that has not come (end of a play_games call, a
+        search path that does not record)."""
+        if self.owed_obs is not None:
+            t, frames = self.owed_obs
+            self.obs[t].copy_(frames.reshape(self.B, -1))
+            self.owed_obs = None
 
     def fields(self, data=None):
         d = self.data if data is None else data
@@ -163,7 +172,19 @@ def _play_step(env, heads, mcts, chunk, t, temperature, train=True):
     263-267).  The single code path behind play_games and play_games_grouped."""
     fused = getattr(env, "fused_step", None)     # built-in env + single-launch search: ONE launch per env step
     env_step = fused(chunk.data, t) if fused is not None else None
-    eng = mcts.run(env.obs, heads, train=train, act_temperature=temperature, **({} if env_step is None else dict(env_step=env_step)))
+    kw = {} if env_step is None else dict(env_step=env_step)
+    # image observations: the frame appended at the previous step IS the observation this search starts from, so the
+    # representation launch writes it into the record while reading it (smz_vision_initial_record); a search path that
+    # does not do that leaves the copy to flush_obs
+    owed = getattr(chunk, "owed_obs", None)
+    if owed is not None and owed[1] is env.obs and getattr(heads, "records_frames", False):
+        kw["record_obs"] = chunk.obs[owed[0]]
+    eng = mcts.run(env.obs, heads, train=train, act_temperature=temperature, **kw)
+    if owed is not None:
+        if getattr(eng, "obs_recorded", False):
+            chunk.owed_obs = None
+        else:
+            chunk.flush_obs()
     if env_step is not None and getattr(eng, "env_stepped", False):
         return
     action, policy, child_visits, root_value = eng.act(temperature)
@@ -176,7 +197,10 @@ def _play_step(env, heads, mcts, chunk, t, temperature, train=True):
     P = lambda x: C.c_void_p(x.data_ptr())
     split = getattr(chunk, "obs", None) is not None
     if split:                                    # image observations stay float32, outside the float64 record
-        chunk.obs[t].copy_(rec_obs.reshape(env.B, -1))
+        if rec_obs is obs:                       # the next search reads this very tensor: its launch copies it (see above)
+            chunk.owed_obs = (t, obs)
+        else:
+            chunk.obs[t].copy_(rec_obs.reshape(env.B, -1))
     _lib.check(_lib.load().smz_traj_pack(P(chunk.data), chunk.T, t, 0 if split else env.obs_dim, env.num_actions,
                                          None if split else P(rec_obs), P(reward), P(terminated), P(action),
                                          P(policy), P(child_visits), P(root_value), env.B,
@@ -192,6 +216,7 @@ def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
     _sync_active(env, mcts)
     for t in range(steps):
         _play_step(env, heads, mcts, chunk, t, temperature, train)
+    chunk.flush_obs()
     return chunk
 
 
@@ -225,6 +250,8 @@ def play_games_grouped(groups, temperature, steps, train=True):
             with torch.cuda.stream(g.stream):
                 _play_step(g.env, g.heads, g.mcts, g.chunk, t, temperature, train)
     for g in groups:
+        with torch.cuda.stream(g.stream):
+            g.chunk.flush_obs()
         cur.wait_stream(g.stream)
     return [g.chunk for g in groups]
 

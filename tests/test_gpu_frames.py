@@ -136,3 +136,84 @@ def test_host_envs_observed_through_rendered_frames_drive_the_vision_heads(on_en
                               keep_partial=False)
     assert len(games) == n_ends and all(tuple(g.observations[0].shape) == (1, 3, 98, 98) for g in games)
     assert env.upload_bytes >= (T + 1) * B * hw[0] * hw[1] * 3
+
+
+def test_representation_launch_appends_the_frames_it_reads_to_the_record():
+    """smz_vision_initial_record: the frames arrive in the record bit for bit, hidden states and policies are those of
+    smz_vision_initial, a NULL record is smz_vision_initial, a pointer that is not 8-byte aligned is refused."""
+    lib_mod, model_mod = _pkg("_lib"), _pkg("model")
+    lib = lib_mod.load()
+    model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L1_seed0.npz"))
+    heads = model.heads("cuda:0")
+    B = 37
+    frames = torch.rand(B, 3, 98, 98, generator=torch.Generator().manual_seed(4)).cuda()
+    h0, p0 = (x.clone() for x in heads.initial(frames))
+    record = torch.full((B + 1, 3 * 98 * 98), -1.0, device="cuda:0")
+    h1, p1 = (x.clone() for x in heads.initial(frames, record=record[:B]))
+    torch.cuda.synchronize()
+    assert torch.equal(record[:B].view(B, 3, 98, 98), frames) and bool((record[B] == -1).all())
+    assert torch.equal(h0, h1) and torch.equal(p0, p1)
+    P = lambda t, off=0: C.c_void_p(t.data_ptr() + off)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.smz_vision_initial_record(C.byref(heads.desc), P(heads.weights), P(frames), P(record, 4), P(h1), P(p1), B - 1, stream)
+    assert rc == lib_mod.SMZ_ERR_INVALID
+    rc = lib.smz_vision_initial_record(C.byref(heads.desc), P(heads.weights), P(frames, 4), None, P(h1), P(p1), B - 1, stream)
+    assert rc == lib_mod.SMZ_ERR_INVALID
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_play_loop_records_frames_through_the_representation_launch(grouped, monkeypatch):
+    """selfplay._play_step leaves the frame record of step t to the representation launch of step t + 1 (and to flush_obs
+    after the last step): every slot of TrajectoryChunk.obs holds the frame the env showed after that step, for one call and
+    for a second call into the same chunk; the search results do not depend on who copied the frames."""
+    envs_mod, sp, mcts_mod, model_mod = (_pkg(m) for m in ("envs", "selfplay", "mcts", "model"))
+    B, T, sims = 16, 5, 6
+    # (one evaluator per group: its output buffers belong to one stream)
+    all_heads = [model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L1_seed0.npz")).heads("cuda:0")
+                 for _ in range(2 if grouped else 1)]
+    heads = all_heads[0]
+    assert len({id(h) for h in all_heads}) == len(all_heads)
+
+    def play(record_in_launch):
+        monkeypatch.setattr(type(heads), "records_frames", record_in_launch)
+        calls = []
+        for h in all_heads:
+            monkeypatch.setattr(h, "initial", lambda obs, record=None, real=h.initial: (calls.append(record is not None), real(obs, record=record))[1])
+        if grouped:
+            groups = [sp.StreamGroup(envs_mod.ImageVec(B // 2, 2, "cuda:0", seed=9, first_env=g * B // 2, total_envs=B), all_heads[g],
+                                     mcts_mod.BatchedMCTS(B // 2, num_simulations=sims, discount=0.999, use_graph=False), T)
+                      for g in range(2)]
+            for g, grp in enumerate(groups):
+                grp.env.reset()
+                grp.mcts.seed(np.arange(B // 2, dtype=np.uint64) + g * B // 2)
+            out = []
+            for _ in range(2):
+                chunks = sp.play_games_grouped(groups, 1.0, T)
+                torch.cuda.synchronize()
+                out.append((torch.cat([c.data for c in chunks], 1).cpu(), torch.cat([c.obs for c in chunks], 1).cpu()))
+            pools = [grp.env.pool.cpu() for grp in groups]
+            frame = lambda t: torch.cat([p[t % 17:t % 17 + B // 2] for p in pools]).reshape(B, -1)
+        else:
+            env = envs_mod.ImageVec(B, 2, "cuda:0", seed=9)
+            env.reset()
+            m = mcts_mod.BatchedMCTS(B, num_simulations=sims, discount=0.999, use_graph=False)
+            m.seed(np.arange(B, dtype=np.uint64))
+            chunk, out = None, []
+            for _ in range(2):
+                chunk = sp.play_games(env, heads, m, 1.0, T, chunk=chunk)
+                torch.cuda.synchronize()
+                assert chunk.owed_obs is None
+                out.append((chunk.data.cpu(), chunk.obs.cpu()))
+            pool = env.pool.cpu()
+            frame = lambda t: pool[t % 17:t % 17 + B].reshape(B, -1)
+        for call, (_, obs) in enumerate(out):
+            for t in range(T):
+                assert torch.equal(obs[t], frame(call * T + t + 1)), (call, t)
+        monkeypatch.undo()
+        return out, calls
+
+    want, calls_off = play(False)
+    got, calls_on = play(True)
+    assert not any(calls_off) and sum(calls_on) == (2 * (T - 1) * (2 if grouped else 1))
+    for (d0, o0), (d1, o1) in zip(want, got):
+        assert torch.equal(d0, d1) and torch.equal(o0, o1)

@@ -12,23 +12,29 @@ int main() {
     std::vector<float> w(d.total_floats), f((size_t)B * 3 * 98 * 98);
     for (int i = 0; i < d.total_floats; i++) w[i] = 0.02f * ((i * 37) % 19 - 9);
     for (size_t i = 0; i < f.size(); i++) f[i] = 0.001f * (float)((i * 131) % 997);
-    float *dw, *df, *oh, *op;
+    float *dw, *df, *oh, *op, *rec;
+    CK(hipMalloc(&rec, f.size() * 4));
     CK(hipMalloc(&dw, w.size() * 4)); CK(hipMalloc(&df, f.size() * 4)); CK(hipMalloc(&oh, (size_t)B * 147 * 4)); CK(hipMalloc(&op, B * 2 * 4));
     CK(hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(df, f.data(), f.size() * 4, hipMemcpyHostToDevice));
     const char *names[9] = {"stem", "res49 x2", "widen", "res25 x2", "pool25", "res13 x3", "pool13", "res7", "head"};
-    for (int rep = 0; rep < 3; rep++) {
+    for (int rep = 0; rep < 6; rep++) {       // odd passes: with the frame copy into a record (smz_vision_initial_record)
         unsigned long long z[12] = {};
         CK(hipMemcpyToSymbol(HIP_SYMBOL(smz_rep_stamps), z, sizeof(z)));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0));
         for (int k = 0; k < 10; k++)
-            if (smz_vision_initial(&d, dw, df, oh, op, B, nullptr) != 0) { printf("launch failed\n"); return 1; }
+            if (smz_vision_initial_record(&d, dw, df, rep % 2 ? rec : nullptr, oh, op, B, nullptr) != 0) { printf("launch failed\n"); return 1; }
         CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(smz_rep_stamps), sizeof(z)));
-        printf("launch %.1f us | ticks per frame:", ms * 1e3 / 10);
+        printf("%s launch %.1f us | ticks per frame:", rep % 2 ? "record" : "plain ", ms * 1e3 / 10);
         for (int i = 0; i < 9; i++) printf(" %s %.0f |", names[i], z[i] / (10.0 * B));
         printf("\n");
     }
+    std::vector<float> back(f.size());
+    CK(hipMemcpy(back.data(), rec, f.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < f.size(); i++) bad += back[i] != f[i];
+    printf("record differs from the frames in %zu floats\n", bad);
     return 0;
 }
