@@ -161,7 +161,8 @@ struct FrameCopy {
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const int i = at + k * kRepThreads + (int)threadIdx.x;
-            if (i < kPieces) r[k] = __builtin_nontemporal_load(src + i);
+            if (i < kPieces) r[k] = src[i];        // (the stem has just read the frame: an ordinary load finds it in the caches;
+                                                   //  a non-temporal one goes to HBM again: +15 us per launch instead of +4)
         }
     }
     template <int N> __device__ inline void store(const v4f (&r)[N]) {
@@ -175,10 +176,11 @@ struct FrameCopy {
     }
 };
 
+// (map sizes are template parameters: the pixel -> (row, column) divisions and the tap offsets become constants)
 // u <- border-padded f(src) for a [C][N][N] map; f = relu(bn(.)) when bn != nullptr, identity otherwise
-template <int C>
-__device__ inline void pad_store(float *u, const float *src, int N, const float *bn) {
-    const int P = N + 2;
+template <int C, int N>
+__device__ inline void pad_store(float *u, const float *src, const float *bn) {
+    constexpr int P = N + 2;
     for (int i = threadIdx.x; i < C * P * P; i += kRepThreads) {
         const int c = i / (P * P), r = i % (P * P), y = r / P - 1, x = r % P - 1;
         float val = 0.f;
@@ -191,9 +193,9 @@ __device__ inline void pad_store(float *u, const float *src, int N, const float 
     rep_barrier();
 }
 // zero border of a [C][N+2][N+2] buffer whose interior a convolution is about to fill
-template <int C>
-__device__ inline void zero_border(float *u, int N) {
-    const int P = N + 2;
+template <int C, int N>
+__device__ inline void zero_border(float *u) {
+    constexpr int P = N + 2;
     for (int i = threadIdx.x; i < C * 4 * P; i += kRepThreads) {
         const int c = i / (4 * P), r = i % (4 * P), side = r / P, k = r % P;
         const int y = side == 0 ? 0 : (side == 1 ? P - 1 : k), x = side < 2 ? k : (side == 2 ? 0 : P - 1);
@@ -201,11 +203,13 @@ __device__ inline void zero_border(float *u, int N) {
     }
 }
 
-// acc[oc] = sum w[oc][ic][ky][kx] * u[ic][y*stride + ky][x*stride + kx] for one output pixel (input channels outermost, taps
-// inside: the order of the wave-per-leaf convolutions is per tap -- the two kernels never meet on the same tensor)
-template <int CIN, int COUT>
-__device__ inline void conv_pixel(const float *u, int P, int y, int x, int stride, const float *w, float (&acc)[COUT]) {
+// acc[oc] = sum w[oc][ic][ky][kx] * u[ic][y*stride + ky][x*stride + kx] for one output pixel of a [CIN][P][P] bordered map
+// (input channels outermost, taps inside: the order of the wave-per-leaf convolutions is per tap -- the two kernels never meet
+// on the same tensor)
+template <int CIN, int COUT, int P, int STRIDE>
+__device__ inline void conv_pixel(const float *u, int y, int x, const float *w, float (&acc)[COUT]) {
     typedef float v2f __attribute__((ext_vector_type(2)));
+    const float *up = u + y * STRIDE * P + x * STRIDE;
     if constexpr (COUT == 3) {      // outputs 0 and 1 advance in one v_pk_fma_f32, output 2 in a v_fma_f32
         v2f a01 = {0.f, 0.f};
         float a2 = 0.f;
@@ -214,7 +218,7 @@ __device__ inline void conv_pixel(const float *u, int P, int y, int x, int strid
         for (int ic = 0; ic < CIN; ic++)
 #pragma unroll
             for (int t = 0; t < 9; t++) {
-                const float val = u[(ic * P + y * stride + t / 3) * P + x * stride + t % 3];
+                const float val = up[ic * P * P + (t / 3) * P + t % 3];
                 const v2f wp = {w[(0 * CIN + ic) * 9 + t], w[(1 * CIN + ic) * 9 + t]}, vv = {val, val};
                 a01 = __builtin_elementwise_fma(wp, vv, a01);
                 a2 = fmaf(w[(2 * CIN + ic) * 9 + t], val, a2);
@@ -227,36 +231,35 @@ __device__ inline void conv_pixel(const float *u, int P, int y, int x, int strid
         for (int ic = 0; ic < CIN; ic++)
 #pragma unroll
             for (int t = 0; t < 9; t++) {
-                const float val = u[(ic * P + y * stride + t / 3) * P + x * stride + t % 3];
+                const float val = up[ic * P * P + (t / 3) * P + t % 3];
 #pragma unroll
                 for (int oc = 0; oc < COUT; oc++) acc[oc] = fmaf(w[(oc * CIN + ic) * 9 + t], val, acc[oc]);
             }
     }
 }
 // dst[oc][y][x] = conv (+ res[oc][y][x] if res)
-template <int CIN, int COUT>
-__device__ inline void conv_map(float *dst, const float *u, int Nin, int Nout, int stride, const float *w, const float *res) {
-    const int P = Nin + 2;
-    for (int i = threadIdx.x; i < Nout * Nout; i += kRepThreads) {
-        const int y = i / Nout, x = i % Nout;
+template <int CIN, int COUT, int NIN, int NOUT, int STRIDE>
+__device__ inline void conv_map(float *dst, const float *u, const float *w, const float *res) {
+    for (int i = threadIdx.x; i < NOUT * NOUT; i += kRepThreads) {
+        const int y = i / NOUT, x = i % NOUT;
         float acc[COUT];
-        conv_pixel<CIN, COUT>(u, P, y, x, stride, w, acc);
+        conv_pixel<CIN, COUT, NIN + 2, STRIDE>(u, y, x, w, acc);
 #pragma unroll
         for (int oc = 0; oc < COUT; oc++) {
-            const int j = (oc * Nout + y) * Nout + x;
+            const int j = oc * NOUT * NOUT + i;
             dst[j] = res ? acc[oc] + res[j] : acc[oc];
         }
     }
     rep_barrier();
 }
 // the same convolution writing relu(bn(conv)) into the interior of the zero-bordered buffer `un` (same size, stride 1)
-template <int C>
-__device__ inline void conv_bn_pad(float *un, const float *u, int N, const float *w, const float *bn) {
-    const int P = N + 2;
+template <int C, int N>
+__device__ inline void conv_bn_pad(float *un, const float *u, const float *w, const float *bn) {
+    constexpr int P = N + 2;
     for (int i = threadIdx.x; i < N * N; i += kRepThreads) {
         const int y = i / N, x = i % N;
         float acc[C];
-        conv_pixel<C, C>(u, P, y, x, 1, w, acc);
+        conv_pixel<C, C, P, 1>(u, y, x, w, acc);
 #pragma unroll
         for (int oc = 0; oc < C; oc++) un[(oc * P + y + 1) * P + x + 1] = fmaxf(acc[oc] * bn[oc] + bn[C + oc], 0.f);
     }
@@ -266,27 +269,27 @@ __device__ inline void conv_bn_pad(float *un, const float *u, int N, const float
 // v2 residual block on a map: t += convA(f(convB(f(convA(f(t)))))), f = relu(bn(.)) with ONE batch-norm
 // (neural_network_vision_model.py:41-79).  `fresh`: the borders of l.v are not known to be zero for this N yet.
 // `fc`: NP pieces of the frame copy per thread ride along with each of the three convolutions.
-template <int C, int NP>
-__device__ inline void residual_map(RepLds &l, int N, const float *wa, const float *wb, const float *bn, bool fresh, FrameCopy &fc) {
+template <int C, int N, int NP>
+__device__ inline void residual_map(RepLds &l, const float *wa, const float *wb, const float *bn, bool fresh, FrameCopy &fc) {
     FrameCopy::v4f r[NP];
-    if (fresh) zero_border<C>(l.v, N);
+    if (fresh) zero_border<C, N>(l.v);
     fc.load(r);
-    pad_store<C>(l.u, l.t, N, bn);                     // (its barrier also covers the border zeroing)
-    conv_bn_pad<C>(l.v, l.u, N, wa, bn);
+    pad_store<C, N>(l.u, l.t, bn);                     // (its barrier also covers the border zeroing)
+    conv_bn_pad<C, N>(l.v, l.u, wa, bn);
     fc.store(r); fc.load(r);
-    conv_bn_pad<C>(l.u, l.v, N, wb, bn);               // l.u's borders are zero from pad_store
+    conv_bn_pad<C, N>(l.u, l.v, wb, bn);               // l.u's borders are zero from pad_store
     fc.store(r); fc.load(r);
-    conv_map<C, C>(l.t, l.u, N, N, 1, wa, l.t);        // each thread reads and writes only its own pixels of t
+    conv_map<C, C, N, N, 1>(l.t, l.u, wa, l.t);        // each thread reads and writes only its own pixels of t
     fc.store(r);
 }
 
 // AvgPool2d(3, stride 2, padding 1), count_include_pad: sum of the zero-padded window / 9
-template <int C>
-__device__ inline void pool_map(RepLds &l, int Nin, int Nout) {
-    pad_store<C>(l.u, l.t, Nin, nullptr);
-    const int P = Nin + 2;
-    for (int i = threadIdx.x; i < C * Nout * Nout; i += kRepThreads) {
-        const int c = i / (Nout * Nout), r = i % (Nout * Nout), y = r / Nout, x = r % Nout;
+template <int C, int NIN, int NOUT>
+__device__ inline void pool_map(RepLds &l) {
+    pad_store<C, NIN>(l.u, l.t, nullptr);
+    constexpr int P = NIN + 2;
+    for (int i = threadIdx.x; i < C * NOUT * NOUT; i += kRepThreads) {
+        const int c = i / (NOUT * NOUT), r = i % (NOUT * NOUT), y = r / NOUT, x = r % NOUT;
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; t++) s += l.u[(c * P + 2 * y + t / 3) * P + 2 * x + t % 3];
@@ -340,29 +343,29 @@ __global__ void __launch_bounds__(kRepThreads, SMZ_REP_WGS) k_vision_initial(smz
     SMZ_RSTAMP(0);
     {
         const float *wa = weights + o[SMZ_VR_NARROW_A], *wb = weights + o[SMZ_VR_NARROW_B], *bn = weights + o[SMZ_VR_NARROW_BN];
-        residual_map<1, 1>(l, 49, wa, wb, bn, true, fc);
-        residual_map<1, 1>(l, 49, wa, wb, bn, false, fc);
+        residual_map<1, 49, 1>(l, wa, wb, bn, true, fc);
+        residual_map<1, 49, 1>(l, wa, wb, bn, false, fc);
     }
     SMZ_RSTAMP(1);
     // widen: conv3x3 stride 2, 1 -> 3 channels, 49 -> 25
-    pad_store<1>(l.u, l.t, 49, nullptr);
-    conv_map<1, 3>(l.t, l.u, 49, 25, 2, weights + o[SMZ_VR_WIDEN], nullptr);     // (reads l.u only: l.t can take the result)
+    pad_store<1, 49>(l.u, l.t, nullptr);
+    conv_map<1, 3, 49, 25, 2>(l.t, l.u, weights + o[SMZ_VR_WIDEN], nullptr);     // (reads l.u only: l.t can take the result)
     SMZ_RSTAMP(2);
     {
         const float *wa = weights + o[SMZ_VR_WIDE_A], *wb = weights + o[SMZ_VR_WIDE_B], *bn = weights + o[SMZ_VR_WIDE_BN];
-        residual_map<3, 2>(l, 25, wa, wb, bn, true, fc);
-        residual_map<3, 2>(l, 25, wa, wb, bn, false, fc);
+        residual_map<3, 25, 2>(l, wa, wb, bn, true, fc);
+        residual_map<3, 25, 2>(l, wa, wb, bn, false, fc);
         SMZ_RSTAMP(3);
-        pool_map<3>(l, 25, 13);
+        pool_map<3, 25, 13>(l);
         SMZ_RSTAMP(4);
-        residual_map<3, 1>(l, 13, wa, wb, bn, true, fc);
-        residual_map<3, 1>(l, 13, wa, wb, bn, false, fc);
-        residual_map<3, 1>(l, 13, wa, wb, bn, false, fc);
+        residual_map<3, 13, 1>(l, wa, wb, bn, true, fc);
+        residual_map<3, 13, 1>(l, wa, wb, bn, false, fc);
+        residual_map<3, 13, 1>(l, wa, wb, bn, false, fc);
         SMZ_RSTAMP(5);
-        pool_map<3>(l, 13, 7);
+        pool_map<3, 13, 7>(l);
         SMZ_RSTAMP(6);
     }
-    residual_map<3, 1>(l, 7, weights + o[SMZ_VR_LAST_A], weights + o[SMZ_VR_LAST_B], weights + o[SMZ_VR_LAST_BN], true, fc);
+    residual_map<3, 7, 1>(l, weights + o[SMZ_VR_LAST_A], weights + o[SMZ_VR_LAST_B], weights + o[SMZ_VR_LAST_BN], true, fc);
     SMZ_RSTAMP(7);
     // wave 0: per-pixel scaling, hidden state out, root policy (the root value is discarded, mcts:319-321)
     if (threadIdx.x < kWave) {

@@ -1,6 +1,8 @@
 // Stage accounting of k_vision_initial (s_memtime ticks of thread 0, averaged over the frames' workgroups).
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -o vision_rep_probe.bin tools/vision_rep_probe.hip
+#ifndef NO_STAMPS        // -DNO_STAMPS: the library's kernel as it ships, launch times only
 #define SMZ_VISION_STAMPS
+#endif
 #include "../stochastic-muzero_amd/csrc/smz_vision.hip"
 #include <cstdio>
 #include <vector>
@@ -19,16 +21,20 @@ int main() {
     const char *names[9] = {"stem", "res49 x2", "widen", "res25 x2", "pool25", "res13 x3", "pool13", "res7", "head"};
     for (int rep = 0; rep < 6; rep++) {       // odd passes: with the frame copy into a record (smz_vision_initial_record)
         unsigned long long z[12] = {};
+#ifdef SMZ_VISION_STAMPS
         CK(hipMemcpyToSymbol(HIP_SYMBOL(smz_rep_stamps), z, sizeof(z)));
+#endif
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0));
-        for (int k = 0; k < 10; k++)
+        for (int k = 0; k < 50; k++)
             if (smz_vision_initial_record(&d, dw, df, rep % 2 ? rec : nullptr, oh, op, B, nullptr) != 0) { printf("launch failed\n"); return 1; }
         CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+#ifdef SMZ_VISION_STAMPS
         CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(smz_rep_stamps), sizeof(z)));
-        printf("%s launch %.1f us | ticks per frame:", rep % 2 ? "record" : "plain ", ms * 1e3 / 10);
-        for (int i = 0; i < 9; i++) printf(" %s %.0f |", names[i], z[i] / (10.0 * B));
+#endif
+        printf("%s launch %.1f us | ticks per frame:", rep % 2 ? "record" : "plain ", ms * 1e3 / 50);
+        for (int i = 0; i < 9; i++) printf(" %s %.0f |", names[i], z[i] / (50.0 * B));
         printf("\n");
     }
     std::vector<float> back(f.size());
