@@ -216,7 +216,8 @@ def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
     _sync_active(env, mcts)
     for t in range(steps):
         _play_step(env, heads, mcts, chunk, t, temperature, train)
-    chunk.flush_obs()
+    if getattr(chunk, "owed_obs", None) is not None:
+        chunk.flush_obs()
     return chunk
 
 
@@ -250,8 +251,9 @@ def play_games_grouped(groups, temperature, steps, train=True):
             with torch.cuda.stream(g.stream):
                 _play_step(g.env, g.heads, g.mcts, g.chunk, t, temperature, train)
     for g in groups:
-        with torch.cuda.stream(g.stream):
-            g.chunk.flush_obs()
+        if getattr(g.chunk, "owed_obs", None) is not None:
+            with torch.cuda.stream(g.stream):
+                g.chunk.flush_obs()
         cur.wait_stream(g.stream)
     return [g.chunk for g in groups]
 
