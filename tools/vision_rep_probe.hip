@@ -3,7 +3,10 @@
 #ifndef NO_STAMPS        // -DNO_STAMPS: the library's kernel as it ships, launch times only
 #define SMZ_VISION_STAMPS
 #endif
-#include "../stochastic-muzero_amd/csrc/smz_vision.hip"
+#ifndef SMZ_SRC          // (-DSMZ_SRC='"..."': another version of the kernel source, to compare output checksums)
+#define SMZ_SRC "../stochastic-muzero_amd/csrc/smz_vision.hip"
+#endif
+#include SMZ_SRC
 #include <cstdio>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -36,6 +39,14 @@ int main() {
         printf("%s launch %.1f us | ticks per frame:", rep % 2 ? "record" : "plain ", ms * 1e3 / 50);
         for (int i = 0; i < 9; i++) printf(" %s %.0f |", names[i], z[i] / (50.0 * B));
         printf("\n");
+    }
+    {   // bit patterns of what the last launch wrote: equal checksums between two builds = bit-identical outputs
+        std::vector<uint32_t> h((size_t)B * 147), q((size_t)B * 2);
+        CK(hipMemcpy(h.data(), oh, h.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(q.data(), op, q.size() * 4, hipMemcpyDeviceToHost));
+        unsigned long long c1 = 0, c2 = 0;
+        for (size_t i = 0; i < h.size(); i++) c1 = c1 * 1000003ull + h[i];
+        for (size_t i = 0; i < q.size(); i++) c2 = c2 * 1000003ull + q[i];
+        printf("checksum hidden %016llx policy %016llx\n", c1, c2);
     }
     std::vector<float> back(f.size());
     CK(hipMemcpy(back.data(), rec, f.size() * 4, hipMemcpyDeviceToHost));
