@@ -16,6 +16,7 @@ for f in $O/${TAG}_bench*.json; do python3 -c "
 import json,sys
 d=json.loads(open('$f').read()); r=d.get('roofline') or {}; c=d.get('cpu_baseline') or {}; b=r.get('bound_actual') or {}
 print('$f'.split('/')[-1], round(d['value']/1e6,2),'M sims/s', round(d['ms_per_step'],4),'ms/step', r.get('bound'), 'frac', round(r.get('frac',0),4), 'chain frac', round(b.get('frac',0),3), 'cpu', round(c.get('value',0)/1e6,3),'M on', c.get('cores'))"; done
+rm -f $O/${TAG}_env_sweep.jsonl; SWEEP_OUT=$O/${TAG}_env_sweep.jsonl tools/sweep_envs.sh hip > /dev/null 2>&1; cat $O/${TAG}_env_sweep.jsonl
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/prof_$TAG.log 2>&1
@@ -55,3 +56,11 @@ PY
 traffic "k_search_mlp" "cartpole_mlp_4096x50" "" "${TAG}_traffic_k_search_mlp.json"
 traffic "k_search_vision" "vision_resnet_1024x50" "--workload vision_resnet_1024x50" "${TAG}_traffic_k_search_vision.json"
 traffic "k_search_mlp" "cartpole_mlp_4096x50+philox" "--rng philox" "${TAG}_traffic_k_search_mlp_philox.json"
+# the bench lines again, now that this build's counter files exist: roofline.traffic is filled from them (bench.py find_traffic)
+cp $O/${TAG}_traffic_*.json $R/profiles/ 2>/dev/null; cd $R
+python bench.py --steps 20 --warmup 5 2>$O/${TAG}_bench.err > $O/${TAG}_bench.json
+python bench.py --steps 8 --warmup 2 --workload vision_resnet_1024x50 2>/dev/null > $O/${TAG}_bench_vision.json
+python bench.py --steps 16 --warmup 3 --rng philox --no-cpu-baseline 2>/dev/null > $O/${TAG}_bench_philox.json
+for f in $O/${TAG}_bench.json $O/${TAG}_bench_vision.json $O/${TAG}_bench_philox.json; do python3 -c "
+import json
+d=json.loads(open('$f').read()); r=d['roofline']; print('$f'.split('/')[-1], round(d['value']/1e6,2), 'traffic', r.get('traffic'), r.get('traffic_source'))"; done
