@@ -281,14 +281,15 @@ typedef struct smz_vision_desc {
 /* Fills OP, total_floats, small_floats and off[] from A/S/H/L.  SMZ_ERR_INVALID when A, S or H exceed 64 (one neuron
  * per lane). */
 int smz_vision_layout(smz_vision_desc *desc);
-/* representation + root prediction: frames_dev [B,3,98,98] f32 -> hidden_out_dev [B,147] (scaled per pixel across
- * channels), policy_out_dev [B,A] (softmax).  One 256-thread workgroup per frame. */
+/* representation + root prediction: frames_dev [B,3,98,98] f32 (8-byte aligned) -> hidden_out_dev [B,147] (scaled per
+ * pixel across channels), policy_out_dev [B,A] (softmax).  One 256-thread workgroup per frame. */
 int smz_vision_initial(const smz_vision_desc *desc, const float *weights_dev, const float *frames_dev,
                        float *hidden_out_dev, float *policy_out_dev, int B, smz_stream stream);
 /* ... which also appends the frames it reads to the trajectory record: frames_copy_dev [B,3,98,98] f32 (NULL: no copy)
- * receives frames_dev, written by the threads of the stem convolution from the pixel pairs they have just loaded --
- * Game.observations.append of the frame the search is about to run on (game.py:263-264: the observation after the previous
- * action), without reading it from HBM a second time.  Both frame pointers 8-byte aligned (SMZ_ERR_INVALID otherwise). */
+ * receives a bit-exact copy of frames_dev -- Game.observations.append of the frame the search is about to run on
+ * (game.py:263-264: the observation after the previous action).  The copy moves in 16-byte pieces alongside the residual
+ * blocks of the launch (the stem has just read the frame, the re-read comes from the caches), not as a second pass over HBM.
+ * frames_dev 8-byte aligned; with a copy both frame pointers 16-byte aligned (SMZ_ERR_INVALID otherwise). */
 int smz_vision_initial_record(const smz_vision_desc *desc, const float *weights_dev, const float *frames_dev,
                               float *frames_copy_dev, float *hidden_out_dev, float *policy_out_dev, int B, smz_stream stream);
 /* Frame ingest: n_frames rendered frames [n][H][W][3] uint8 (as a host environment uploads them) -> the
