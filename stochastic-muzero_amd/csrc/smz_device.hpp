@@ -68,6 +68,8 @@ struct Params {
                                 // ({-1, -1} for a switched-off tree): smz_set_leaf_ids_out
     int32_t tree0;              // index of the tree whose blocks `nodes` points at: 0, except in a kernel that keeps its workgroup's
                                 // trees in LDS for the search (k_search_vision) and points `nodes` there
+    int32_t thr_off, thr_stride;  // THR kernels (two children per block): the float64 chance threshold of expansion block b lives
+                                  // at word thr_off + (b - 1) * thr_stride of its tree (chance_threshold2)
 };
 #ifdef SMZ_NO_MASK
 __device__ inline bool tree_active(const Params &, int) { return true; }
@@ -519,6 +521,25 @@ __device__ inline int pick_chance(const Kids<N> &k, int cnt, RNG &rng) {
     return sample_cdf<N>(q64, cnt, rng.random_sample());
 }
 
+// A chance-flagged node with TWO children picks child 1 iff t <= u, where u is the draw and t = cdf[0] / cdf[1] of
+// pick_chance / sample_cdf: a function of the two priors alone.  The priors of a block never change after its expansion,
+// so the specialised search kernel computes t ONCE, when it writes the block, instead of on every visit of the node
+// (two float32 quotients and a float64 one leave the descent's dependent chain; a chance node is visited ~4 times in a
+// 50-simulation search).  Same operations in the same order as pick_chance<2> + sample_cdf<2>: the pick is the same bit for bit.
+__device__ inline double chance_threshold2(float p0, float p1) {
+    float tmp[2] = {(1.0f - p0) + 1e-12f, (1.0f - p1) + 1e-12f};
+    const float s = np_sum<float, 2>(tmp, 2);
+    const float r = fabsf((float)((double)s / 2.0));
+    tmp[0] = p0 + r; tmp[1] = p1 + r;
+    const float qs = np_sum<float, 2>(tmp, 2);
+    const double q0 = (double)(tmp[0] / qs), q1 = (double)(tmp[1] / qs);
+    double acc = 0.0;
+    acc += q0;
+    const double c0 = acc;
+    acc += q1;
+    return c0 / acc;
+}
+
 // Correctly rounded x / n for a visit count n in [1, sims + 1] through a table of correctly rounded reciprocals:
 // q = RN(x r) is a faithful quotient, e = x - q n is exact in an FMA, RN(q + e r) = RN(x / n) (Markstein's theorem; its
 // one exception, a divisor whose significand is all ones, cannot be a small integer).  x = sqrt(N) pb_c prior is a
@@ -610,10 +631,13 @@ __device__ __forceinline__ PathCol path_col(const Params &P, int tree) { return 
 // LUT: the reciprocal table of div_by_count follows the pb_c table (pbc_sqrt[sims + 2 + n] = 1 / n)
 // PAIR (MAXA == 2, KS == 2, A == 2): two lanes per tree, see pick_decision_pair; `me` = 0 for the tree's lane (which
 // alone writes the path records), 1 for its helper.  Chance levels are evaluated redundantly by both lanes.
-template <int MAXA, int KS, bool STATS = true, bool LUT = false, bool PAIR = false, class RNG = Rng, class REC = uint4 *>
+// THR (KS == 2): chance levels compare the draw with the block's stored threshold (chance_threshold2, written by
+// expand_backup_tree<..., THR>) instead of recomputing it.
+template <int MAXA, int KS, bool STATS = true, bool LUT = false, bool PAIR = false, bool THR = false, class RNG = Rng, class REC = uint4 *>
 __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const TreeHdr &h, const double *pbc_sqrt,
                                    int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children,
                                    REC rec, int me = 0) {
+    static_assert(!THR || KS == 2, "stored chance thresholds: two children per block");
     constexpr int NK = KS > 0 ? KS : MAXA;     // register arrays of the expansion levels
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
@@ -643,7 +667,12 @@ __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const Tr
         const int cnt = KS > 0 ? KS : K;
         int pick;
         if (depth_flag(depth)) {
-            pick = pick_chance<NK>(k, cnt, rng);
+            if constexpr (THR) {
+                const double t = *reinterpret_cast<const double *>(tb + P.thr_off + (size_t)(blk - 1) * P.thr_stride);
+                pick = (t <= rng.random_sample()) ? 1 : 0;
+            } else {
+                pick = pick_chance<NK>(k, cnt, rng);
+            }
         } else {
             if constexpr (PAIR) pick = pick_decision_pair(k, me, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
             else pick = pick_decision<NK>(k, cnt, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
@@ -679,9 +708,10 @@ __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const Tr
 // ---------------------------------------------------------------------------------------------------------------
 // EXPAND_ONLY: stop after the expansion and return the leaf reward through *leaf_reward_out -- the caller runs the
 // backup with backup_levels_lanes (several lanes per tree).
-template <int MAXA, int KS, bool EXPAND_ONLY = false, class RNG = Rng, class REC = const uint4 *>
+template <int MAXA, int KS, bool EXPAND_ONLY = false, bool THR = false, class RNG = Rng, class REC = const uint4 *>
 __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, TreeHdr &h, const float *policy_row,
                                          float reward, float value, REC rec, float *leaf_reward_out = nullptr) {
+    static_assert(!THR || KS == 2, "stored chance thresholds: two children per block");
     constexpr int CH = 8;   // path records fetched per round trip
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
@@ -711,6 +741,10 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, Tr
             nb4[2] = make_uint4(0u, 0u, (uint32_t)picks[0], (uint32_t)picks[1]);              // child, action
             if (P.eb_words >= 16) nb4[3] = make_uint4(0u, 0u, 0u, 0u);                        // (padding: the block leaves as one whole 64-byte line;
                                                                                               //  LDS-resident trees pack blocks at 12 words)
+            if constexpr (THR) {      // the new node sits at depth `len`: its children are sampled iff that depth is chance-flagged
+                if (depth_flag(len))
+                    *reinterpret_cast<double *>(tb + P.thr_off + (size_t)e * P.thr_stride) = chance_threshold2(pj[0], pj[1]);
+            }
         } else {
             for (int j = 0; j < K; j++) {
                 nb[2 * j] = 0u;                              // visit

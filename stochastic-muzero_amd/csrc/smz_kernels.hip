@@ -650,7 +650,8 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
     m.rng_off = m.pv_off + tpw * P.P * 4;
     m.out_off = m.rng_off + r4(tpw * kRngStride);
     m.per_wave = m.out_off + r4(tpw * (P.A + 2));
-    m.tree_words = P.rb_words + P.sims * 6 * P.K;
+    m.tree_words = r4(P.rb_words + P.sims * 6 * P.K + (P.K == 2 ? 2 * P.sims : 0));   // (+ the chance thresholds, one double per block;
+                                                                                      //  trees stay 16-byte aligned)
     m.trees_off = m.wave_off + waves * m.per_wave;
     return m;
 }
@@ -708,6 +709,13 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         P.tree0 = blockIdx.x * waves * tpw;
         P.eb_words = 6 * KS;
         P.tree_words = ml.tree_words;
+    }
+    // Chance thresholds (select_tree / expand_backup_tree <THR>): in the padding of the 64-byte block when the trees are in
+    // global memory, behind the tree's packed blocks when they are in LDS
+    constexpr bool THR = AEX && KS == 2;
+    if (THR) {
+        P.thr_off = TLDS ? P.rb_words + P.sims * 6 * KS : P.rb_words + 12;
+        P.thr_stride = TLDS ? 2 : P.eb_words;
     }
     double *pbc_lds = reinterpret_cast<double *>(lds + ml.pbc_off);
     const int n_pbc = P.sims + 2;
@@ -779,7 +787,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         float leaf_rw = 0.f;
         if (valid) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            if (s > 0 && !(dbg & 4)) expand_backup_tree<MAXA, KS, LBKP>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
+            if (s > 0 && !(dbg & 4)) expand_backup_tree<MAXA, KS, LBKP, THR>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
                                                       outs[lane * slot + A], pvals + lane * P.P, &leaf_rw);
         }
         if constexpr (LBKP) {
@@ -824,8 +832,8 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
                     hs.mn = hmn; hs.mx = hmx; hs.root_visit = hrv;
                 }
                 int len = 0;
-                const Leaf Lp = select_tree<MAXA, KS, false, true, true>(P, tree0 + src, rng, hs, pbc_lds, len, n_dec, n_chance,
-                                                                        n_children, pvals + src * P.P, lane >> 1);
+                const Leaf Lp = select_tree<MAXA, KS, false, true, true, THR>(P, tree0 + src, rng, hs, pbc_lds, len, n_dec, n_chance,
+                                                                             n_children, pvals + src * P.P, lane >> 1);
                 if (lane < 2) {
                     L = Lp;
                     h.path_len = len;
@@ -835,7 +843,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         } else if (valid) {
             int len = 0;
             if (dbg & 2) { L.leaf_id = 1; L.parent_id = 0; L.action = 0; L.branch = 0; len = 1; }
-            else L = select_tree<MAXA, KS, INSTR, true>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
+            else L = select_tree<MAXA, KS, INSTR, true, false, THR>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
             h.path_len = len;
             if (INSTR) n_desc++;
             packed = rng.pack();
@@ -917,8 +925,8 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
     if (valid) {
         if (P.sims > 0) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            expand_backup_tree<MAXA, KS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
-                                         pvals + lane * P.P);
+            expand_backup_tree<MAXA, KS, false, THR>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
+                                                     pvals + lane * P.P);
             // leave the last path where the step-wise entry points and the debug dump expect it
             for (int i = 0; i < h.path_len; i++) P.path[(size_t)i * P.B + tree] = pvals[lane * P.P + i];
             packed = rng.pack();

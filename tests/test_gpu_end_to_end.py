@@ -756,10 +756,10 @@ def test_vision_single_launch_search_with_more_actions_equals_stepwise(A, L, B, 
 
 
 @pytest.mark.parametrize("wname,B,sims,mode", [("weights_ckpt421", 2570, 50, "plain"), ("weights_lunar_L0", 4096, 30, "plain"),
-                                               ("weights_ckpt421", 2049, 60, "plain"), ("weights_ckpt421", 4096, 40, "mask"),
+                                               ("weights_ckpt421", 2049, 52, "plain"), ("weights_ckpt421", 4096, 40, "mask"),
                                                ("weights_lunar_L0", 3000, 25, "mask"), ("weights_ckpt421", 4096, 40, "philox")])
 def test_lds_resident_trees_equal_trees_in_global_memory(wname, B, sims, mode, monkeypatch):
-    """k_search_mlp<..., TLDS> (round 3: the workgroup's trees live in LDS for the search, blocks packed at 48 bytes, weights in
+    """k_search_mlp<..., TLDS> (round 3: the workgroup's trees live in LDS for the search, blocks packed at 48 bytes + 8 bytes of chance threshold each, weights in
     the compact LDS image, written back to the 64-byte-granule layout at the end) against the same kernel with the trees in
     global memory (SMZ_SEARCH_TLDS=0): ragged batches (the last workgroup partly empty), 4 actions, the largest simulation count
     that still fits -- visits, priors, values, every dumped tree array of sampled trees, path, action outputs and stream
