@@ -68,8 +68,11 @@ struct Params {
                                 // ({-1, -1} for a switched-off tree): smz_set_leaf_ids_out
     int32_t tree0;              // index of the tree whose blocks `nodes` points at: 0, except in a kernel that keeps its workgroup's
                                 // trees in LDS for the search (k_search_vision) and points `nodes` there
-    int32_t thr_off, thr_stride;  // THR kernels (two children per block): the float64 chance threshold of expansion block b lives
-                                  // at word thr_off + (b - 1) * thr_stride of its tree (chance_threshold2)
+    int32_t thr_off, thr_stride;  // THR kernels (two children per block): two spare words per expansion block b at word
+                                  // thr_off + (b - 1) * thr_stride of its tree.  Block of a chance-flagged node: its float64 sampling
+                                  // threshold (chance_threshold2).  Block of a decision-flagged node: float32 y[2], the children's
+                                  // reward + discount * value_sum / visits as of their last backup (value_term)
+    int32_t ry_off;               // ... and y[A] of the root's children at this word of the root block (-1: no room, not kept)
 };
 #ifdef SMZ_NO_MASK
 __device__ inline bool tree_active(const Params &, int) { return true; }
@@ -461,6 +464,7 @@ struct Kids {
     int32_t vis[N], chd[N], act[N];
     float vsum[N], rew[N], pri[N];
     double pri64[N];
+    float yv[N];     // YV kernels: reward + discount * value_sum / visits as stored by the last backup (meaningful when vis > 0)
 };
 
 // run-time child count: predicated dword loads
@@ -555,23 +559,29 @@ __device__ inline double div_by_count(double x, int n, const double *r64) {
 
 // decision-flagged node: pUCT argmax (mcts:235-243, 257-259)
 // r64: reciprocal table (1/n at r64[n], n <= sims + 1) or nullptr (compile-time at every call site) for the IEEE division
-template <int N>
+// The value term of a child before the MinMax normalisation: reward + discount * value() (mcts:239-241).  The backup that
+// last touched the child has computed value() = value_sum / visits for the MinMax update; YV kernels keep the term it leads
+// to beside the block (Params::thr_off) and the next descent reads it instead of dividing again -- the same two operands, the
+// same three operations, one IEEE division less on the dependent chain of every decision level.
+__device__ inline float value_term(float reward, float disc32, float qv) {
+    const float dv = disc32 * qv;
+    return reward + dv;
+}
+template <int N, bool YV = false>
 __device__ inline double puct_score(const Kids<N> &k, int j, double sp, bool norm, float mn, float span, float disc32,
                                     double u, const double *r64) {
     const int Nc = k.vis[j];
     const double prior_score = r64 ? div_by_count(sp * k.pri64[j], Nc + 1, r64) : (sp * k.pri64[j]) / (double)(Nc + 1);
     double value_score = 0.0;
     if (Nc > 0) {
-        const float qv = k.vsum[j] / (float)Nc;
-        const float dv = disc32 * qv;
-        float x = k.rew[j] + dv;
+        float x = YV ? k.yv[j] : value_term(k.rew[j], disc32, k.vsum[j] / (float)Nc);
         if (norm) { const float num = x - mn; x = num / span; }
         value_score = (double)x;
     }
     const double jitter = 1e-7 + (2e-7 - 1e-7) * u;
     return (prior_score + value_score) + jitter;
 }
-template <int N, class RNG>
+template <int N, bool YV = false, class RNG>
 __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool norm, float mn, float span, float disc32,
                                     RNG &rng, const double *r64 = nullptr) {
     double best = 0.0;
@@ -586,7 +596,7 @@ __device__ inline int pick_decision(const Kids<N> &k, int cnt, double sp, bool n
     for (int j = 0; j < N; j++) {
         if (j < cnt) {
             const double u = batched ? RNG::to_double(jw[kBatch ? 2 * j : 0], jw[kBatch ? 2 * j + 1 : 1]) : rng.random_sample();
-            const double score = puct_score<N>(k, j, sp, norm, mn, span, disc32, u, r64);
+            const double score = puct_score<N, YV>(k, j, sp, norm, mn, span, disc32, u, r64);
             if (j == 0 || score >= best) { best = score; pick = j; }  // exact tie -> larger action
         }
     }
@@ -602,7 +612,7 @@ __device__ inline double quad_partner(double v) {          // value held by lane
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-template <class RNG>
+template <bool YV = false, class RNG>
 __device__ inline int pick_decision_pair(const Kids<2> &k, int me, double sp, bool norm, float mn, float span,
                                          float disc32, RNG &rng, const double *r64) {
     uint32_t jw[4];
@@ -612,8 +622,9 @@ __device__ inline int pick_decision_pair(const Kids<2> &k, int me, double sp, bo
     mine.vsum[0] = me ? k.vsum[1] : k.vsum[0];
     mine.rew[0] = me ? k.rew[1] : k.rew[0];
     mine.pri64[0] = me ? k.pri64[1] : k.pri64[0];
+    if (YV) mine.yv[0] = me ? k.yv[1] : k.yv[0];
     const double u = RNG::to_double(me ? jw[2] : jw[0], me ? jw[3] : jw[1]);
-    const double s_me = puct_score<2>(mine, 0, sp, norm, mn, span, disc32, u, r64);
+    const double s_me = puct_score<2, YV>(mine, 0, sp, norm, mn, span, disc32, u, r64);
     const double s_other = quad_partner(s_me);
     const double s0 = me ? s_other : s_me, s1 = me ? s_me : s_other;
     return s1 >= s0 ? 1 : 0;      // exact tie -> larger action
@@ -632,12 +643,15 @@ __device__ __forceinline__ PathCol path_col(const Params &P, int tree) { return 
 // PAIR (MAXA == 2, KS == 2, A == 2): two lanes per tree, see pick_decision_pair; `me` = 0 for the tree's lane (which
 // alone writes the path records), 1 for its helper.  Chance levels are evaluated redundantly by both lanes.
 // THR (KS == 2): chance levels compare the draw with the block's stored threshold (chance_threshold2, written by
-// expand_backup_tree<..., THR>) instead of recomputing it.
-template <int MAXA, int KS, bool STATS = true, bool LUT = false, bool PAIR = false, bool THR = false, class RNG = Rng, class REC = uint4 *>
+// expand_backup_tree<..., THR>) instead of recomputing it.  YV (needs THR's two words per block): decision levels read the
+// children's value terms as the last backup left them (value_term) instead of dividing value_sum by visits again.
+template <int MAXA, int KS, bool STATS = true, bool LUT = false, bool PAIR = false, bool THR = false, bool YV = false, class RNG = Rng, class REC = uint4 *>
 __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const TreeHdr &h, const double *pbc_sqrt,
                                    int &path_len_out, unsigned &n_dec, unsigned &n_chance, unsigned &n_children,
                                    REC rec, int me = 0) {
     static_assert(!THR || KS == 2, "stored chance thresholds: two children per block");
+    static_assert(!YV || THR, "stored value terms live in the threshold words of decision-flagged blocks");
+    constexpr bool RY = YV && MAXA <= 8;       // the root block has room for its children's value terms (Params::ry_off)
     constexpr int NK = KS > 0 ? KS : MAXA;     // register arrays of the expansion levels
     const int A = P.A, K = P.K;
     uint32_t *tb = tree_base(P, tree);
@@ -648,9 +662,13 @@ __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const Tr
     {   // ---- root level: decision-flagged, A children, float64 priors ----------------------------------------------
         Kids<MAXA> k;
         load_kids_dyn<MAXA>(tb, A, true, P.rp_off, k);
+        if constexpr (RY) {
+#pragma unroll
+            for (int j = 0; j < MAXA; j++) k.yv[j] = j < A ? __uint_as_float(tb[P.ry_off + j]) : 0.f;
+        }
         int pick;
-        if constexpr (PAIR) pick = pick_decision_pair(k, me, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
-        else pick = pick_decision<MAXA>(k, A, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
+        if constexpr (PAIR) pick = pick_decision_pair<RY>(k, me, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
+        else pick = pick_decision<MAXA, RY>(k, A, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
         float pv = 0.f, pr = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXA; j++) if (j == pick) { c = k.chd[j]; cur_visit = k.vis[j]; action = j; pv = k.vsum[j]; pr = k.rew[j]; }
@@ -674,8 +692,12 @@ __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const Tr
                 pick = pick_chance<NK>(k, cnt, rng);
             }
         } else {
-            if constexpr (PAIR) pick = pick_decision_pair(k, me, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
-            else pick = pick_decision<NK>(k, cnt, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
+            if constexpr (YV) {
+                const uint2 y2 = *reinterpret_cast<const uint2 *>(tb + P.thr_off + (size_t)(blk - 1) * P.thr_stride);
+                k.yv[0] = __uint_as_float(y2.x); k.yv[1] = __uint_as_float(y2.y);
+            }
+            if constexpr (PAIR) pick = pick_decision_pair<YV>(k, me, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
+            else pick = pick_decision<NK, YV>(k, cnt, pbc_sqrt[cur_visit], norm, mn, span, P.disc32, rng, LUT ? pbc_sqrt + P.sims + 2 : nullptr);
         }
         float pv = 0.f, pr = 0.f;
 #pragma unroll
@@ -701,6 +723,17 @@ __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const Tr
     return L;
 }
 
+// YV kernels: the value term of the child in slot `sl` of block `b`, chosen at path level `level` (= the depth of the block's
+// node), goes beside the block -- unless that node samples its children (the two words hold its threshold then, and a value
+// term there would never be read).
+__device__ inline void store_value_term(const Params &P, uint32_t *tb, int b, int sl, int level, float y) {
+    if (b == 0) {
+        if (P.ry_off >= 0) tb[P.ry_off + sl] = __float_as_uint(y);
+    } else if (!depth_flag(level)) {
+        tb[P.thr_off + (size_t)(b - 1) * P.thr_stride + sl] = __float_as_uint(y);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // expansion + backup (monte_carlo_tree_search.py:289-308); the leaf's hidden row is stored by the caller.
 // The path records of the preceding select carry every visited node's (visit, value_sum, reward): the backup only
@@ -708,7 +741,7 @@ __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const Tr
 // ---------------------------------------------------------------------------------------------------------------
 // EXPAND_ONLY: stop after the expansion and return the leaf reward through *leaf_reward_out -- the caller runs the
 // backup with backup_levels_lanes (several lanes per tree).
-template <int MAXA, int KS, bool EXPAND_ONLY = false, bool THR = false, class RNG = Rng, class REC = const uint4 *>
+template <int MAXA, int KS, bool EXPAND_ONLY = false, bool THR = false, bool YV = false, class RNG = Rng, class REC = const uint4 *>
 __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, TreeHdr &h, const float *policy_row,
                                          float reward, float value, REC rec, float *leaf_reward_out = nullptr) {
     static_assert(!THR || KS == 2, "stored chance thresholds: two children per block");
@@ -791,6 +824,7 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, Tr
                 const float qv = nvs / (float)nvc;
                 if (qv > mx) mx = qv;
                 if (qv < mn) mn = qv;
+                if constexpr (YV) store_value_term(P, tb, b, sl, i0 - q, value_term(r, P.disc32, qv));
                 const float dv = P.disc32 * v;
                 v = r + dv;
             }
@@ -822,7 +856,7 @@ __device__ inline void minmax_shl(float &mn, float &mx) {      // mn = min(mn, m
     mn = fminf(mn, smn);
     mx = fmaxf(mx, smx);
 }
-template <int TPW>
+template <int TPW, bool YV = false>
 __device__ inline void backup_levels_lanes(const Params &P, int tree, int j, int len, float value, float leaf_reward,
                                            const uint4 *rec, float &mn, float &mx, float &v_root) {
     const int A = P.A, K = P.K;
@@ -852,6 +886,8 @@ __device__ inline void backup_levels_lanes(const Params &P, int tree, int j, int
             const float qv = nvs / (float)nvc;
             if (qv > mx) mx = qv;
             if (qv < mn) mn = qv;
+            if constexpr (YV)
+                store_value_term(P, tb, b, sl, i, value_term((i == len - 1) ? leaf_reward : __uint_as_float(e4.w), P.disc32, qv));
         }
     }
     v_root = v;

@@ -712,10 +712,14 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
     }
     // Chance thresholds (select_tree / expand_backup_tree <THR>): in the padding of the 64-byte block when the trees are in
     // global memory, behind the tree's packed blocks when they are in LDS
-    constexpr bool THR = AEX && KS == 2;
+    // ... and, with the trees in LDS, the children's value terms of the decision-flagged blocks (select_tree<YV>: one division
+    // less per decision level; with the trees in global memory the extra store per backup level costs more than it saves:
+    // 423 -> 415 M at 4096 x 100)
+    constexpr bool THR = AEX && KS == 2, YV = THR && TLDS;
     if (THR) {
         P.thr_off = TLDS ? P.rb_words + P.sims * 6 * KS : P.rb_words + 12;
         P.thr_stride = TLDS ? 2 : P.eb_words;
+        P.ry_off = (YV && MAXA <= 8 && P.rp_off + 3 * A <= P.rb_words) ? P.rp_off + 2 * A : -1;      // (select_tree<YV> reads it for MAXA <= 8)
     }
     double *pbc_lds = reinterpret_cast<double *>(lds + ml.pbc_off);
     const int n_pbc = P.sims + 2;
@@ -787,7 +791,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         float leaf_rw = 0.f;
         if (valid) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            if (s > 0 && !(dbg & 4)) expand_backup_tree<MAXA, KS, LBKP, THR>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
+            if (s > 0 && !(dbg & 4)) expand_backup_tree<MAXA, KS, LBKP, THR, YV>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
                                                       outs[lane * slot + A], pvals + lane * P.P, &leaf_rw);
         }
         if constexpr (LBKP) {
@@ -798,7 +802,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
                 if (lane < 8 * kFastTpw && SMZ_SLOT_VALID(src)) {
                     const bool own = lane < kFastTpw;
                     float mn = own ? h.mn : __builtin_inff(), mx = own ? h.mx : -__builtin_inff(), v_root = 0.f;
-                    backup_levels_lanes<kFastTpw>(P, tree0 + src, lane / kFastTpw, len, outs[src * slot + A], lrw,
+                    backup_levels_lanes<kFastTpw, YV>(P, tree0 + src, lane / kFastTpw, len, outs[src * slot + A], lrw,
                                                   pvals + src * P.P, mn, mx, v_root);
                     if (own) {   // the root itself (reward 0)
                         const float nvs = h.root_value_sum + v_root;
@@ -832,7 +836,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
                     hs.mn = hmn; hs.mx = hmx; hs.root_visit = hrv;
                 }
                 int len = 0;
-                const Leaf Lp = select_tree<MAXA, KS, false, true, true, THR>(P, tree0 + src, rng, hs, pbc_lds, len, n_dec, n_chance,
+                const Leaf Lp = select_tree<MAXA, KS, false, true, true, THR, YV>(P, tree0 + src, rng, hs, pbc_lds, len, n_dec, n_chance,
                                                                              n_children, pvals + src * P.P, lane >> 1);
                 if (lane < 2) {
                     L = Lp;
@@ -843,7 +847,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         } else if (valid) {
             int len = 0;
             if (dbg & 2) { L.leaf_id = 1; L.parent_id = 0; L.action = 0; L.branch = 0; len = 1; }
-            else L = select_tree<MAXA, KS, INSTR, true, false, THR>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
+            else L = select_tree<MAXA, KS, INSTR, true, false, THR, YV>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
             h.path_len = len;
             if (INSTR) n_desc++;
             packed = rng.pack();
@@ -925,7 +929,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
     if (valid) {
         if (P.sims > 0) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            expand_backup_tree<MAXA, KS, false, THR>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
+            expand_backup_tree<MAXA, KS, false, THR, YV>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
                                                      pvals + lane * P.P);
             // leave the last path where the step-wise entry points and the debug dump expect it
             for (int i = 0; i < h.path_len; i++) P.path[(size_t)i * P.B + tree] = pvals[lane * P.P + i];
