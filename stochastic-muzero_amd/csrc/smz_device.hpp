@@ -292,6 +292,23 @@ __device__ inline void choice_noreplace(RNG &rng, double (&p)[MAXA], int n, int 
     double cdf[MAXA], x[MAXA];
     int32_t cand[MAXA];
     int n_uniq = 0;
+    if constexpr (MAXA == 2) {
+        // Both of two entries (the reference's default maxium_action_sample on a two-action env, and every two-action root):
+        // the result is {0, 1} in some order and only the number of draws is open.  Round one draws twice against
+        // t = cdf[0] / cdf[1]; if both draws fall on the same side, round two zeroes the entry found and draws once more --
+        // its cdf is then {0, p1} / p1 or {p0, p0} / p0 and the other entry comes out whatever that draw is.
+        const double last = (0.0 + p[0]) + p[1];
+        if (n == 2 && size == 2 && last > 0.0 && last < __builtin_inf()) {
+            uint32_t w[4];
+            rng.template take<4>(w);
+            const double t = (0.0 + p[0]) / last;
+            const bool c0 = t <= RNG::to_double(w[0], w[1]), c1 = t <= RNG::to_double(w[2], w[3]);
+            if (c0 == c1) (void)rng.random_sample();
+            out[0] = c0 ? 1 : 0;
+            out[1] = c0 ? 0 : 1;
+            return;
+        }
+    }
     while (n_uniq < size) {
         const int m = size - n_uniq;
         if (MAXA <= 4 && m == MAXA) {            // a full round of draws: one staged-words check for all of them
