@@ -55,16 +55,41 @@ WORKLOADS = {
 }
 
 
+def _strip_comments(text):
+    """C / C++ source without comments and with runs of white space collapsed (string and character literals kept as they are)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_sha16():
-    """sha256 (first 16 hex digits) of the kernel sources + the ABI header: counter files under profiles/ carry the value they
-    were measured with, so a later kernel change drops stale `roofline.traffic` figures by itself."""
+    """sha256 (first 16 hex digits) of the kernel sources + the ABI header, comments and white space aside: counter files under
+    profiles/ carry the value they were measured with, so a later change of the kernel CODE drops stale `roofline.traffic`
+    figures by itself (and a corrected comment does not)."""
     import glob
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, "stochastic-muzero_amd", "csrc")
     for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.hpp")) + [os.path.join(ROOT, "include", "smz.h")]):
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_strip_comments(open(f, encoding="utf-8").read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -574,8 +574,6 @@ __device__ inline double div_by_count(double x, int n, const double *r64) {
     return fma(e, r, q);
 }
 
-// decision-flagged node: pUCT argmax (mcts:235-243, 257-259)
-// r64: reciprocal table (1/n at r64[n], n <= sims + 1) or nullptr (compile-time at every call site) for the IEEE division
 // The value term of a child before the MinMax normalisation: reward + discount * value() (mcts:239-241).  The backup that
 // last touched the child has computed value() = value_sum / visits for the MinMax update; YV kernels keep the term it leads
 // to beside the block (Params::thr_off) and the next descent reads it instead of dividing again -- the same two operands, the
@@ -584,6 +582,8 @@ __device__ inline float value_term(float reward, float disc32, float qv) {
     const float dv = disc32 * qv;
     return reward + dv;
 }
+// decision-flagged node: pUCT argmax (mcts:235-243, 257-259)
+// r64: reciprocal table (1/n at r64[n], n <= sims + 1) or nullptr (compile-time at every call site) for the IEEE division
 template <int N, bool YV = false>
 __device__ inline double puct_score(const Kids<N> &k, int j, double sp, bool norm, float mn, float span, float disc32,
                                     double u, const double *r64) {

@@ -8,10 +8,11 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction: parity with the reference's
 // separately rounded multiplies and adds).
-// SMZ_PART: 0 / undefined = the whole library part in one translation unit; the Makefile compiles this file twice --
+// SMZ_PART: 0 / undefined = the whole library part in one translation unit; the Makefile compiles this file five times --
 // 1 = everything but the single-launch search kernel and the fused expand+backup+select entry point, 2 = the search
 // kernel for the action buckets 2 and 4 with smz_search_mlp(_act), 4 = the search kernel for the buckets 8-32,
-// 3 = only smz_expand_backup_select, 5 = nothing but the shared helpers and the handle (included by smz_vision_search.hip)
+// 3 = only smz_expand_backup_select, 6 = the masked / Philox instantiations of the search kernel that keep the trees in LDS,
+// 5 = nothing but the shared helpers and the handle (included by smz_vision_search.hip and smz_search_reg.hip)
 // -- the template instantiations behind those are most of the compile time, and the parts build in parallel.
 #ifndef SMZ_SEARCH_THREADS
 #define SMZ_SEARCH_THREADS 512   // threads per workgroup the single-launch search is register-allocated for (8 waves: 2 per SIMD, 256 VGPRs)
@@ -677,7 +678,7 @@ constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
 // that is recomputed where needed; with one it is state that stays live through the search loop -- in the specialised
 // instantiation that costs scalar registers it does not have (35 -> 45 spilled, -3 % measured), so it exists both ways.
 // PHX: the specialised instantiation for SMZ_RNG_PHILOX handles (counter streams: no state words to load or store).
-// TLDS (specialised instantiation, when it fits: ~60 simulations at 2 actions): the workgroup's 16 trees live in LDS for the
+// TLDS (specialised instantiation, when it fits: ~53 simulations at 2 actions): the workgroup's 16 trees live in LDS for the
 // search -- a descent level is an LDS round trip instead of an L2 one, the backup's stores stay on the CU -- and go to their
 // place in global memory once, at the end.  LDS room comes from the compact weight image (smz_mlp::mat_op) and from packing
 // expansion blocks at 6 K words instead of 64-byte granules.
@@ -1831,7 +1832,7 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
 #if SMZ_PART != 4
     {   // LDS-resident trees (k_search_mlp<..., TLDS>, compiled in their own translation unit, SMZ_PART 6): the specialised
         // instantiations -- plain, masked (smz_set_active) and Philox -- when the workgroup's trees fit next to the compact
-        // weight image (checkpoint-421 shape, 2 actions: up to ~62 simulations); SMZ_SEARCH_TLDS=0 keeps the trees in global
+        // weight image (checkpoint-421 shape, 2 actions: up to ~53 simulations); SMZ_SEARCH_TLDS=0 keeps the trees in global
         // memory (A/B runs)
         const MegaLds mt = mega_lds(*desc, P, tpw, true, kWaves);
         const size_t lds_t = ((size_t)mt.trees_off + (size_t)kWaves * tpw * mt.tree_words) * sizeof(float);
