@@ -90,9 +90,8 @@ int smz_create(const smz_config *cfg, smz_handle **out);
 /* [sync] */
 int smz_destroy(smz_handle *h);
 int smz_abi_version(void);
-/* Optional pieces compiled into this library (bit mask).  SMZ_FEATURE_SEARCH_REG: the register-resident experimental search
- * kernel of csrc/smz_search_reg.hip (`make REG=1`; a measured dead end kept as evidence, selected with SMZ_SEARCH_REG=1). */
-#define SMZ_FEATURE_SEARCH_REG 1
+/* Optional pieces compiled into this library (bit mask; none at present: the register-resident experimental search kernel
+ * of rounds 2-3, a measured dead end, left the tree in round 4 -- profiles/r02_reg_kernel_ab.txt, git history). */
 int smz_build_features(void);
 const char *smz_last_error(void);
 /* Number of nodes each tree can hold: 1 + A + num_simulations * K. */

@@ -11,7 +11,6 @@ LIB_PATH = os.environ.get("SMZ_LIB_PATH") or os.path.join(_HERE, "libsmz.so")   
 
 SMZ_OK, SMZ_ERR_INVALID, SMZ_ERR_HIP, SMZ_ERR_NOMEM, SMZ_ERR_STATE, SMZ_ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5
 RNG_MT19937_NUMPY, RNG_PHILOX = 0, 1
-FEATURE_SEARCH_REG = 1
 MAX_ACTIONS = 32
 
 

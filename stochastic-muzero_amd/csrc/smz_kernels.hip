@@ -12,7 +12,7 @@
 // 1 = everything but the single-launch search kernel and the fused expand+backup+select entry point, 2 = the search
 // kernel for the action buckets 2 and 4 with smz_search_mlp(_act), 4 = the search kernel for the buckets 8-32,
 // 3 = only smz_expand_backup_select, 6 = the masked / Philox instantiations of the search kernel that keep the trees in LDS,
-// 5 = nothing but the shared helpers and the handle (included by smz_vision_search.hip and smz_search_reg.hip)
+// 5 = nothing but the shared helpers and the handle (included by smz_vision_search.hip)
 // -- the template instantiations behind those are most of the compile time, and the parts build in parallel.
 #ifndef SMZ_SEARCH_THREADS
 #define SMZ_SEARCH_THREADS 512   // threads per workgroup the single-launch search is register-allocated for (8 waves: 2 per SIMD, 256 VGPRs)
@@ -1382,13 +1382,7 @@ extern "C" {
 #if SMZ_PART == 0 || SMZ_PART == 1
 const char *smz_last_error(void) { return g_err; }
 int smz_abi_version(void) { return SMZ_ABI_VERSION; }
-int smz_build_features(void) {
-#ifdef SMZ_WITH_REG
-    return SMZ_FEATURE_SEARCH_REG;
-#else
-    return 0;
-#endif
-}
+int smz_build_features(void) { return 0; }
 int smz_node_capacity(const smz_handle *h) { return h ? h->N : SMZ_ERR_INVALID; }
 int smz_last_kernel(const smz_handle *h, char *buf, int cap) {
     if (!h || !buf || cap < 1) return fail(SMZ_ERR_INVALID, "smz_last_kernel: bad argument%s");
@@ -1721,10 +1715,6 @@ int smz_internal_search_launch_wide(smz_handle *h, const smz_mlp_desc *desc, con
 // SMZ_PART 6: the instantiations that keep the workgroup's trees in LDS (P, geometry and LDS size come from the caller)
 int smz_internal_search_launch_tlds(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
                                     int train, SearchActArgs a, Params P, int kWaves, int blocks, size_t lds_t, smz_stream stream);
-// smz_search_reg.hip: the register-resident / matrix-core kernel for the shipped network shape
-int smz_internal_search_launch_reg(smz_handle *h, const smz_mlp_desc *desc, const float *weights_dev, const float *obs_dev,
-                                   int train, double temperature, int32_t *action, double *policy, double *child_visits,
-                                   float *root_value, const double *pow_table_host, smz_stream stream);
 #if SMZ_PART == 0 || SMZ_PART == 6
 // k_search_mlp<MA, 2, 1, false, true, true, PHX, TLDS = true>: masked (smz_set_active) | Philox handles.  The caller
 // (SMZ_SEARCH_LAUNCH of SMZ_PART 2) has validated everything and computed the geometry.
@@ -1771,21 +1761,6 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     if (train && h->cfg.num_simulations > 0 && !(h->cfg.root_dirichlet_alpha > 0))
         return fail(SMZ_ERR_INVALID, "root_dirichlet_alpha must be > 0 to draw noise (numpy raises ValueError)%s");
     DeviceGuard guard(h->cfg.device);
-#if SMZ_PART == 2 && defined(SMZ_WITH_REG)
-    {   // (library built with `make REG=1`) SMZ_SEARCH_REG=1: the experimental kernel of smz_search_reg.hip for the shipped shape (S 31, H 64, L 0; 2 or 4
-        // actions, two sampled children, MT19937 streams) -- four trees per wavefront, weights in registers, layers on the
-        // matrix cores.  Bit-identical to the kernel below; measured slower at 4096 trees (338 M vs 392 M simulations/s: one
-        // wavefront per SIMD cannot overlap its tree phases with another wave's network evaluation), hence opt-in.
-        const char *reg_env = getenv("SMZ_SEARCH_REG");
-        const bool reg_on = reg_env && atoi(reg_env) == 1;
-        const bool shape = h->K == 2 && (h->P.A == 2 || h->P.A == 4) && h->P.A == h->maxa && desc->S == kFastS &&
-                           desc->H == kFastH && desc->L == kFastL && !h->P.philox;
-        const bool plain = !(h->P.stats || h->P.dbg) || (h->P.dbg & 64) != 0;
-        if (reg_on && shape && plain && !a.env.state)
-            return smz_internal_search_launch_reg(h, desc, weights_dev, obs_dev, train, a.temperature, a.action, a.policy,
-                                                  a.child_visits, a.root_value, pow_table_host, stream);
-    }
-#endif
     int kWaves = 8;
     if (const char *e = getenv("SMZ_SEARCH_WAVES")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4 || v == 8 || v == 12 || v == 16) && v * kWave <= SMZ_SEARCH_THREADS) kWaves = v; }
     Params P = h->P;

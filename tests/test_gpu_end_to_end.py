@@ -36,11 +36,13 @@ def test_batched_heads_match_reference_head_outputs(name, wname, backend):
     ncase, sims = data["tape_branch"].shape
     A = data["root_policy"].shape[-1]
     hid, pol = heads.initial(torch.from_numpy(data["obs"]).cuda())
-    # Tolerances follow what is MEASURED on MI355X (tools/head_error_report.py -> profiles/r02_head_errors.json): hidden
-    # states and policies differ from the reference's torch-CPU numbers by <= 3.6e-7 / 2.4e-7 absolute; decoded scalars
-    # (inverse support transform, muzero_model.py:575-591) by <= 1.9e-5 relative on checkpoint 421 (values ~ 70) and
-    # <= 1.3e-4 absolute near zero -- the float32 cancellation of sqrt(1 + 4 eps (|y| + 1 + eps)) - 1, which the
-    # torch-ROCm GEMM path shows to the same digit.  north_star's 1e-5 is met by everything but that transform.
+    # Tolerances follow what is MEASURED on MI355X (tools/head_error_report.py -> profiles/r04_head_errors.json): hidden
+    # states and policies differ from the reference's torch-CPU numbers by <= 3.6e-7 / 2.4e-7 absolute.  Decoded scalars
+    # (inverse support transform, muzero_model.py:575-591) are a float32 STAIRCASE in the support expectation (one stair
+    # = 1.45e-5 relative at checkpoint 421's values ~ 70, 1.2e-4 absolute near zero; golden_util.DECODE_STEP): > 99 % of
+    # the decodes are bit-identical to the reference's, the rest sit exactly one stair away, and the reference's own
+    # float32 result is 0.75 stairs (3.6e-5 relative) from the exact value of its formula on its own logits
+    # (tests/golden/decode_floor_*.npz, tests/test_decode_floor.py) -- north_star's 1e-5 is below that floor.
     torch.testing.assert_close(hid.cpu(), torch.from_numpy(data["root_hidden"]), rtol=0, atol=1e-6)
     torch.testing.assert_close(pol.cpu(), torch.from_numpy(data["root_policy"]), rtol=0, atol=1e-6)
     fe = _FakeEngine()
@@ -52,8 +54,8 @@ def test_batched_heads_match_reference_head_outputs(name, wname, backend):
     torch.cuda.synchronize()
     torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(ncase * sims, -1)), rtol=0, atol=1e-6)
     torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1)), rtol=0, atol=1e-6)
-    torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=3e-5, atol=2e-4)
-    torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=3e-5, atol=2e-4)
+    gu.assert_decoded_like_the_reference(rw.cpu().numpy(), data["tape_reward"], "reward")
+    gu.assert_decoded_like_the_reference(v2.cpu().numpy(), data["tape_value"], "value")
     assert (rw.cpu()[torch.from_numpy(data["tape_branch"].reshape(-1)) == 0] == 0).all()
 
 
@@ -244,44 +246,6 @@ def test_single_launch_search_equals_stepwise_search(wname, B, sims, K):
         assert np.array_equal(ra.random_sample(700), rb.random_sample(700))
 
 
-@pytest.mark.parametrize("wname,B,sims", [("weights_ckpt421", 4096, 50), ("weights_lunar_L0", 1030, 20), ("weights_ckpt421", 37, 3)])
-def test_register_resident_search_kernel_equals_production_kernel(wname, B, sims, monkeypatch):
-    """SMZ_SEARCH_REG=1 selects k_search_mlp_reg (smz_search_reg.hip: four trees per wavefront, weights in registers,
-    layers as v_mfma_f32_4x4x1 chains, tails on the MFMA output layout).  Its arithmetic is arranged to round like the
-    vector-unit heads (even / odd accumulator chains, sums in wave_sum's association), so whole searches must agree bit for
-    bit with the production kernel: visits, priors, values, every dumped tree array, stream positions."""
-    mcts_mod, model_mod, _, _ = _mods()
-    lib_mod = import_module("stochastic-muzero_amd._lib")
-    if not lib_mod.load().smz_build_features() & lib_mod.FEATURE_SEARCH_REG:
-        pytest.skip("libsmz.so built without the experimental kernel (make -C stochastic-muzero_amd/csrc REG=1)")
-    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
-    heads = model.heads("cuda:0", backend="hip")
-    obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(3)).mul(0.3).cuda()
-    res = []
-    for reg in ("1", "0"):
-        monkeypatch.setenv("SMZ_SEARCH_REG", reg)
-        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997,
-                                 root_exploration_fraction=0.25, use_graph=False, single_launch=True)
-        m.seed(np.arange(B, dtype=np.uint64) + 11)
-        for rep in range(2):
-            e = m.run(obs, heads, train=True, act_temperature=1.0)
-        assert m._single is True
-        visits, priors, rv, cr = e.root_stats()
-        action, policy, cv, _ = e.act(1.0)
-        torch.cuda.synchronize()
-        out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr, action, policy, cv)]
-        dumps = [e.dump_tree(i) for i in (0, 1, 2, 3, B // 2, B - 1)]
-        states = [e.get_rng_state(i) for i in (0, B - 1)]
-        res.append((out, dumps, states))
-    for a, b in zip(res[0][0], res[1][0]):
-        assert np.array_equal(a, b)
-    for da, db in zip(res[0][1], res[1][1]):
-        for k in da:
-            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
-    for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
-        assert np.array_equal(ka, kb) and pa == pb
-
-
 def test_module_heads_with_image_shaped_hidden_states_and_action_planes():
     """The generic five-module path with a vision-shaped family: hidden state [B,3,7,7], action fed as a constant
     plane (a+1)/A (muzero_model.py:511-522).  Engine and per-tree oracle are fed the SAME module outputs, so every
@@ -462,8 +426,8 @@ def test_vision_family_heads_on_gpu_match_the_reference_tape(backend):
     #  ATen's; measured 1.21e-5 on one of 29 400 hidden values, where the per-pixel min-max scaling divides by a small range)
     torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(fe.B, -1)), rtol=0, atol=2e-5)
     torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(fe.B, -1)), rtol=0, atol=1e-6)
-    torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=3e-5, atol=2e-4)
-    torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=3e-5, atol=2e-4)
+    gu.assert_decoded_like_the_reference(rw.cpu().numpy(), data["tape_reward"], "reward")
+    gu.assert_decoded_like_the_reference(v2.cpu().numpy(), data["tape_value"], "value")
 
 
 @pytest.mark.parametrize("backend", ["hip", "torch"])
@@ -528,8 +492,10 @@ def test_hip_vision_heads_agree_with_the_torch_modules_on_a_large_batch():
         rw_ref = torch.where(branch, model.inverse_transform_with_support(r_logits).flatten(), torch.zeros(B))
     torch.testing.assert_close(h2, h_ref.reshape(B, -1), rtol=0, atol=2e-5)
     torch.testing.assert_close(pol, pol_ref, rtol=0, atol=2e-5)
-    torch.testing.assert_close(rw, rw_ref, rtol=5e-5, atol=2e-4)
-    torch.testing.assert_close(val, val_ref, rtol=5e-5, atol=2e-4)
+    # decoded scalars: the hidden planes that enter the towers differ by up to 2e-5 here, so the support expectation may move
+    # by more than the reference's own rounding does -- two stairs of the float32 decode (golden_util.DECODE_STEP) instead of one
+    assert gu.decode_steps(rw.numpy(), rw_ref.numpy()).max() <= 2.05
+    assert gu.decode_steps(val.numpy(), val_ref.numpy()).max() <= 2.05
     assert (rw[~branch] == 0).all() and (rw[branch] != 0).any()
 
 
@@ -839,8 +805,8 @@ def test_checkpoint_450_deep_wide_networks_run_on_the_tile_kernel():
                        float((p2.cpu() - torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1))).abs().max()))
         torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(ncase * sims, -1)), rtol=0, atol=4e-6)
         torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1)), rtol=0, atol=2e-6)
-        torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=5e-5, atol=4e-4)
-        torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=5e-5, atol=4e-4)
+        gu.assert_decoded_like_the_reference(v2.cpu().numpy(), data["tape_value"], "value")
+        gu.assert_decoded_like_the_reference(rw.cpu().numpy(), data["tape_reward"], "reward")
     print("checkpoint 450 heads vs the reference's tape, max |hidden|, |policy| error:", worst)
     m = mcts_mod.BatchedMCTS(ncase, num_simulations=int(cfg["num_simulations"]), maxium_action_sample=2,
                              discount=float(cfg["discount"]), root_dirichlet_alpha=float(cfg["root_dirichlet_alpha"]),
@@ -899,8 +865,8 @@ def test_config434_network_shape_runs_on_the_gemm_heads():
         torch.cuda.synchronize()
         torch.testing.assert_close(h2.cpu(), torch.from_numpy(data["tape_hidden_out"].reshape(ncase * sims, -1)), rtol=0, atol=2e-6)
         torch.testing.assert_close(p2.cpu(), torch.from_numpy(data["tape_policy"].reshape(ncase * sims, -1)), rtol=0, atol=1e-6)
-        torch.testing.assert_close(v2.cpu(), torch.from_numpy(data["tape_value"].reshape(-1)), rtol=3e-5, atol=2e-4)
-        torch.testing.assert_close(rw.cpu(), torch.from_numpy(data["tape_reward"].reshape(-1)), rtol=3e-5, atol=2e-4)
+        gu.assert_decoded_like_the_reference(v2.cpu().numpy(), data["tape_value"], "value")
+        gu.assert_decoded_like_the_reference(rw.cpu().numpy(), data["tape_reward"], "reward")
     # whole batched search (step-wise kernels + GEMM heads in one HIP graph) from the fixture's seeds
     m = mcts_mod.BatchedMCTS(ncase, num_simulations=int(cfg["num_simulations"]), maxium_action_sample=2,
                              discount=float(cfg["discount"]), root_dirichlet_alpha=float(cfg["root_dirichlet_alpha"]),

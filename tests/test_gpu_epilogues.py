@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+import golden_util as gu
+
 pytestmark = pytest.mark.gpu
 
 
@@ -25,6 +27,11 @@ def _ref_scale(x):
     return (x - mn) / sc
 
 
+def _within_the_floor(out, exact64):
+    steps = gu.decode_steps(out.cpu().numpy(), exact64.cpu().numpy())
+    assert steps.max() <= gu.DECODE_FLOOR_STEPS, f"{steps.max():.3f} stairs from the exact value of the formula"
+
+
 def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -41,11 +48,10 @@ def test_support_decode(B, S):
     logits = (torch.randn(B, S, generator=g) * 3).cuda()
     out = torch.empty(B, device="cuda")
     smz._lib.check(lib.smz_support_decode(_p(logits), S, _p(out), B, _s()))
-    ref = _ref_decode(logits.double()).float()
-    # float32 cancellation in the reference formula: 2e-4 absolute near zero, 5e-5 relative elsewhere
-    torch.testing.assert_close(out, ref, rtol=5e-5, atol=2e-4)
-    logits64 = _ref_decode(logits)
-    torch.testing.assert_close(out, logits64, rtol=5e-5, atol=2e-4)
+    # the float32 formula is a staircase in the support expectation (golden_util.DECODE_STEP); the reference's own float32
+    # result is up to 0.752 stairs from the exact value (tests/test_decode_floor.py): the device must be no further
+    _within_the_floor(out, _ref_decode(logits.double()))
+    assert gu.decode_steps(out.cpu().numpy(), _ref_decode(logits).cpu().numpy()).max() <= 2 * gu.DECODE_FLOOR_STEPS   # torch-ROCm float32
 
 
 @pytest.mark.parametrize("B,A", [(4096, 2), (513, 4), (100, 18)])
@@ -72,8 +78,7 @@ def test_dynamics_and_prediction_epilogues(B, A, S):
     m = br.bool()
     ref_h = torch.where(m[:, None], _ref_scale(sd.clone()), _ref_scale(sa.clone()))
     torch.testing.assert_close(hid, ref_h, rtol=1e-6, atol=1e-6)
-    ref_r = torch.where(m, _ref_decode(rl), torch.zeros_like(rw))
-    torch.testing.assert_close(rw, ref_r, rtol=5e-5, atol=2e-4)
+    _within_the_floor(rw, torch.where(m, _ref_decode(rl.double()), torch.zeros_like(rw, dtype=torch.float64)))
     assert (rw[~m] == 0).all()
     # prediction epilogue: the four logit blocks are column slices of one [B, 2A+2S] GEMM output (row stride ld)
     ld = 2 * A + 2 * S
@@ -84,7 +89,7 @@ def test_dynamics_and_prediction_epilogues(B, A, S):
     pol = torch.empty(B, A, device="cuda"); val = torch.empty(B, device="cuda")
     smz._lib.check(lib.smz_prediction_epilogue(ptr(0), ptr(A), ptr(A + S), ptr(2 * A + S), ld, _p(br), A, S, _p(pol), _p(val), B, _s()))
     torch.testing.assert_close(pol, torch.where(m[:, None], torch.softmax(pp, -1), torch.softmax(pa, -1)), rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(val, torch.where(m, _ref_decode(vp), _ref_decode(va)), rtol=5e-5, atol=2e-4)
+    _within_the_floor(val, torch.where(m, _ref_decode(vp.double()), _ref_decode(va.double())))
 
 
 def test_cartpole_step_and_traj_pack():

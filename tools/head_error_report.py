@@ -21,10 +21,12 @@ class FE:
     pass
 
 
-def err(a, b):
+def err(a, b, decoded=False):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     d = np.abs(a - b)
-    return dict(max_abs=float(d.max()), max_rel=float((d / np.maximum(np.abs(b), 1e-30))[np.abs(b) > 1e-3].max()) if (np.abs(b) > 1e-3).any() else 0.0,
+    steps = gu.decode_steps(a, b) if decoded else None
+    extra = dict(max_stairs=float(steps.max())) if decoded else {}
+    return dict(**extra, max_abs=float(d.max()), max_rel=float((d / np.maximum(np.abs(b), 1e-30))[np.abs(b) > 1e-3].max()) if (np.abs(b) > 1e-3).any() else 0.0,
                 mean_abs=float(d.mean()))
 
 
@@ -56,13 +58,13 @@ def main():
             dyn = data["tape_branch"].reshape(-1) == 1
             r = dict(hidden=err(h2.cpu().numpy(), data["tape_hidden_out"].reshape(ncase * sims, -1)),
                      policy=err(p2.cpu().numpy(), data["tape_policy"].reshape(ncase * sims, -1)),
-                     value=err(v2.cpu().numpy(), data["tape_value"].reshape(-1)),
-                     reward=err(rw.cpu().numpy()[dyn], data["tape_reward"].reshape(-1)[dyn]) if dyn.any() else None,
+                     value=err(v2.cpu().numpy(), data["tape_value"].reshape(-1), decoded=True),
+                     reward=err(rw.cpu().numpy()[dyn], data["tape_reward"].reshape(-1)[dyn], decoded=True) if dyn.any() else None,
                      evaluations=int(ncase * sims), heads=type(heads).__name__)
             rep[f"{name}/{backend}"] = r
-            print(name, backend, "hidden %.2e policy %.2e value abs %.2e rel %.2e reward rel %.2e" % (
-                r["hidden"]["max_abs"], r["policy"]["max_abs"], r["value"]["max_abs"], r["value"]["max_rel"],
-                r["reward"]["max_rel"] if r["reward"] else 0.0))
+            print(name, backend, "hidden %.2e policy %.2e value abs %.2e rel %.2e stairs %.3f reward rel %.2e stairs %.3f" % (
+                r["hidden"]["max_abs"], r["policy"]["max_abs"], r["value"]["max_abs"], r["value"]["max_rel"], r["value"]["max_stairs"],
+                r["reward"]["max_rel"] if r["reward"] else 0.0, r["reward"]["max_stairs"] if r["reward"] else 0.0))
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     json.dump(rep, open(out_path, "w"), indent=1)
 
