@@ -203,8 +203,36 @@ def cpu_baseline_vision(wl, model, seconds_target=12.0):
         done += sims
     dt = time.perf_counter() - t0
     return dict(value=done / dt, unit="simulations/s", cores=1, kind="port",
-                sample=f"{done // sims} searches x {sims} sims on 98x98x3 frames, oracle tree (oracle/smz_oracle.c) driven by "
-                       f"batch-1 torch-CPU heads of the same ResNet-v2 weights, 1 process / 1 torch thread, {dt:.1f} s")
+                sample=f"PER CORE: {done // sims} searches x {sims} sims on 98x98x3 frames, oracle tree (oracle/smz_oracle.c) driven by "
+                       f"batch-1 torch-CPU heads of the same ResNet-v2 weights, 1 process / 1 torch thread of {host_cores()} host "
+                       f"cores, {dt:.1f} s (the reference's Ray fan-out would run one such process per core)")
+
+
+class ReplaySink:
+    """What ReplayBuffer.save_game does with a game (replay_buffer.py:109-137), restated as the bench's sink: evict beyond the
+    window, make_priority(td_steps) -> per-position and per-game priorities, append, count positions; games that were not
+    reanalysed would also go to the reanalyse stack (empty here).  Left out: the re-normalisation of soft_prio_game after every
+    save (np.array(prio_game) / sum: O(buffer) per game, the reference's own quadratic cost -- not this engine's)."""
+
+    def __init__(self, td_steps=50, window_size=10 ** 9):
+        self.td_steps, self.window_size = td_steps, window_size
+        self.buffer, self.prio_position, self.prio_game, self.positions = [], [], [], 0
+
+    def save_game(self, game):
+        if len(self.buffer) > self.window_size:
+            self.positions -= self.buffer.pop(0).game_length
+            self.prio_position.pop(0)
+            self.prio_game.pop(0)
+        pos, top = game.make_priority(self.td_steps)
+        self.prio_position.append(pos)
+        self.prio_game.append(top)
+        self.buffer.append(game)
+        self.positions += game.game_length
+        if not game.reanalyzed:
+            pass                                           # reanalyse_buffer_save_game: no reanalyse buffers in the bench
+
+    def clear(self):
+        self.buffer, self.prio_position, self.prio_game, self.positions = [], [], [], 0
 
 
 def self_launch(args, argv):
@@ -224,7 +252,7 @@ def self_launch(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=None, help="env steps per timed block (default 16; 64 with --end-to-end)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cartpole_mlp_4096x50", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the workload's)")
@@ -238,8 +266,15 @@ def main():
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SMZ_STREAM_GROUPS", "0")),
                     help="independent env groups per GPU, each on its own HIP stream (0 = 2 groups from 262 144 envs on -- "
                          "one group's tree kernel overlaps the other's network kernel: +6..14 % measured -- else 1)")
-    ap.add_argument("--min-timed-seconds", type=float, default=0.5, help="repeat the K-step block until this much is timed")
-    ap.add_argument("--max-blocks", type=int, default=200)
+    ap.add_argument("--min-timed-seconds", type=float, default=8.0,
+                    help="repeat the K-step block until this much is timed (default 8 s: ~900 blocks of the headline workload, so "
+                         "that the timed region is the larger part of the command's run time)")
+    ap.add_argument("--max-blocks", type=int, default=4000)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=6.0, help="wall-clock budget of the cpu_baseline sample (all host cores)")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="time selfplay.self_play_iteration, the function learning_cycle calls (self_play.py:245-271): K env steps, the "
+                         "chunk's transfer to the host, Game records (selfplay.chunk_to_records) and replay_buffer.save_game of every "
+                         "game into a sink that does ReplayBuffer.save_game's per-game work -- its own labelled line, never the headline")
     ap.add_argument("--rng", default="mt19937", choices=["mt19937", "philox"],
                     help="mt19937: per-tree numpy-legacy streams (parity mode, the headline); philox: counter-based "
                          "streams (throughput mode: same distributions, different numbers) -- reported as its own workload")
@@ -247,7 +282,14 @@ def main():
                     help="cartpole workloads: step the envs on the HOST -- the PCIe-inclusive rate of the boundary's "
                          "host-buffer variant: 'python' = envs.HostVecEnv over Python CartPoles (measures the Python), 'native' = "
                          "envs.HostCartPoleVec (compiled host step, smz_host_cartpole_step)")
+    ap.add_argument("--host-workers", type=int, default=None,
+                    help="--host-env python: env worker processes per GPU, split over the env groups (default min(64, host cores / 2); "
+                         "0 = step the envs serially in this process)")
+    ap.add_argument("--frame-upload", default="taps", choices=["taps", "frames"],
+                    help="--host-env on the vision workload: upload only the pixels the 98x98 resize reads (taps) or whole frames")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 64 if args.end_to_end else 16
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -296,8 +338,17 @@ def main():
         model = model_mod.Muzero.from_arrays(wpath)      # trained ckpt-421 weights exported as plain arrays
     total = B * world
     lo = rank * B
+    # the CPU leg runs FIRST (rank 0, N = 1 only, bounded wall time): the GPU part then fills the rest of the command's run time
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = (cpu_baseline_vision(wl, model, args.cpu_baseline_seconds) if wl["env"] == "image"
+                        else cpu_baseline_mlp(wl, wpath, args.cpu_baseline_seconds))
     T = max(args.steps, args.warmup, 1)
-    G = args.groups if args.groups > 0 else (2 if (B >= 262144 and B % 2 == 0) else 1)
+    # host envs behind Python (--host-env python): two env groups, so that one group's search runs while the other's envs step
+    G = args.groups if args.groups > 0 else (2 if ((B >= 262144 or args.host_env == "python") and B % 2 == 0) else 1)
+    host_workers = 0
+    if args.host_env == "python":
+        host_workers = args.host_workers if args.host_workers is not None else min(64, max(1, host_cores() // 2))
     assert B % G == 0, "--groups must divide the env count"
     Bg = B // G
     groups = []
@@ -306,15 +357,16 @@ def main():
         if wl["env"] == "cartpole" and args.host_env == "native":
             env = envs_mod.HostCartPoleVec(Bg, dev, seed=0, first_env=glo)
         elif wl["env"] == "cartpole" and args.host_env:
-            env = envs_mod.HostVecEnv([envs_mod.HostCartPole() for _ in range(Bg)], 4, 2, dev, env_seed=0, limit=0,
-                                      on_end="reset", first_env=glo)
+            env = envs_mod.HostVecEnv([envs_mod.HostCartPole for _ in range(Bg)], 4, 2, dev, env_seed=0, limit=0,
+                                      on_end="reset", first_env=glo, workers=host_workers // G)
         elif wl["env"] == "cartpole":
             env = envs_mod.CartPoleVec(Bg, dev, seed=0, first_env=glo, total_envs=total)
         elif wl["env"] == "image" and args.host_env:
             # host envs observed through rendered 400x600x3 uint8 frames (CartPole-v1's render size), uploaded
             # through pinned memory and resized to 98x98 on the engine's stream (smz_frames_resize_u8)
             env = envs_mod.HostImageVecEnv([envs_mod.HostCartPoleRender((400, 600)) for _ in range(Bg)], (400, 600), wl["A"], dev,
-                                           env_seed=0, limit=0, on_end="reset", first_env=glo)
+                                           env_seed=0, limit=0, on_end="reset", first_env=glo, workers=host_workers // G,
+                                           upload=args.frame_upload)
         elif wl["env"] == "image":
             env = envs_mod.ImageVec(Bg, wl["A"], dev, seed=0, first_env=glo, total_envs=total)
         else:
@@ -355,6 +407,28 @@ def main():
             gather_chunks(chunks, args.steps)
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
+
+    sink = ReplaySink(td_steps=50)                            # config/experiment_421_config.json: td_steps 50
+    e2e_parts = []
+    if args.end_to_end:
+        assert G == 1, "--end-to-end times self_play_iteration: one env group"
+
+        def gather_fn(x):
+            return gather_mod.gather_to_learner(x)
+
+        def timed_block():                                    # noqa: F811  (replaces the search-only block)
+            """ONE self_play_iteration of K steps -- play, (gather,) transfer, Game records, save_game x games -- between two
+            barrier + synchronize pairs; max over ranks."""
+            sink.clear()
+            barrier()
+            t0 = time.perf_counter()
+            games, _ = sp.self_play_iteration(env, model, mcts, args.temperature, args.steps, replay_buffer=sink,
+                                              gather=gather_fn if world > 1 else None, ignore_termination=True)
+            barrier()
+            dt_block = max_over_ranks(time.perf_counter() - t0)
+            if rank == 0:
+                e2e_parts.append((len(games), sink.positions))
+            return dt_block
 
     # one priming step outside everything: code-object upload, LDS opt-in and allocator warm-up are initialisation, not
     # part of a step (a run with --warmup 0 would otherwise time them)
@@ -398,7 +472,8 @@ def main():
             gts.append(max_over_ranks(time.perf_counter() - t0))
         gather_ms = 1e3 * float(np.median(gts))
     sims_total = total * wl["sims"] * args.steps
-    headline = args.workload == "cartpole_mlp_4096x50" and B == 4096 and not args.host_env and args.rng == "mt19937"
+    headline = (args.workload == "cartpole_mlp_4096x50" and B == 4096 and not args.host_env and args.rng == "mt19937"
+                and not args.end_to_end)
     single = getattr(mcts, "_single", None) is True
     data_note = {"cartpole": "synthetic (CartPole-shaped Euler env, fixed-length episodes; checkpoint-421 weights)",
                  "synthetic": "synthetic (N(0,1) observations of LunarLander width generated on the device; random-init weights, reference init rule)",
@@ -413,17 +488,21 @@ def main():
                         ("step-wise kernels" + ("" if args.no_graph else ", one HIP graph per env step")),
               "stream_groups": G, "heads": type(groups[0].heads).__name__,
               "env": ("host, compiled step (envs.HostCartPoleVec: pinned-memory action download + observation upload per step)" if args.host_env == "native"
-                      else "host, Python envs rendering 400x600x3 uint8 frames (envs.HostImageVecEnv: pinned-memory frame upload + smz_frames_resize_u8 per step)" if (args.host_env and wl["env"] == "image")
-                      else "host, Python envs (envs.HostVecEnv, pinned-memory action download + observation upload per step)" if args.host_env else "device"),
+                      else f"host, Python envs rendering 400x600x3 uint8 frames (envs.HostImageVecEnv: {host_workers} worker processes over {G} env group(s), page-locked shared block, "
+                           f"upload = {args.frame_upload}: " + ("115 KB of resize taps per frame + smz_frames_resize_taps_u8" if args.frame_upload == "taps" else "720 KB frames + smz_frames_resize_u8") + " per step)" if (args.host_env and wl["env"] == "image")
+                      else f"host, Python envs (envs.HostVecEnv: {host_workers} worker processes over {G} env group(s) writing into a page-locked shared block; action download + observation upload per step; "
+                           "one group's search overlaps the other's host step)" if args.host_env else "device"),
+              "host_workers": host_workers if args.host_env == "python" else None,
               "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}
     if world > 1:
         config["collective_backend"] = "nccl (RCCL)" if backend == "nccl" else f"{backend} ({world} ranks share {n_dev} GPU(s))"
         config["ranks"] = world
         config["ranks_seen_by_collective"] = ranks_seen
         config["gpus_visible"] = n_dev
-    out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs x 50 sims" if headline else
+    out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs \u00d7 50 sims" if headline else
                      f"MCTS simulations/sec (whole node), {args.workload} at {B} envs/GPU" + (" (host-resident envs)" if args.host_env else "")
-                     + (" (Philox throughput-mode random streams)" if args.rng == "philox" else ""),
+                     + (" (Philox throughput-mode random streams)" if args.rng == "philox" else "")
+                     + (" (END TO END: self_play_iteration = search + transfer + Game records + save_game)" if args.end_to_end else ""),
            "value": sims_total / dt, "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32 (tree values, heads) + f64 (pUCT scores, root priors) + i32 (counts)",
@@ -434,6 +513,29 @@ def main():
                       "timed_region_s": float(np.sum(blocks)),
                       "rule": "value and ms_per_step from the median block; every block is K steps between barrier + "
                               "synchronize pairs, max over ranks"}}
+    if args.end_to_end and rank == 0:
+        # where one iteration's time goes (one extra iteration, each part between synchronisations)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        env.reset()
+        chunk = sp.play_games(env, heads, mcts, args.temperature, args.steps)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        games = sp.chunk_to_records(chunk, None, env.num_actions, mcts.discount, limit_of_game_play=args.steps,
+                                    ignore_termination=True, td_steps=sink.td_steps, observation_shape=getattr(env, "frame", None))
+        t2 = time.perf_counter()
+        sink.clear()
+        for g in games:
+            sink.save_game(g)
+        t3 = time.perf_counter()
+        out["end_to_end"] = {"games_per_iteration": e2e_parts[-1][0], "positions_per_iteration": e2e_parts[-1][1],
+                             "search_ms": 1e3 * (t1 - t0), "records_ms": 1e3 * (t2 - t1), "save_game_ms": 1e3 * (t3 - t2),
+                             "records": "selfplay.chunk_to_records: game ends + n-step targets + priorities on the device, env-major "
+                                        "transposes, transfer to the host, one ArrayGameRecord per game",
+                             "sink": "bench.ReplaySink.save_game per game: make_priority(td_steps=50) + priority / position "
+                                     "bookkeeping (replay_buffer.py:109-137 without its O(buffer) re-normalisation per save)",
+                             "note": "the three parts of ONE extra iteration, each between synchronisations; `value` is the whole "
+                                     "self_play_iteration call (env.reset + play + records + save), median block"}
     if per_rank_rate is not None:
         out["per_rank_simulations_per_s"] = per_rank_rate
         out["timing"]["gather_ms_median"] = gather_ms
@@ -532,7 +634,8 @@ def main():
         # workgroups) -- nothing to contend with, every latency exposed.  frac = chain / launch says how much of the launch the
         # dependent chain alone explains; the second wavefront per SIMD then adds its whole work for the remaining 1 - frac.
         bound_actual = None
-        if single and wl["env"] != "image" and Bg % 2 == 0 and Bg // 2 >= 1024:
+        # (a geometry the user forced with SMZ_SEARCH_WAVES applies to the production launch too: the comparison would be void)
+        if single and wl["env"] != "image" and Bg % 2 == 0 and Bg // 2 >= 1024 and "SMZ_SEARCH_WAVES" not in os.environ:
             os.environ["SMZ_SEARCH_WAVES"] = "4"
             try:
                 Bh = Bg // 2
@@ -571,7 +674,9 @@ def main():
         # ... of the kernel instantiation that actually ran (smz_last_kernel), same workload, same kernel sources
         traffic, traffic_note = None, None
         launched = eng.last_kernel() if single else ""
-        if single and Bg == wl["envs"]:
+        if os.environ.get("SMZ_LIB_PATH"):
+            traffic_note = "SMZ_LIB_PATH is set: a variant library does not inherit counter files measured on the default build"
+        elif single and Bg == wl["envs"]:
             tj, tname = find_traffic(args.workload + ("" if args.rng == "mt19937" else "+philox"), launched)
             if tj is not None:
                 traffic = tj["hbm_bytes_per_launch_raw"]
@@ -621,8 +726,11 @@ def main():
         r["hbm"] = {k: r[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_note", "bytes_per_launch")}
         r.update(bound="compute", achieved=c["achieved"], peak=c["peak"], unit=c["unit"], frac=c["frac"],
                  flops_per_launch=c["flops_per_launch"], macs_per_leaf=c["macs_per_leaf"], compute_note=c["note"])
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:                                # N=1 only (contract)
-        out["cpu_baseline"] = cpu_baseline_vision(wl, model) if wl["env"] == "image" else cpu_baseline_mlp(wl, wpath)
+    if cpu_baseline is not None:                                                            # N=1 only (contract)
+        out["cpu_baseline"] = cpu_baseline
+    for g in groups:
+        if hasattr(g.env, "close"):
+            g.env.close()                                  # host envs: the worker processes exit
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

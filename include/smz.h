@@ -24,6 +24,7 @@
 #ifndef SMZ_H
 #define SMZ_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -298,6 +299,19 @@ int smz_vision_initial_record(const smz_vision_desc *desc, const float *weights_
  * a full batch.  SMZ_ERR_TOO_LARGE for rows wider than ~10 000 pixels. */
 int smz_frames_resize_u8(const uint8_t *frames_dev, int n_frames, int H, int W, int out_h, int out_w, const int32_t *rows_dev,
                          float *out_dev, smz_stream stream);
+/* The same resize from TAP-COMPACTED frames (round 4): taps_dev [n][2 out_h][2 out_w][3] uint8 holds of each H x W frame only
+ * the pixels the resize reads -- row 2 oy + r = source row y_r(oy), column 2 ox + q = source column x_q(ox), the (i0, i1) pairs
+ * of ATen's align_corners = False index rule (host_envs.tap_index) -- 115 KB instead of 720 KB per 400 x 600 frame over PCIe.
+ * Bit-identical to smz_frames_resize_u8 on the full frames. */
+int smz_frames_resize_taps_u8(const uint8_t *taps_dev, int n_frames, int H, int W, int out_h, int out_w, const int32_t *rows_dev,
+                              float *out_dev, smz_stream stream);
+/* Host-buffer boundary (replaces the per-frame / per-observation torch.tensor(...) of game.py:145-167 and the Ray
+ * object store of self_play.py:240-256 for envs that live on the host): [sync] page-lock / release a caller-owned host mapping
+ * (e.g. the shared-memory block the env worker processes write their rows into), and copy between it and device memory
+ * asynchronously on the caller's stream (to_device != 0: host -> device). */
+int smz_host_register(void *host_ptr, size_t bytes);
+int smz_host_unregister(void *host_ptr);
+int smz_copy_async(void *dst, const void *src, size_t bytes, int to_device, smz_stream stream);
 /* recurrent step for all trees, one wavefront per leaf: parent_hidden_dev [B,ld] (first 147 floats of each row),
  * last_action_dev [B], branch_dev [B] as written by smz_select -> hidden_out_dev [B,147], reward_out_dev [B] (0 on the
  * afterstate branch), policy_out_dev [B,A], value_out_dev [B].  The action enters as the constant plane (a+1)/A

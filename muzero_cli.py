@@ -107,8 +107,9 @@ def main(argv):
         steps = opts["steps"] or int(min(p["game_iter"], config["gameplay"]["limit_of_game_play"]))
         chunk = sp.play_games(env, model.heads(device), search, p["temperature"], steps,
                               train=bool(p["mcts_with_or_without_dirichlet_noise"]))
-        torch.cuda.synchronize()
-        games = sp.chunk_to_games(chunk.data, env.obs_dim, env.num_actions, search.discount, limit_of_game_play=steps)
+        # (the chunk itself says where its observations live: wider than TrajectoryChunk.SPLIT_OBS they are in chunk.obs)
+        games = sp.chunk_to_records(chunk, None, env.num_actions, search.discount, limit_of_game_play=steps,
+                                    observation_shape=getattr(env, "frame", None))
         rewards = [sum(g.rewards) for g in games]
         out["play"] = dict(games=len(games), mean_reward=float(np.mean(rewards)), max_reward=float(np.max(rewards)),
                            min_reward=float(np.min(rewards)), steps=steps)

@@ -99,6 +99,10 @@ SIGNATURES = {
                                               C.POINTER(CartPoleEnv), _P]),
     "smz_search_mlp": (C.c_int, [_P, C.POINTER(MlpDesc), _P, _P, C.c_int, _P]),
     "smz_frames_resize_u8": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "smz_frames_resize_taps_u8": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "smz_host_register": (C.c_int, [_P, C.c_size_t]),
+    "smz_host_unregister": (C.c_int, [_P]),
+    "smz_copy_async": (C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
     "smz_search_vision": (C.c_int, [_P, C.POINTER(VisionDesc), _P, _P, _P, C.c_int, _P]),
     "smz_search_vision_act": (C.c_int, [_P, C.POINTER(VisionDesc), _P, _P, _P, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
     "smz_cartpole_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),

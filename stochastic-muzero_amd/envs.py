@@ -9,6 +9,8 @@ import ctypes as C
 import os
 
 import numpy as np
+import time
+
 import torch
 
 from . import _lib
@@ -174,292 +176,327 @@ class ImageVec:
         return self.obs, self.reward, self.terminated
 
 
-class HostCartPole:
-    """One CartPole-v1 shaped game on the host behind the gym call shape (reset(seed=) -> (obs, info); step(a) -> (obs,
-    reward, terminated, truncated, info)): float64 Euler physics with CartPole-v1's published constants, the arithmetic
-    of smz_cartpole_step.  gymnasium is not part of this build; this class is what the host-environment path is
-    exercised with, and what `muzero_cli.py` uses for a single-game run."""
-    metadata = {"render_fps": 50}
+from .host_envs import HostCartPole, HostCartPoleRender  # noqa: E402,F401  (numpy-only module: the worker processes import it too)
+from . import host_envs as _he  # noqa: E402
 
-    def __init__(self):
-        self.state = None
 
-    def reset(self, seed=None):
-        self.state = np.random.RandomState(seed).uniform(-0.05, 0.05, size=4)
-        return self.state.astype(np.float32), {}
-
-    def step(self, action):
-        if action not in (0, 1):
-            raise ValueError(f"illegal action {action!r}")
-        x, xd, th, thd = (float(v) for v in self.state)
-        force = 10.0 if action == 1 else -10.0
-        ct, sn = np.cos(th), np.sin(th)
-        temp = (force + 0.05 * thd * thd * sn) / 1.1
-        tha = (9.8 * sn - ct * temp) / (0.5 * (4.0 / 3.0 - 0.1 * ct * ct / 1.1))
-        xa = temp - 0.05 * tha * ct / 1.1
-        self.state = np.array([x + 0.02 * xd, xd + 0.02 * xa, th + 0.02 * thd, thd + 0.02 * tha])
-        term = bool(abs(self.state[0]) > 2.4 or abs(self.state[2]) > 12 * 2 * np.pi / 360)
-        return self.state.astype(np.float32), 1.0, term, False, {}
-
-    def close(self):
+class _Done:
+    def synchronize(self):
         pass
 
 
 class HostVecEnv:
     """B environments that live on the HOST (gymnasium-style objects) behind the interface the batched loop drives
-    (SURVEY 8f-4): per env step one pinned-memory download of the B actions and one pinned-memory upload of the B
-    observations / rewards / flags, both asynchronous on the engine's stream; the only host wait is for the actions.
+    (SURVEY 8f-4): per env step one download of the B actions and one upload of the B observations / rewards / flags through
+    page-locked memory, both asynchronous on the engine's stream; the only host wait is for the actions.
 
-    `envs`: a list of B single environments (reset(seed=) -> obs | (obs, info); step(a) -> (obs, reward, terminated, ...)).
-    Per env the wrapper keeps what the reference's Game keeps around env.step (game.py:96-131, 223-273):
-      * the first observation comes from env.reset(seed=env_seed + global env index) (game.py:102 draws that seed from
-        Python's unseeded `random`; a reproducible rule replaces the draw);
-      * a step that raises is an illegal move: observation unchanged, reward min(-steps so far, -limit, -1), termination
-        flag unchanged (game.py:123-131);
-      * flags as smz_cartpole_step_ctl: 1 terminated, 2 stopped by `limit` (game.py:270-271), 3 no step (switched off);
-      * on_end "mask": a finished env is switched off (`active`, handed to the search); "reset": it is reset at once and
-        the NEXT search sees the fresh observation while the record keeps the post-step one (`record_obs`).
+    `envs`: a list of B single environments (reset(seed=) -> obs | (obs, info); step(a) -> (obs, reward, terminated, ...)) or
+    of zero-argument callables that build one (the gymnasium.vector convention).  The rules the reference's Game keeps around
+    env.step (first observation from reset(seed=env_seed + global index), illegal-move rule, limit / termination flags, mask /
+    reset at a game's end: game.py:96-131, 223-273) live in host_envs.HostSlice.
+
+    workers = 0: the envs are stepped in this process, one after the other (the serial adapter).
+    workers = N: N child processes (fresh interpreters that import numpy and the env's module, never torch or the GPU runtime),
+    each stepping a contiguous slice of the envs with the same HostSlice code and writing its rows straight into ONE shared,
+    page-locked block the GPU copies from -- the Ray fan-out of self_play.py:240-256 without pickling a model or a game per
+    task.  Results are identical to workers = 0 env by env (tests/test_host_envs.py, test_gpu_host_envs.py).
+
+    step(action) = step_begin(action) + step_end(): the split lets selfplay.play_games_grouped search one env group on the
+    GPU while another group's envs step on the host.
     Observations are flattened float32 vectors (game.py:145-167); rendered RGB frames: HostImageVecEnv."""
 
     def __init__(self, envs, obs_dim, num_actions, device, action_map=None, env_seed=0, limit=0, on_end="reset", first_env=0,
-                 transform=None):
+                 transform=None, workers=0, _adapter=None):
         assert on_end in ("mask", "reset")
-        self.envs, self.B = list(envs), len(envs)
+        self.lib = _lib.load()
+        self.B = len(envs)
         self.obs_dim, self.num_actions = int(obs_dim), int(num_actions)
         self.device = torch.device(device)
         self.action_map = list(action_map) if action_map is not None else list(range(self.num_actions))
         self.env_seed, self.limit, self.on_end, self.first_env = int(env_seed), int(limit), on_end, int(first_env)
-        self.transform = transform
-        B = self.B
-        pin = dict(pin_memory=torch.cuda.is_available())
-        self._h_reward = torch.zeros(B, dtype=torch.float32, **pin)
-        self._h_flag = torch.zeros(B, dtype=torch.uint8, **pin)
-        self._h_active = torch.ones(B, dtype=torch.uint8, **pin)
-        self._h_action = torch.zeros(B, dtype=torch.int32, **pin)
+        self.adapter = _adapter if _adapter is not None else _he.VectorAdapter(self.obs_dim, transform)
+        self.workers = int(min(max(0, workers), self.B))
+        B, row, dtype = self.B, self.adapter.row, self.adapter.dtype
+        lay = _he.block_layout(B, row, dtype)
+        self._procs, self._block, self._registered, self._seq = [], None, False, 0
+        if self.workers:
+            self._block = _he.SharedBlock(lay["total"])
+            buf = self._block.mm
+            self._base = torch.frombuffer(buf, dtype=torch.uint8)
+            if self.device.type != "cpu":             # (device "cpu": the CPU tests of the stepping logic, no GPU runtime)
+                _lib.check(self.lib.smz_host_register(C.c_void_p(self._base.data_ptr()), lay["total"]))
+                self._registered = True
+        else:
+            self._base = torch.zeros(lay["total"], dtype=torch.uint8, pin_memory=self.device.type != "cpu")
+            buf = memoryview(self._base.numpy())
+        self._arr, self._ctrl, self._lay = _he.map_arrays(buf, B, row, dtype, max(1, self.workers))
+        self._host_ptr = self._base.data_ptr()
+        tdt = torch.float32 if dtype is np.float32 else torch.uint8
+        self._d_action = torch.zeros(B, dtype=torch.int32, device=self.device)
         self.reward = torch.zeros(B, dtype=torch.float32, device=self.device)
         self.terminated = torch.zeros(B, dtype=torch.uint8, device=self.device)
         self.active = torch.ones(B, dtype=torch.uint8, device=self.device) if on_end == "mask" else None
-        self.step_count = np.zeros(B, np.int64)
-        self.episode = np.zeros(B, np.int64)
-        self.done = np.zeros(B, bool)
+        self._d_rows = torch.zeros(B, row, dtype=tdt, device=self.device)          # the envs' rows as uploaded
+        self._side_cap = 0
         self.transfer_seconds = 0.0            # host time spent waiting for the action download (diagnostic)
-        self._alloc_observations(pin)
+        self.host_step_seconds = 0.0           # host time spent stepping (or waiting for the workers)
+        self.upload_bytes = 0
+        self._pending = None
+        self._alloc_observations()
+        if self.workers:
+            self._start_workers(envs)
+            self._slice = None
+        else:
+            envs = [_he.build_env(e) for e in envs]
+            self._slice = _he.HostSlice(envs, 0, self.adapter, self._arr, self.action_map, self.env_seed, self.limit, self.on_end,
+                                        self.first_env)
+        self.envs = self._slice.envs if self._slice is not None else None
 
-    # ---- observation storage (vector observations; HostImageVecEnv overrides these four) -------------------------------
-    def _alloc_observations(self, pin):
-        B, o = self.B, self.obs_dim
-        self._h_obs = torch.zeros(B, o, dtype=torch.float32, **pin)          # next search's input
-        self._h_rec = torch.zeros(B, o, dtype=torch.float32, **pin)          # post-step observation (the record's)
-        self.obs = torch.zeros(B, o, dtype=torch.float32, device=self.device)
-        self.record_obs = torch.zeros(B, o, dtype=torch.float32, device=self.device)
+    @property
+    def episode(self):
+        """Game number of every env (serial adapter only: with workers the counters live in the worker processes)."""
+        if self._slice is None:
+            raise AttributeError("episode counters live in the worker processes (workers > 0)")
+        return self._slice.episode
 
-    def _observe(self, env, obs):
-        """What the agent sees after env.reset / env.step returned `obs`."""
-        obs = obs[0] if isinstance(obs, tuple) else obs
-        if self.transform is not None:
-            obs = self.transform(obs)
-        return np.asarray(obs, dtype=np.float32).reshape(-1)
+    @property
+    def step_count(self):
+        if self._slice is None:
+            raise AttributeError("step counters live in the worker processes (workers > 0)")
+        return self._slice.step_count
 
-    def _store(self, i, seen, after_step):
-        """Keeps env i's observation: after a step it is both the record's and (until a reset replaces it) the next
-        search's input; after a reset only the latter."""
-        row = torch.from_numpy(seen)
-        self._h_obs[i] = row
+    # ---- observation tensors (vector observations; HostImageVecEnv overrides these) --------------------------------------
+    def _alloc_observations(self):
+        self.obs = self._d_rows                                                   # [B, obs_dim] float32: the uploaded rows themselves
+        self.record_obs = torch.zeros_like(self._d_rows)                          # post-step observations (the record's)
+        self.record_patch = None
+
+    def _rows_to_observations(self, rows_dev, n, index_dev, out):
+        """Turns n uploaded rows into observation rows of `out` (row index_dev[i], or i)."""
+        if index_dev is None:
+            if out is not rows_dev:
+                out.copy_(rows_dev)
+        else:
+            out.index_copy_(0, index_dev[:n].long(), rows_dev[:n])
+
+    def _publish(self, after_step):
+        """The rows of this step are on the device (self._d_rows): derive `obs` and what the record shows."""
         if after_step:
-            self._h_rec[i] = row
+            self.record_obs.copy_(self._d_rows)
 
-    def _keep(self, i):
-        """A step that did not change env i's observation (illegal move, game.py:123-131): the record's row is the current one."""
-        self._h_rec[i] = self._h_obs[i]
+    def _patch_record(self, n):
+        self._rows_to_observations(self._d_side, n, self._d_side_rows, self.record_obs)
 
-    def _upload_observations(self, after_step):
-        self.obs.copy_(self._h_obs, non_blocking=True)
+    # ---- transfers ----------------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _h2d(self, dst, name, nbytes=None):
+        off = self._lay[name]
+        nbytes = dst.numel() * dst.element_size() if nbytes is None else nbytes
+        if self.device.type == "cpu":              # (CPU tests of the stepping logic: no GPU runtime, a plain copy)
+            dst.view(-1).view(torch.uint8).numpy()[:] = np.frombuffer(self._base.numpy(), np.uint8, nbytes, off)
+            return
+        _lib.check(self.lib.smz_copy_async(C.c_void_p(dst.data_ptr()), C.c_void_p(self._host_ptr + off), nbytes, 1, self._stream()))
+
+    def _upload(self, after_step):
+        B = self.B
+        self._h2d(self._d_rows, "obs")
+        self.upload_bytes += self._d_rows.numel() * self._d_rows.element_size()
+        self._publish(after_step)
         if after_step:
-            self.record_obs.copy_(self._h_rec, non_blocking=True)
+            self._h2d(self.reward, "reward")
+            self._h2d(self.terminated, "flag")
+            ended = np.nonzero(self._arr["ended"])[0]
+            n = len(ended)
+            if n:                                  # envs reset inside this step: their post-step rows go into the record
+                if n > self._side_cap:
+                    self._side_cap = max(n, 2 * self._side_cap, 8)
+                    pin = dict(pin_memory=self.device.type != "cpu")
+                    self._h_side = torch.zeros(self._side_cap, self.adapter.row, dtype=self._d_rows.dtype, **pin)
+                    self._h_side_rows = torch.zeros(self._side_cap, dtype=torch.int32, **pin)
+                    self._d_side = torch.zeros(self._side_cap, self.adapter.row, dtype=self._d_rows.dtype, device=self.device)
+                    self._d_side_rows = torch.zeros(self._side_cap, dtype=torch.int32, device=self.device)
+                self._h_side.numpy()[:n] = self._arr["rec"][ended]
+                self._h_side_rows.numpy()[:n] = ended
+                self._d_side[:n].copy_(self._h_side[:n], non_blocking=True)
+                self._d_side_rows[:n].copy_(self._h_side_rows[:n], non_blocking=True)
+                self.upload_bytes += n * self.adapter.row * self._d_rows.element_size()
+                self._patch_record(n)
+            else:
+                self.record_patch = None
+        if self.active is not None:
+            self._h2d(self.active, "active")
+
+    # ---- workers --------------------------------------------------------------------------------------------------------------
+    def _start_workers(self, envs):
+        import pickle
+        import subprocess
+        import sys
+        import tempfile
+        here = os.path.dirname(os.path.abspath(__file__))
+        W, B = self.workers, self.B
+        cuts = [B * w // W for w in range(W + 1)]
+        self._spec_files = []
+        env_vars = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        for w in range(W):
+            spec = dict(block_path=self._block.path, nbytes=self._block.nbytes, B=B, row=self.adapter.row, dtype=self.adapter.dtype,
+                        workers=W, worker=w, lo=cuts[w], envs=list(envs[cuts[w]:cuts[w + 1]]), adapter=self.adapter,
+                        action_map=self.action_map, env_seed=self.env_seed, limit=self.limit, on_end=self.on_end,
+                        first_env=self.first_env, parent_pid=os.getpid())
+            f = tempfile.NamedTemporaryFile(prefix="smz_hostenv_spec_", suffix=".pkl", delete=False)
+            pickle.dump(spec, f, protocol=pickle.HIGHEST_PROTOCOL)
+            f.close()
+            self._spec_files.append(f.name)
+            self._procs.append(subprocess.Popen([sys.executable, os.path.join(here, "host_worker.py"), f.name], env=env_vars))
+        alive = lambda: all(p.poll() is None for p in self._procs)           # noqa: E731
+        t0 = time.perf_counter()
+        while not all(self._ctrl[8 + w] == -1 for w in range(W)):            # every worker has mapped the block
+            if not alive():
+                self.close()
+                raise RuntimeError("a host-env worker process exited while starting (its traceback is above)")
+            if time.perf_counter() - t0 > 120:
+                self.close()
+                raise TimeoutError("host-env workers did not start within 120 s")
+            time.sleep(0.002)
+        self._block.unlink()
+        for f in self._spec_files:
+            os.unlink(f)
+        self._spec_files = []
+
+    def _command(self, cmd):
+        """Starts `cmd` on every worker (returns at once) -- or runs it here (workers = 0)."""
+        if self._slice is not None:
+            self._slice.reset_all() if cmd == _he.CMD_RESET else self._slice.step_all()
+            return
+        self._seq += 1
+        self._ctrl[1] = cmd
+        self._ctrl[0] = self._seq
+
+    def _wait_workers(self):
+        if self._slice is not None:
+            return
+        alive = lambda: all(p.poll() is None for p in self._procs)           # noqa: E731
+        for w in range(self.workers):
+            _he.wait_for(self._ctrl, 8 + w, self._seq, spin=20000, alive=alive)
 
     # ---- the loop's interface --------------------------------------------------------------------------------------------
-    def _reset_one(self, i):
-        seed = self.env_seed + self.first_env + i + 1000003 * int(self.episode[i])
-        self._store(i, self._observe(self.envs[i], self.envs[i].reset(seed=seed)), after_step=False)
-        self.step_count[i] = 0
-        self.done[i] = False
-
     def reset(self):
-        self.episode[:] = 0
-        for i in range(self.B):
-            self._reset_one(i)
-        self._h_active.fill_(1)
-        self._upload_observations(after_step=False)
-        if self.active is not None:
-            self.active.copy_(self._h_active, non_blocking=True)
+        self._command(_he.CMD_RESET)
+        self._wait_workers()
+        self._upload(after_step=False)
         return self.obs
 
-    def step(self, action):
-        import time
+    def step_begin(self, action):
+        """Enqueues the download of this step's actions; the search that produced them is still running."""
+        if self.device.type == "cpu":
+            self._arr["action"][:] = action.numpy()
+            self._pending = _Done()
+            return
         stream = torch.cuda.current_stream(self.device)
-        self._h_action.copy_(action, non_blocking=True)
+        _lib.check(self.lib.smz_copy_async(C.c_void_p(self._host_ptr + self._lay["action"]), C.c_void_p(action.data_ptr()),
+                                           4 * self.B, 0, self._stream()))
         ev = torch.cuda.Event()
         ev.record(stream)
+        self._pending = ev
+
+    def step_end(self):
+        """Waits for the actions, steps the envs (here or on the workers), enqueues the uploads."""
         t0 = time.perf_counter()
-        ev.synchronize()                                  # the search of this step has to finish before the env can move
-        self.transfer_seconds += time.perf_counter() - t0
-        acts = self._h_action.numpy()
-        rew, flag, act_h = self._h_reward.numpy(), self._h_flag.numpy(), self._h_active.numpy()
-        for i, env in enumerate(self.envs):
-            if not act_h[i]:
-                flag[i], rew[i] = 3, 0.0
-                continue
-            try:
-                out = env.step(self.action_map[int(acts[i])])
-                seen, r, term = self._observe(env, out[0]), float(out[1]), bool(out[2])
-            except Exception:                             # illegal move (game.py:123-131): the observation stays
-                limit = self.limit if self.limit > 0 else float("inf")          # Game's default limit_of_game_play
-                seen, r, term = None, float(min(-int(self.step_count[i]), -limit, -1)), bool(self.done[i])
-            self.step_count[i] += 1
-            f = 2 if (self.limit > 0 and self.step_count[i] == self.limit) else (1 if term else 0)
-            self.done[i] = term and f != 2
-            rew[i], flag[i] = r, f
-            if seen is not None:
-                self._store(i, seen, after_step=True)
-            else:
-                self._keep(i)                             # illegal move: the record shows the unchanged observation
-            if f:
-                if self.on_end == "reset":
-                    self.episode[i] += 1
-                    self._reset_one(i)
-                else:
-                    act_h[i] = 0
-        self._upload_observations(after_step=True)
-        self.reward.copy_(self._h_reward, non_blocking=True)
-        self.terminated.copy_(self._h_flag, non_blocking=True)
-        if self.active is not None:
-            self.active.copy_(self._h_active, non_blocking=True)
+        self._pending.synchronize()                       # the search of this step has to finish before the env can move
+        self._pending = None
+        t1 = time.perf_counter()
+        self._command(_he.CMD_STEP)
+        self._wait_workers()
+        self.transfer_seconds += t1 - t0
+        self.host_step_seconds += time.perf_counter() - t1
+        self._upload(after_step=True)
         return self.obs, self.reward, self.terminated
 
+    def step(self, action):
+        self.step_begin(action)
+        return self.step_end()
+
     def close(self):
-        for e in self.envs:
-            e.close()
+        if self._procs:
+            try:
+                self._seq += 1
+                self._ctrl[1] = _he.CMD_EXIT
+                self._ctrl[0] = self._seq
+            except Exception:
+                pass
+            for p in self._procs:
+                try:
+                    p.wait(timeout=5)
+                except Exception:
+                    p.kill()
+            self._procs = []
+        if self._registered:
+            self.lib.smz_host_unregister(C.c_void_p(self._host_ptr))
+            self._registered = False
+        if self._block is not None:
+            self._block.unlink()
+        for f in getattr(self, "_spec_files", []):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+        if self._slice is not None:
+            self._slice.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HostImageVecEnv(HostVecEnv):
     """HostVecEnv for environments observed through rendered RGB frames (the reference's rgb_observation games:
     game.py:82-89, 105-107, 142-143 -- every frame through ToTensor + Resize(98, 98), one at a time on the CPU).
 
-    Per env step the B uint8 frames [H][W][3] go up through ONE pinned buffer as they are (3 bytes per pixel instead of 12)
-    and one launch of smz_frames_resize_u8 on the engine's stream turns them into the [B,3,98,98] float32 tensor the vision
-    heads read.  frame_source "render": the frame is env.render() (what the reference's Game.render shows the agent);
-    "obs": the env's observation itself is the frame.  With on_end="reset" the few envs that finished a game this step have
-    two frames -- the post-step one for the record and the reset one for the next search: the post-step ones travel in a
-    small side buffer and are resized into `record_obs` rows by a second, indexed launch."""
+    Per env step the B uint8 frames go up through the page-locked block as they are and ONE launch on the engine's stream turns
+    them into the [B,3,98,98] float32 tensor the vision heads read.  upload="frames": whole [H][W][3] frames (3 bytes per
+    pixel; smz_frames_resize_u8); upload="taps" (default): only the source pixels the bilinear resize reads, gathered by the
+    env's process ([2 out_h][2 out_w][3]: 115 KB instead of 720 KB for a 400 x 600 frame; smz_frames_resize_taps_u8) -- the
+    blend runs on the device with the full-frame kernel's arithmetic, so both give bit-identical observations.
+    frame_source "render": the frame is env.render() (what the reference's Game.render shows the agent); "obs": the env's
+    observation itself is the frame.
+
+    The record (round 4): `obs` is the next search's input and -- except for the few envs that finished a game
+    this step -- also the frame the record shows, so `record_obs` is None (the representation launch of the next search copies
+    the frames into the trajectory chunk while reading them, smz_vision_initial_record) and `record_patch` = (rows, frames)
+    carries the post-step frames of the ended envs, which selfplay._play_step writes over those rows of the record."""
     frame = (3, 98, 98)
 
-    def __init__(self, envs, frame_hw, num_actions, device, out_hw=(98, 98), frame_source="render", **kw):
-        assert frame_source in ("render", "obs")
+    def __init__(self, envs, frame_hw, num_actions, device, out_hw=(98, 98), frame_source="render", upload="taps", **kw):
         self.H, self.W = int(frame_hw[0]), int(frame_hw[1])
         self.out_h, self.out_w = int(out_hw[0]), int(out_hw[1])
         self.frame = (3, self.out_h, self.out_w)
-        self.frame_source = frame_source
-        self.lib = _lib.load()
-        super().__init__(envs, 3 * self.out_h * self.out_w, num_actions, device, **kw)
+        self.frame_source, self.upload = frame_source, upload
+        adapter = _he.FrameAdapter(frame_hw, out_hw, frame_source, upload)
+        super().__init__(envs, 3 * self.out_h * self.out_w, num_actions, device, _adapter=adapter, **kw)
 
-    def _alloc_observations(self, pin):
-        B, H, W = self.B, self.H, self.W
-        self._h_frames = torch.zeros(B, H, W, 3, dtype=torch.uint8, **pin)        # next search's frames
-        self._h_frames_np = self._h_frames.numpy()
-        self._d_frames = torch.zeros(B, H, W, 3, dtype=torch.uint8, device=self.device)
-        self.obs = torch.zeros((B,) + self.frame, dtype=torch.float32, device=self.device)
-        self.record_obs = torch.zeros((B,) + self.frame, dtype=torch.float32, device=self.device) if self.on_end == "reset" else None
-        self._side_cap = 0
-        self._ended = []                                                          # (env, post-step frame) of this step
-        self.upload_bytes = 0                                                     # diagnostic: PCIe bytes of frames so far
+    def _alloc_observations(self):
+        self.obs = torch.zeros((self.B,) + self.frame, dtype=torch.float32, device=self.device)
+        self.record_obs = None
+        self.record_patch = None
+        self._patch_frames = None
 
-    def _observe(self, env, obs):
-        frame = env.render() if self.frame_source == "render" else (obs[0] if isinstance(obs, tuple) else obs)
-        frame = np.asarray(frame)
-        assert frame.shape == (self.H, self.W, 3), f"frame {frame.shape}, expected {(self.H, self.W, 3)}"
-        return frame.astype(np.uint8, copy=False)          # (the reference: x.copy().astype(np.uint8), game.py:84)
-
-    def _store(self, i, seen, after_step):
-        if not after_step and self._stepping:
-            # a reset inside step(): the frame in the main buffer is this env's post-step one -- the record needs it
-            self._ended.append((i, self._h_frames[i].clone()))
-        np.copyto(self._h_frames_np[i], seen)          # (a numpy view of the pinned buffer: no tensor-indexing overhead per env)
-
-    def _keep(self, i):
-        pass                                               # the frame in the main buffer is still the current one
-
-    _stepping = False
-
-    def step(self, action):
-        self._stepping, self._ended = True, []
-        try:
-            return super().step(action)
-        finally:
-            self._stepping = False
-
-    def _resize(self, frames_dev, n, rows_dev, out):
+    def _rows_to_observations(self, rows_dev, n, index_dev, out):
         P = lambda x: None if x is None else C.c_void_p(x.data_ptr())
-        _lib.check(self.lib.smz_frames_resize_u8(P(frames_dev), n, self.H, self.W, self.out_h, self.out_w, P(rows_dev), P(out),
-                                                 C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        fn = self.lib.smz_frames_resize_taps_u8 if self.upload == "taps" else self.lib.smz_frames_resize_u8
+        _lib.check(fn(P(rows_dev), n, self.H, self.W, self.out_h, self.out_w, P(index_dev), P(out), self._stream()))
 
-    def _upload_observations(self, after_step):
-        self._d_frames.copy_(self._h_frames, non_blocking=True)
-        self.upload_bytes += self._h_frames.numel()
-        self._resize(self._d_frames, self.B, None, self.obs)
-        if not after_step or self.record_obs is None:
-            return
-        self.record_obs.copy_(self.obs)
-        n = len(self._ended)
-        if n == 0:
-            return
-        if n > self._side_cap:                         # grows to the largest number of simultaneous game ends seen
-            pin = dict(pin_memory=torch.cuda.is_available())
-            self._side_cap = max(n, 2 * self._side_cap, 8)
-            self._h_side = torch.zeros(self._side_cap, self.H, self.W, 3, dtype=torch.uint8, **pin)
-            self._h_rows = torch.zeros(self._side_cap, dtype=torch.int32, **pin)
-            self._d_side = torch.zeros(self._side_cap, self.H, self.W, 3, dtype=torch.uint8, device=self.device)
-            self._d_rows = torch.zeros(self._side_cap, dtype=torch.int32, device=self.device)
-        else:
-            torch.cuda.current_stream(self.device).synchronize()      # the side buffers of the previous use have been read
-        for k, (i, fr) in enumerate(self._ended):
-            self._h_side[k] = fr
-            self._h_rows[k] = i
-        self._d_side[:n].copy_(self._h_side[:n], non_blocking=True)
-        self._d_rows[:n].copy_(self._h_rows[:n], non_blocking=True)
-        self.upload_bytes += n * self.H * self.W * 3
-        self._resize(self._d_side, n, self._d_rows, self.record_obs)
+    def _publish(self, after_step):
+        self._rows_to_observations(self._d_rows, self.B, None, self.obs)
+        self.record_patch = None
 
-
-class HostCartPoleRender(HostCartPole):
-    """HostCartPole with a render(): an H x W x 3 uint8 picture of the cart and the pole (white background, black cart,
-    brown pole, a track line) -- a stand-in for CartPole-v1's pygame renderer (400 x 600 frames), which is not part of this
-    image.  Drawn with numpy slices: cheap enough to feed a thousand envs from Python."""
-
-    def __init__(self, frame_hw=(400, 600)):
-        super().__init__()
-        self.H, self.W = int(frame_hw[0]), int(frame_hw[1])
-        self._img = None
-
-    def render(self):
-        """The frame buffer is reused from call to call (a fresh 720 KB array costs 0.5 ms of page faults): copy it to keep it."""
-        H, W = self.H, self.W
-        if self._img is None:
-            self._img = np.empty((H, W, 3), np.uint8)
-            dy, dx = np.meshgrid([-1, 0, 1], [-1, 0, 1], indexing="ij")
-            self._dy, self._dx, self._col = dy.ravel(), dx.ravel(), np.array((202, 152, 101), np.uint8)
-        img = self._img
-        img[...] = 255
-        x, _, th, _ = (float(v) for v in self.state)
-        cy = int(H * 0.75)
-        img[cy + H // 40:cy + H // 40 + 1, :, :] = 0                                       # track
-        cx = int(np.clip((x / 4.8 + 0.5) * W, 0, W - 1))
-        cw, ch = W // 12, H // 13
-        img[max(0, cy - ch // 2):cy + ch // 2, max(0, cx - cw // 2):min(W, cx + cw // 2)] = 0
-        k = np.arange(0, H // 4, 2)                                                         # pole: a run of 3x3 dots
-        px, py = (cx + k * np.sin(th)).astype(np.int64), (cy - ch // 2 - k * np.cos(th)).astype(np.int64)
-        ok = (px >= 1) & (px < W - 1) & (py >= 1) & (py < H - 1)
-        img[(py[ok][:, None] + self._dy).ravel(), (px[ok][:, None] + self._dx).ravel()] = self._col
-        return img
+    def _patch_record(self, n):
+        if self._patch_frames is None or self._patch_frames.shape[0] < self._side_cap:
+            self._patch_frames = torch.zeros((self._side_cap,) + self.frame, dtype=torch.float32, device=self.device)
+        self._rows_to_observations(self._d_side, n, None, self._patch_frames)
+        self.record_patch = (self._d_side_rows[:n], self._patch_frames[:n])
 
 
 class HostCartPoleVec:

@@ -81,6 +81,176 @@ class GameRecord:
         return out
 
 
+class _Column:
+    """One of a game's six per-step lists (game.py:72-77) as a window into the host copy of a trajectory chunk: `rows` is an
+    array slice [n, ...] of the chunk, `item` turns a row into what the reference's list holds at that position.  Reads
+    (len, index, slice, iteration, `+`) convert on the fly; the first mutation (append, item assignment, ...) turns the column
+    into a real list of its items, after which it simply is that list."""
+    __slots__ = ("_rows", "_item", "_list")
+
+    def __init__(self, rows, item):
+        self._rows, self._item, self._list = rows, item, None
+
+    def _real(self):
+        if self._list is None:
+            item = self._item
+            self._list = [item(r) for r in self._rows]
+            self._rows = None
+        return self._list
+
+    def __len__(self):
+        return len(self._rows) if self._list is None else len(self._list)
+
+    def __getitem__(self, i):
+        if self._list is not None:
+            return self._list[i]
+        if isinstance(i, slice):
+            item = self._item
+            return [item(r) for r in self._rows[i]]
+        return self._item(self._rows[i])             # (numpy raises IndexError past the end, like a list)
+
+    def __iter__(self):
+        if self._list is not None:
+            return iter(self._list)
+        return map(self._item, self._rows)
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __repr__(self):
+        return repr(list(self))
+
+    def __reduce__(self):                             # pickled (ReplayBuffer.save_buffer) as the plain list it stands for
+        return (list, (list(self),))
+
+    # mutations: become the list
+    def __setitem__(self, i, v): self._real()[i] = v
+    def __delitem__(self, i): del self._real()[i]
+    def append(self, v): self._real().append(v)
+    def extend(self, v): self._real().extend(v)
+    def insert(self, i, v): self._real().insert(i, v)
+    def pop(self, *a): return self._real().pop(*a)
+    def __iadd__(self, other):
+        self._real().extend(other)
+        return self
+
+
+class ChunkHostCopy:
+    """What the games of one trajectory chunk share: ONE env-major host copy `rec` [B][T][F] (float64) of the chunk's records,
+    optionally the float32 observations [B][T][n] that live outside the record, the device-computed n-step value targets /
+    |root value - target| [B][T] for `td_steps` (selfplay.chunk_targets: bit-identical to make_target / make_priority), and
+    the constants of the games.  ArrayGameRecord reads windows of these arrays."""
+
+    def __init__(self, rec, obs_dim, A, discount, priority_scale, limit_of_game_play, observations=None, observation_shape=None,
+                 td_steps=None, target=None, abs_td=None):
+        self.rec, self.o, self.A = rec, int(obs_dim), int(A)
+        self.discount, self.priority_scale, self.limit_of_game_play = discount, priority_scale, limit_of_game_play
+        self.observations, self.observation_shape = observations, tuple(observation_shape) if observation_shape else None
+        self.td_steps, self.target, self.abs_td = td_steps, target, abs_td
+        self.prio = None if abs_td is None else abs_td ** priority_scale     # make_priority's positions, every game at once
+
+
+def _obs_vector(row):
+    return torch.from_numpy(row.astype(np.float32))[None, ...]       # game.py:145-167: [1, obs] float32
+
+
+_COLUMNS = ("observations", "rewards", "policies", "action_history", "root_values", "child_visits")
+_SHARED = ("discount", "action_space_size", "priority_scale", "limit_of_game_play")
+
+
+class ArrayGameRecord(GameRecord):
+    """A GameRecord whose six lists are windows [t0, t1) of env `e` into a ChunkHostCopy instead of per-step Python objects
+    (selfplay.chunk_to_records builds 4096 of them from a 64-step chunk in milliseconds where chunk_to_games -- the checker --
+    appends 1.6 M list items).  Everything the reference reads from a stored game works unchanged: len / index / slice /
+    iterate / append on the lists (game.py:72-77, replay_buffer.py:185-214), game_length, make_target, make_priority,
+    make_image, make_extended_image, reanalyzed, done, env.  make_target / make_priority are served from the device-computed
+    arrays when they were computed for the same td_steps and the game's lists have not been modified; otherwise by
+    GameRecord's own loops over the lists."""
+
+    def __init__(self, src, e, t0, t1, done):
+        self._src, self._e, self._t0, self._t1 = src, e, t0, t1
+        self.done, self.reanalyzed, self.env = done, False, None
+
+    def __getattr__(self, name):                      # only reached for attributes not set yet
+        if name in _COLUMNS:
+            col = self._column(name)
+            self.__dict__[name] = col
+            return col
+        if name in _SHARED:
+            src = self.__dict__["_src"]
+            return src.A if name == "action_space_size" else getattr(src, name)
+        raise AttributeError(name)
+
+    def _column(self, name):
+        src, e, t0, t1 = self._src, self._e, self._t0, self._t1
+        o, A = src.o, src.A
+        rows = src.rec[e, t0:t1]
+        if name == "observations":
+            if src.observations is None:
+                return _Column(rows[:, :o], _obs_vector)
+            shape = src.observation_shape
+            frames = torch.from_numpy(src.observations[e, t0:t1]) if isinstance(src.observations, np.ndarray) else src.observations[e, t0:t1]
+            return _Column(frames, (lambda f: f.reshape((1,) + shape)) if shape else (lambda f: f[None, ...]))
+        if name == "rewards":
+            return _Column(rows[:, o], float)
+        if name == "policies":
+            return _Column(rows[:, o + 2:o + 2 + A], _same)
+        if name == "action_history":
+            return _Column(rows[:, o + 2 + A:o + 2 + 2 * A], _same)
+        if name == "root_values":
+            return _Column(rows[:, o + 2 + 2 * A], np.float32)
+        return _Column(rows[:, o + 3 + 2 * A:o + 3 + 3 * A], _same)
+
+    def _pristine(self, *names):
+        d = self.__dict__
+        return all(n not in d or (isinstance(d[n], _Column) and d[n]._list is None) for n in names)
+
+    @property
+    def game_length(self):
+        if "action_history" in self.__dict__:
+            return len(self.__dict__["action_history"])
+        return self._t1 - self._t0
+
+    def make_priority(self, td_steps):
+        src = self._src
+        if src.prio is not None and td_steps == src.td_steps and td_steps >= 1 and self._t1 > self._t0 and \
+                self.priority_scale == src.priority_scale and self._pristine("rewards", "root_values"):
+            pos = src.prio[self._e, self._t0:self._t1]
+            return pos, np.max(pos)
+        return super().make_priority(td_steps)
+
+    def make_target(self, state_index, num_unroll, td_steps):
+        src = self._src
+        if src.target is None or td_steps != src.td_steps or not self._pristine("rewards", "root_values", "child_visits"):
+            return super().make_target(state_index, num_unroll, td_steps)
+        e, t0, n = self._e, self._t0, self._t1 - self._t0
+        o, A = src.o, src.A
+        rec, tgt = src.rec[e], src.target[e]
+        targets = []
+        for cur in range(state_index, state_index + num_unroll):
+            last_reward = float(rec[t0 + cur - 1, o]) if 0 < cur <= n else 0.0
+            if 0 <= cur < n:
+                # (NEP 50: a bootstrapped return is a numpy float32 in the reference, a return past the end a Python float)
+                v = tgt[t0 + cur]
+                targets.append([np.float32(v) if cur + td_steps < n else float(v), last_reward,
+                                rec[t0 + cur, o + 3 + 2 * A:o + 3 + 3 * A]])
+            elif cur < 0:
+                return super().make_target(state_index, num_unroll, td_steps)      # negative indices: the lists' own rules
+            else:
+                targets.append([0.0, last_reward, np.zeros(A, dtype=np.float64)])
+        return targets
+
+
+def _same(row):
+    return row
+
+
 def _resize_frame(shape):
     def transform(frame):
         x = torch.from_numpy(np.ascontiguousarray(frame).astype(np.uint8)).permute(2, 0, 1).to(torch.float32) / 255

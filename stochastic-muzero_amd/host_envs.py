@@ -1,0 +1,348 @@
+"""Host-resident environments: the per-env rules of the reference's Game around env.step (game.py:96-131, 223-273) over a
+SLICE of a vector env's rows, the built-in CartPole stand-ins, and the worker process of the parallel stepper.
+
+numpy + standard library only: envs.HostVecEnv runs a HostSlice in-process (the serial adapter); with `workers=N` it starts N
+child processes (host_worker.py -> worker_main) that never import torch or touch the GPU, each owning a contiguous slice of
+the envs and running the SAME HostSlice code on views of one shared-memory block -- the parallel stepper is the serial one by
+construction, env by env.  This replaces the Ray fan-out of the reference's self-play (self_play.py:240-256: one game per
+worker process) for envs that live on the host.
+
+Shared block (SharedBlock): one file-backed mapping (/dev/shm) holding, for all B envs of the vector env,
+    action i32 [B] | reward f32 [B] | flag u8 [B] | active u8 [B] | ended u8 [B] | obs <dtype> [B][row] | rec <dtype> [B][row]
+and a control page: `go` (step sequence number written by the parent), `cmd`, one `done` sequence number per worker.  The
+parent registers the mapping with the HIP runtime (page-locked), so rows written by a worker are DMA'd to the GPU from where
+they lie.  Hand-off is by sequence numbers in shared memory (spin, then short sleeps): a step of 4096 CartPoles is ~0.1 ms of
+work per worker, less than a pipe round trip.
+"""
+import mmap
+import os
+import pickle
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# built-in stand-ins (gymnasium is not part of this build)
+# ---------------------------------------------------------------------------------------------------------------------------
+class HostCartPole:
+    """One CartPole-v1 shaped game on the host behind the gym call shape (reset(seed=) -> (obs, info); step(a) -> (obs,
+    reward, terminated, truncated, info)): float64 Euler physics with CartPole-v1's published constants, the arithmetic
+    of smz_cartpole_step.  gymnasium is not part of this build; this class is what the host-environment path is
+    exercised with, and what `muzero_cli.py` uses for a single-game run."""
+    metadata = {"render_fps": 50}
+
+    def __init__(self):
+        self.state = None
+
+    def reset(self, seed=None):
+        self.state = np.random.RandomState(seed).uniform(-0.05, 0.05, size=4)
+        return self.state.astype(np.float32), {}
+
+    def step(self, action):
+        if action not in (0, 1):
+            raise ValueError(f"illegal action {action!r}")
+        x, xd, th, thd = (float(v) for v in self.state)
+        force = 10.0 if action == 1 else -10.0
+        ct, sn = np.cos(th), np.sin(th)
+        temp = (force + 0.05 * thd * thd * sn) / 1.1
+        tha = (9.8 * sn - ct * temp) / (0.5 * (4.0 / 3.0 - 0.1 * ct * ct / 1.1))
+        xa = temp - 0.05 * tha * ct / 1.1
+        self.state = np.array([x + 0.02 * xd, xd + 0.02 * xa, th + 0.02 * thd, thd + 0.02 * tha])
+        term = bool(abs(self.state[0]) > 2.4 or abs(self.state[2]) > 12 * 2 * np.pi / 360)
+        return self.state.astype(np.float32), 1.0, term, False, {}
+
+    def close(self):
+        pass
+
+
+class HostCartPoleRender(HostCartPole):
+    """HostCartPole with a render(): an H x W x 3 uint8 picture of the cart and the pole (white background, black cart,
+    brown pole, a track line) -- a stand-in for CartPole-v1's pygame renderer (400 x 600 frames), which is not part of this
+    image.  Drawn with numpy slices: cheap enough to feed a thousand envs from Python."""
+
+    def __init__(self, frame_hw=(400, 600)):
+        super().__init__()
+        self.H, self.W = int(frame_hw[0]), int(frame_hw[1])
+        self._img = None
+
+    def __getstate__(self):                                 # (sent to a worker process: the frame buffer stays behind)
+        d = dict(self.__dict__)
+        d["_img"] = None
+        return d
+
+    def render(self):
+        """The frame buffer is reused from call to call (a fresh 720 KB array costs 0.5 ms of page faults): copy it to keep it."""
+        H, W = self.H, self.W
+        if self._img is None:
+            self._img = np.empty((H, W, 3), np.uint8)
+            dy, dx = np.meshgrid([-1, 0, 1], [-1, 0, 1], indexing="ij")
+            self._dy, self._dx, self._col = dy.ravel(), dx.ravel(), np.array((202, 152, 101), np.uint8)
+        img = self._img
+        img[...] = 255
+        x, _, th, _ = (float(v) for v in self.state)
+        cy = int(H * 0.75)
+        img[cy + H // 40:cy + H // 40 + 1, :, :] = 0                                       # track
+        cx = int(np.clip((x / 4.8 + 0.5) * W, 0, W - 1))
+        cw, ch = W // 12, H // 13
+        img[max(0, cy - ch // 2):cy + ch // 2, max(0, cx - cw // 2):min(W, cx + cw // 2)] = 0
+        k = np.arange(0, H // 4, 2)                                                         # pole: a run of 3x3 dots
+        px, py = (cx + k * np.sin(th)).astype(np.int64), (cy - ch // 2 - k * np.cos(th)).astype(np.int64)
+        ok = (px >= 1) & (px < W - 1) & (py >= 1) & (py < H - 1)
+        img[(py[ok][:, None] + self._dy).ravel(), (px[ok][:, None] + self._dx).ravel()] = self._col
+        return img
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# observation adapters: what of env.reset / env.step's observation goes into the env's row
+# ---------------------------------------------------------------------------------------------------------------------------
+def tap_index(n_in, n_out):
+    """Source indices of a bilinear resize n_in -> n_out as ATen's upsample_bilinear2d (align_corners False) and
+    smz_frames.hip's src_index compute them: src = fma(scale, dst + 0.5, -0.5) in float32, clamped at 0; i0 = min(int(src),
+    n_in - 1), i1 = min(i0 + 1, n_in - 1).  Returns int32 [2 * n_out]: (i0, i1) of every output index.  (scale * (dst + 0.5)
+    and the subtraction are exact in float64, so rounding the float64 result once IS the float32 fma.)"""
+    scale = np.float32(n_in) / np.float32(n_out)
+    dst = np.arange(n_out, dtype=np.float64) + 0.5
+    src = (np.float64(scale) * dst - 0.5).astype(np.float32)
+    src = np.maximum(src, np.float32(0))
+    i0 = np.minimum(src.astype(np.int32), n_in - 1)
+    i1 = np.minimum(i0 + 1, n_in - 1)
+    return np.stack([i0, i1], 1).reshape(-1).astype(np.int32)
+
+
+class VectorAdapter:
+    """Flattened float32 observation vectors (game.py:145-167)."""
+    dtype = np.float32
+
+    def __init__(self, obs_dim, transform=None):
+        self.row, self.transform = int(obs_dim), transform
+
+    def observe(self, env, obs):
+        obs = obs[0] if isinstance(obs, tuple) else obs
+        if self.transform is not None:
+            obs = self.transform(obs)
+        return np.asarray(obs, dtype=np.float32).reshape(-1)
+
+
+class FrameAdapter:
+    """Rendered uint8 frames [H][W][3] (the reference's rgb_observation games, game.py:82-89, 105-107, 142-143).
+    upload="frames": the row is the whole frame.  upload="taps": the row holds only the source pixels a bilinear resize to
+    out_hw reads -- rows y0/y1 and columns x0/x1 of every output pixel, [2 out_h][2 out_w][3] (98 x 98 from 400 x 600: 115 KB
+    instead of 720 KB per frame) -- and the device blends them with the full-frame kernel's own arithmetic
+    (smz_frames_resize_taps_u8), so the two uploads give bit-identical observations."""
+    dtype = np.uint8
+
+    def __init__(self, frame_hw, out_hw, frame_source="render", upload="frames"):
+        assert frame_source in ("render", "obs") and upload in ("frames", "taps")
+        self.H, self.W = int(frame_hw[0]), int(frame_hw[1])
+        self.out_h, self.out_w = int(out_hw[0]), int(out_hw[1])
+        self.frame_source, self.upload = frame_source, upload
+        if upload == "taps":
+            self._ix = np.ix_(tap_index(self.H, self.out_h), tap_index(self.W, self.out_w))
+            self.row = 2 * self.out_h * 2 * self.out_w * 3
+        else:
+            self.row = self.H * self.W * 3
+
+    def observe(self, env, obs):
+        frame = env.render() if self.frame_source == "render" else (obs[0] if isinstance(obs, tuple) else obs)
+        frame = np.asarray(frame)
+        assert frame.shape == (self.H, self.W, 3), f"frame {frame.shape}, expected {(self.H, self.W, 3)}"
+        frame = frame.astype(np.uint8, copy=False)          # (the reference: x.copy().astype(np.uint8), game.py:84)
+        if self.upload == "taps":
+            return frame[self._ix].reshape(-1)
+        return frame.reshape(-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the rules around env.step for a slice of envs
+# ---------------------------------------------------------------------------------------------------------------------------
+class HostSlice:
+    """Envs [lo, hi) of a vector env and their rows in the (shared or private) buffers.  Per env it keeps what the reference's
+    Game keeps around env.step (game.py:96-131, 223-273):
+      * the first observation comes from env.reset(seed=env_seed + global env index [+ 1000003 * game number]);
+      * a step that raises is an illegal move: observation unchanged, reward min(-steps so far, -limit, -1), termination
+        flag unchanged (game.py:123-131);
+      * flags: 1 terminated, 2 stopped by `limit` (game.py:270-271), 3 no step (switched off);
+      * on_end "mask": a finished env is switched off (`active`); "reset": it is reset at once -- `obs` gets the fresh
+        observation for the next search, `rec` keeps the post-step one for the record and `ended` marks the row."""
+
+    def __init__(self, envs, lo, adapter, arrays, action_map, env_seed, limit, on_end, first_env):
+        self.envs, self.lo, self.n = list(envs), int(lo), len(envs)
+        self.adapter, self.action_map = adapter, list(action_map)
+        self.env_seed, self.limit, self.on_end, self.first_env = int(env_seed), int(limit), on_end, int(first_env)
+        hi = self.lo + self.n
+        for name in ("action", "reward", "flag", "active", "ended", "obs", "rec"):
+            setattr(self, name, arrays[name][self.lo:hi])
+        self.step_count = np.zeros(self.n, np.int64)
+        self.episode = np.zeros(self.n, np.int64)
+        self.done = np.zeros(self.n, bool)
+
+    def _reset_one(self, i):
+        seed = self.env_seed + self.first_env + self.lo + i + 1000003 * int(self.episode[i])
+        self.obs[i] = self.adapter.observe(self.envs[i], self.envs[i].reset(seed=seed))
+        self.step_count[i] = 0
+        self.done[i] = False
+
+    def reset_all(self):
+        self.episode[:] = 0
+        for i in range(self.n):
+            self._reset_one(i)
+        self.active[:] = 1
+        self.ended[:] = 0
+
+    def step_all(self):
+        envs, amap, observe = self.envs, self.action_map, self.adapter.observe
+        acts, rew, flag, active, ended = self.action.tolist(), self.reward, self.flag, self.active, self.ended
+        obs, rec, count = self.obs, self.rec, self.step_count
+        limit, reset_mode = self.limit, self.on_end == "reset"
+        ended[:] = 0
+        live = active.tolist()
+        for i in range(self.n):
+            if not live[i]:
+                flag[i], rew[i] = 3, 0.0
+                continue
+            env = envs[i]
+            try:
+                out = env.step(amap[acts[i]])
+                seen, r, term = observe(env, out[0]), float(out[1]), bool(out[2])
+            except Exception:                             # illegal move (game.py:123-131): the observation stays
+                lim = limit if limit > 0 else float("inf")                       # Game's default limit_of_game_play
+                seen, r, term = None, float(min(-int(count[i]), -lim, -1)), bool(self.done[i])
+            c = count[i] = count[i] + 1
+            f = 2 if (limit > 0 and c == limit) else (1 if term else 0)
+            self.done[i] = term and f != 2
+            rew[i], flag[i] = r, f
+            if seen is not None:
+                obs[i] = seen
+            if f:
+                if reset_mode:
+                    rec[i] = obs[i]                       # the record keeps the post-step observation ...
+                    ended[i] = 1
+                    self.episode[i] += 1
+                    self._reset_one(i)                    # ... and the next search starts from the fresh one
+                else:
+                    active[i] = 0
+
+    def close(self):
+        for e in self.envs:
+            try:
+                e.close()
+            except Exception:
+                pass
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the shared block
+# ---------------------------------------------------------------------------------------------------------------------------
+def build_env(e):
+    """An env object as it is; a class or a zero-argument factory (the gymnasium.vector `env_fns` convention) is called."""
+    return e() if isinstance(e, type) or (callable(e) and not hasattr(e, "step")) else e
+
+
+CTRL_BYTES = 4096
+CMD_STEP, CMD_RESET, CMD_EXIT = 1, 2, 3
+
+
+def block_layout(B, row, dtype):
+    """Byte offsets of the arrays of a B-env block, every array on a 4 KB boundary (rows of different workers never share a
+    page with another array)."""
+    item = np.dtype(dtype).itemsize
+    out, off = {}, CTRL_BYTES
+    for name, nbytes in (("action", 4 * B), ("reward", 4 * B), ("flag", B), ("active", B), ("ended", B),
+                         ("obs", B * row * item), ("rec", B * row * item)):
+        out[name] = off
+        off += (nbytes + 4095) // 4096 * 4096
+    out["total"] = off
+    return out
+
+
+def map_arrays(buf, B, row, dtype, workers):
+    lay = block_layout(B, row, dtype)
+    arr = dict(action=np.frombuffer(buf, np.int32, B, lay["action"]), reward=np.frombuffer(buf, np.float32, B, lay["reward"]),
+               flag=np.frombuffer(buf, np.uint8, B, lay["flag"]), active=np.frombuffer(buf, np.uint8, B, lay["active"]),
+               ended=np.frombuffer(buf, np.uint8, B, lay["ended"]),
+               obs=np.frombuffer(buf, dtype, B * row, lay["obs"]).reshape(B, row),
+               rec=np.frombuffer(buf, dtype, B * row, lay["rec"]).reshape(B, row))
+    ctrl = np.frombuffer(buf, np.int64, CTRL_BYTES // 8, 0)      # [0] go sequence, [1] command, [8 + w] done sequence of worker w
+    assert 8 + workers <= ctrl.size
+    return arr, ctrl, lay
+
+
+class SharedBlock:
+    """A file-backed shared mapping created by the parent; the file is unlinked once every worker has attached."""
+
+    def __init__(self, nbytes):
+        d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        fd, self.path = tempfile.mkstemp(prefix="smz_hostenv_", dir=d)
+        try:
+            os.ftruncate(fd, nbytes)
+            self.mm = mmap.mmap(fd, nbytes)
+        finally:
+            os.close(fd)
+        self.nbytes = nbytes
+
+    def unlink(self):
+        if self.path:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+            self.path = None
+
+
+def wait_for(ctrl, index, value, spin=2000, timeout=None, alive=None):
+    """Waits until ctrl[index] >= value: a short spin (a step is tens of microseconds away), then sleeps that grow to 0.2 ms."""
+    n, nap = 0, 20e-6
+    t0 = time.perf_counter() if timeout is not None else 0.0
+    while ctrl[index] < value:
+        n += 1
+        if n > spin:
+            time.sleep(nap)
+            nap = min(nap * 1.5, 200e-6)
+            if n % 64 == 0:
+                if alive is not None and not alive():
+                    raise RuntimeError("host-env worker died")
+                if timeout is not None and time.perf_counter() - t0 > timeout:
+                    raise TimeoutError("host-env worker did not answer")
+
+
+def worker_main(spec_path):
+    """Entry of a worker process (host_worker.py): attach the block, build the slice, serve step / reset commands."""
+    with open(spec_path, "rb") as f:
+        spec = pickle.load(f)
+    fd = os.open(spec["block_path"], os.O_RDWR)
+    try:
+        mm = mmap.mmap(fd, spec["nbytes"])
+    finally:
+        os.close(fd)
+    arr, ctrl, _ = map_arrays(mm, spec["B"], spec["row"], spec["dtype"], spec["workers"])
+    envs = [build_env(e) for e in spec["envs"]]
+    sl = HostSlice(envs, spec["lo"], spec["adapter"], arr, spec["action_map"], spec["env_seed"], spec["limit"], spec["on_end"],
+                   spec["first_env"])
+    w, parent = spec["worker"], spec["parent_pid"]
+    seq = 0
+    ctrl[8 + w] = -1                                       # attached (the parent waits for every worker's -1 -> then unlinks the file)
+    alive = lambda: os.getppid() == parent                 # noqa: E731  (an orphaned worker exits instead of spinning for ever)
+    try:
+        while True:
+            seq += 1
+            wait_for(ctrl, 0, seq, spin=spec.get("spin", 20000), alive=alive)
+            cmd = int(ctrl[1])
+            if cmd == CMD_EXIT:
+                break
+            if cmd == CMD_RESET:
+                sl.reset_all()
+            else:
+                sl.step_all()
+            ctrl[8 + w] = seq
+    except RuntimeError:
+        pass
+    finally:
+        sl.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(worker_main(sys.argv[1]))

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .game import Game, GameRecord  # noqa: F401  (GameRecord is re-exported: selfplay.GameRecord)
+from .game import ArrayGameRecord, ChunkHostCopy, Game, GameRecord  # noqa: F401  (re-exported: selfplay.GameRecord ...)
 
 
 def temperature_scheduler(epoch=1, actual_epoch=1, mode="static_temperature"):
@@ -63,6 +63,7 @@ class TrajectoryChunk:
         self.data = torch.zeros(self.T, self.B, self.F, dtype=torch.float64, device=device)
         self.obs = None if self.rec_obs_dim else torch.zeros(self.T, self.B, self.obs_dim, dtype=torch.float32, device=device)
         self.owed_obs = None        # (slot, tensor): frames of step `slot` that the next representation launch will copy
+        self.owed_patch = None      # (rows i32 [n], frames f32 [n, ...]): rows of that slot that show OTHER frames (envs reset in the step)
 
     def flush_obs(self):
         """Copies frames whose record was left to a representation launch that has not come (end of a play_games call, a
@@ -70,12 +71,36 @@ class TrajectoryChunk:
         if self.owed_obs is not None:
             t, frames = self.owed_obs
             self.obs[t].copy_(frames.reshape(self.B, -1))
+            self._patch(t)
             self.owed_obs = None
+
+    def apply_patch(self):
+        """After a representation launch has written the owed frames: the rows of envs that were reset inside that step."""
+        if self.owed_patch is not None:
+            self._patch(self._owed_slot)
+
+    def _patch(self, t):
+        if self.owed_patch is not None:
+            rows, frames = self.owed_patch
+            self.obs[t].index_copy_(0, rows.long(), frames.reshape(frames.shape[0], -1))
+            self.owed_patch = None
+
+    @property
+    def owed_obs(self):
+        return self._owed
+
+    @owed_obs.setter
+    def owed_obs(self, v):
+        self._owed = v
+        if v is not None:
+            self._owed_slot = v[0]
 
     def fields(self, data=None):
         d = self.data if data is None else data
         o, A = self.rec_obs_dim, self.A
-        return dict(observation=d[..., :o] if self.obs is None else self.obs, reward=d[..., o], terminated=d[..., o + 1],
+        # (a gathered `data` of other ranks has its frames in a gathered message of its own: no observation entry then)
+        obs = d[..., :o] if self.obs is None else (self.obs if data is None else None)
+        return dict(observation=obs, reward=d[..., o], terminated=d[..., o + 1],
                     policy=d[..., o + 2:o + 2 + A],
                     action_onehot=d[..., o + 2 + A:o + 2 + 2 * A], root_value=d[..., o + 2 + 2 * A],
                     child_visits=d[..., o + 3 + 2 * A:o + 3 + 3 * A])
@@ -95,9 +120,12 @@ def chunk_targets(chunk_data, obs_dim, A, discount, td_steps, ignore_termination
     -1: no game) as a fourth result."""
     assert after_end in ("drop", "new_game")
     lib = _lib.load()
+    if isinstance(chunk_data, TrajectoryChunk):
+        chunk_data, obs_dim = chunk_data.data, chunk_data.rec_obs_dim
     T, B, F = chunk_data.shape
     assert chunk_data.is_cuda and chunk_data.dtype == torch.float64 and chunk_data.is_contiguous()
-    assert F == lib.smz_traj_floats(int(obs_dim), int(A))
+    assert F == lib.smz_traj_floats(int(obs_dim), int(A)), \
+        f"a record of {F} floats is not obs_dim {obs_dim} + 3 * {A} + 3 (image observations: pass the TrajectoryChunk or obs_dim=0)"
     dev = chunk_data.device
     pows = torch.tensor([discount ** i for i in range(int(td_steps) + 1)], dtype=torch.float64).to(dev)   # Python's pow
     length = torch.empty(B, dtype=torch.int32, device=dev)
@@ -122,11 +150,16 @@ def chunk_to_games(chunk_data, obs_dim, A, discount, priority_scale=1, limit_of_
     end flag is then one game per env).  `observations` [T][B][n] float32 (TrajectoryChunk.obs): the observations live outside
     the record (obs_dim is then 0), each stored as [1, *observation_shape] like the reference's frames ([1,3,98,98])."""
     assert after_end in ("drop", "new_game")
+    if isinstance(chunk_data, TrajectoryChunk):      # the chunk knows where its observations live
+        chunk = chunk_data
+        chunk_data, obs_dim, observations = chunk.data, chunk.rec_obs_dim, chunk.obs if observations is None else observations
     d = chunk_data.detach().cpu().numpy() if torch.is_tensor(chunk_data) else np.asarray(chunk_data)
     T, B, F = d.shape
     o = obs_dim
+    assert F == o + 3 * A + 3, (f"a record of {F} floats is not obs_dim {o} + 3 * {A} + 3: observations wider than "
+                                f"TrajectoryChunk.SPLIT_OBS live in chunk.obs (pass the TrajectoryChunk, or obs_dim=0 and observations=)")
     if observations is not None:
-        assert o == 0 and F == 3 * A + 3
+        assert o == 0
         observations = observations.detach().cpu() if torch.is_tensor(observations) else torch.as_tensor(np.asarray(observations))
         observations = observations.to(torch.float32)
     games = []
@@ -160,16 +193,100 @@ def chunk_to_games(chunk_data, obs_dim, A, discount, priority_scale=1, limit_of_
     return games
 
 
+def _segments(flags, game_end, keep_partial):
+    """Game windows of an env-major chunk: flags [B][T] (the record's flag slot), game_end [B][T] (smz_traj_targets_games:
+    one past the last row of the row's game, -1 = no game).  Returns (env, t0, t1, last_flag) arrays in chunk_to_games'
+    order (env-major, games of an env in time order)."""
+    B, T = game_end.shape
+    start = game_end >= 0
+    start[:, 1:] &= game_end[:, 1:] != game_end[:, :-1]
+    e, t0 = np.nonzero(start)                                  # row-major: env-major, time order
+    t1 = game_end[e, t0]
+    last = flags[e, t1 - 1]
+    if not keep_partial:
+        keep = last != 0
+        e, t0, t1, last = e[keep], t0[keep], t1[keep], last[keep]
+    return e, t0, t1, last
+
+
+def chunk_to_records(chunk_data, obs_dim, A, discount, priority_scale=1, limit_of_game_play=float("inf"),
+                     ignore_termination=False, keep_partial=True, after_end="drop", observations=None, observation_shape=None,
+                     td_steps=None):
+    """chunk_to_games for a device chunk at the speed of the search that fills it: the same games, in the same order, as
+    ArrayGameRecord windows into ONE env-major host copy of the chunk (game.py).  The device cuts the games
+    (smz_traj_targets_games: game ends per row) and, when `td_steps` is given, computes every position's n-step value target and
+    priority in the same launch pair, so that ReplayBuffer.save_game's make_priority (replay_buffer.py:109-137) and
+    sample_batch's make_target (:185-214) are array reads.  Host work: two transfers, one numpy pass over the [B][T] flags, one
+    small object per game.  The checker is chunk_to_games: field by field the same (tests/test_gpu_records.py).
+
+    An env whose "no step" rows (flag 3) are followed by played rows again -- a caller that switches envs off and on inside a
+    chunk -- is not a window: those envs go through chunk_to_games."""
+    assert after_end in ("drop", "new_game")
+    if isinstance(chunk_data, TrajectoryChunk):
+        chunk = chunk_data
+        chunk_data, obs_dim, observations = chunk.data, chunk.rec_obs_dim, chunk.obs if observations is None else observations
+    assert torch.is_tensor(chunk_data) and chunk_data.is_cuda, "chunk_to_records reads a device chunk (host arrays: chunk_to_games)"
+    T, B, F = chunk_data.shape
+    o = int(obs_dim)
+    assert F == o + 3 * A + 3, f"record of {F} floats is not obs_dim {o} + 3 * {A} + 3 (image observations live in chunk.obs: obs_dim 0)"
+    td = 0 if td_steps is None else int(td_steps)
+    _, target, err, game_end = chunk_targets(chunk_data, o, A, discount, td, ignore_termination, after_end, return_game_end=True)
+    # env-major on the device (a game's rows become one contiguous window), then to the host
+    rec = chunk_data.permute(1, 0, 2).contiguous().cpu().numpy()
+    game_end = game_end.t().contiguous().cpu().numpy()
+    if td_steps is not None:
+        target, err = target.t().contiguous().cpu().numpy(), err.t().contiguous().cpu().numpy()
+    else:
+        target = err = None
+    if observations is not None:
+        assert o == 0
+        observations = observations.permute(1, 0, 2).contiguous().to(torch.float32).cpu()
+    return records_from_host_copy(rec, game_end, o, A, discount, priority_scale, limit_of_game_play, ignore_termination,
+                                  keep_partial, after_end, observations, observation_shape, td_steps, target, err)
+
+
+def records_from_host_copy(rec, game_end, obs_dim, A, discount, priority_scale=1, limit_of_game_play=float("inf"),
+                           ignore_termination=False, keep_partial=True, after_end="drop", observations=None,
+                           observation_shape=None, td_steps=None, target=None, abs_td=None):
+    """The host half of chunk_to_records: env-major arrays rec [B][T][F], game_end [B][T] (int32, -1 = no game) and optionally
+    target / abs_td [B][T] for td_steps -> the list of ArrayGameRecord."""
+    B, T, _ = rec.shape
+    o = int(obs_dim)
+    flags = np.zeros((B, T), np.int8) if ignore_termination else rec[:, :, o + 1].astype(np.int8)
+    src = ChunkHostCopy(rec, o, A, discount, priority_scale, limit_of_game_play, observations, observation_shape,
+                        td_steps, target, abs_td)
+    odd = ((flags[:, :-1] == 3) & (flags[:, 1:] != 3)).any(1) if T > 1 else np.zeros(B, bool)
+    if odd.any():
+        game_end = game_end.copy()
+        game_end[odd] = -1
+    e, t0, t1, last = _segments(flags, game_end, keep_partial)
+    done = (last == 1) & ((t1 - t0) != limit_of_game_play)                      # game.py:270-271
+    games = [ArrayGameRecord(src, *w) for w in zip(e.tolist(), t0.tolist(), t1.tolist(), done.tolist())]
+    if odd.any():                                                              # the rare envs: the general loop, merged in env order
+        merged, k, envs = [], 0, e.tolist()
+        for env in np.nonzero(odd)[0].tolist():
+            sub = chunk_to_games(rec[env][:, None, :], o, A, discount, priority_scale, limit_of_game_play, ignore_termination,
+                                 keep_partial, after_end,
+                                 None if observations is None else observations[env][:, None, :], observation_shape)
+            while k < len(games) and envs[k] < env:
+                merged.append(games[k]); k += 1
+            merged.extend(sub)
+        merged.extend(games[k:])
+        games = merged
+    return games
+
+
 def _sync_active(env, mcts):
     """Hands the env's on/off array to the search (finished games stop consuming simulations, self_play.py:79)."""
     if getattr(env, "active", None) is not None or getattr(mcts, "_active", None) is not None:
         mcts.set_active(getattr(env, "active", None))
 
 
-def _play_step(env, heads, mcts, chunk, t, temperature, train=True):
-    """ONE env step of all env.B environments on the current stream -- the loop body of self_play.py:79-94: search the
-    current observation, pick the action (game.py:179-232), step the env, append the record (game.py:193-195,
-    263-267).  The single code path behind play_games and play_games_grouped."""
+def _search_phase(env, heads, mcts, chunk, t, temperature, train=True):
+    """First half of ONE env step of all env.B environments on the current stream -- self_play.py:79-94 up to the env's move:
+    search the current observation and pick the action (game.py:179-232).  For a host env with split stepping
+    (envs.HostVecEnv.step_begin) the download of the actions is enqueued too, so that the host can turn to another env group
+    while this search runs.  Returns what _record_phase needs (None: the launch stepped and recorded the built-in env itself)."""
     fused = getattr(env, "fused_step", None)     # built-in env + single-launch search: ONE launch per env step
     env_step = fused(chunk.data, t) if fused is not None else None
     kw = {} if env_step is None else dict(env_step=env_step)
@@ -183,15 +300,26 @@ def _play_step(env, heads, mcts, chunk, t, temperature, train=True):
     if owed is not None:
         if getattr(eng, "obs_recorded", False):
             chunk.owed_obs = None
+            chunk.apply_patch()
         else:
             chunk.flush_obs()
     if env_step is not None and getattr(eng, "env_stepped", False):
+        return None
+    out = eng.act(temperature)
+    if hasattr(env, "step_begin"):
+        env.step_begin(out[0])
+    return out
+
+
+def _record_phase(env, chunk, t, out):
+    """Second half: step the env with the chosen actions and append the record (game.py:193-195, 263-267)."""
+    if out is None:
         return
-    action, policy, child_visits, root_value = eng.act(temperature)
+    action, policy, child_visits, root_value = out
     if hasattr(env, "step_and_record"):          # built-in env: step + record in one launch
         env.step_and_record(action, chunk.data, t, policy, child_visits, root_value)
         return
-    obs, reward, terminated = env.step(action)
+    obs, reward, terminated = env.step_end() if hasattr(env, "step_begin") else env.step(action)
     rec_obs = getattr(env, "record_obs", None)   # post-step observation when `obs` already is the next game's reset one
     rec_obs = obs if rec_obs is None else rec_obs
     P = lambda x: C.c_void_p(x.data_ptr())
@@ -199,12 +327,20 @@ def _play_step(env, heads, mcts, chunk, t, temperature, train=True):
     if split:                                    # image observations stay float32, outside the float64 record
         if rec_obs is obs:                       # the next search reads this very tensor: its launch copies it (see above)
             chunk.owed_obs = (t, obs)
+            # ... except for the rows of envs that were reset inside this step: their post-step frames overwrite the copy
+            chunk.owed_patch = getattr(env, "record_patch", None)
         else:
             chunk.obs[t].copy_(rec_obs.reshape(env.B, -1))
     _lib.check(_lib.load().smz_traj_pack(P(chunk.data), chunk.T, t, 0 if split else env.obs_dim, env.num_actions,
                                          None if split else P(rec_obs), P(reward), P(terminated), P(action),
                                          P(policy), P(child_visits), P(root_value), env.B,
                                          C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)))
+
+
+def _play_step(env, heads, mcts, chunk, t, temperature, train=True):
+    """ONE env step of all env.B environments on the current stream -- the loop body of self_play.py:79-94.  The single code
+    path behind play_games and play_games_grouped (which runs the two halves of different env groups interleaved)."""
+    _record_phase(env, chunk, t, _search_phase(env, heads, mcts, chunk, t, temperature, train))
 
 
 def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
@@ -246,10 +382,19 @@ def play_games_grouped(groups, temperature, steps, train=True):
         g.stream.wait_stream(cur)
         assert g.chunk.T >= steps
         _sync_active(g.env, g.mcts)
+    # software pipeline: the search of step t + 1 of a group is enqueued right after its step t, BEFORE the host turns to the
+    # next group -- while the host waits for / steps the envs of one group (host envs: envs.HostVecEnv.step_end), the GPU runs
+    # the other groups' searches.  Per group the order of operations is play_games' own.
+    pend = []
+    for g in groups:
+        with torch.cuda.stream(g.stream):
+            pend.append(_search_phase(g.env, g.heads, g.mcts, g.chunk, 0, temperature, train) if steps > 0 else None)
     for t in range(steps):
-        for g in groups:
+        for k, g in enumerate(groups):
             with torch.cuda.stream(g.stream):
-                _play_step(g.env, g.heads, g.mcts, g.chunk, t, temperature, train)
+                _record_phase(g.env, g.chunk, t, pend[k])
+                if t + 1 < steps:
+                    pend[k] = _search_phase(g.env, g.heads, g.mcts, g.chunk, t + 1, temperature, train)
     for g in groups:
         if getattr(g.chunk, "owed_obs", None) is not None:
             with torch.cuda.stream(g.stream):
@@ -360,11 +505,15 @@ def play_game(environment=None, model=None, monte_carlo_tree_search=None, temper
 
 
 def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None, gather=None, priority_scale=1,
-                        ignore_termination=False, limit_of_game_play=None):
+                        ignore_termination=False, limit_of_game_play=None, td_steps=None, records="array"):
     """Self-play half of one learning_cycle iteration (self_play.py:245-271): play, gather to the learner rank,
     hand the games to replay_buffer.save_game, return (games, mean reward) on the learner rank.
     An env built with on_end="reset" plays game after game inside the chunk (only finished games are handed on, the
-    unfinished tail is dropped); on_end="mask" plays one game per env and stops searching it when it ends."""
+    unfinished tail is dropped); on_end="mask" plays one game per env and stops searching it when it ends.
+
+    records="array" (default): the games are ArrayGameRecord windows into one host copy of the chunk (chunk_to_records), with
+    the value targets and priorities of `td_steps` (default: replay_buffer.td_steps when the buffer has one) computed on the
+    device; records="lists": chunk_to_games' per-step Python lists (the checker; ~100x slower at 4096 envs x 64 steps)."""
     heads = model.heads(env.device)
     env.reset()
     chunk = play_games(env, heads, mcts, temperature, steps)
@@ -376,19 +525,42 @@ def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None
             return None, None
         data = torch.cat([p for p in parts], dim=1)
         frames = torch.cat([p for p in fparts], dim=1) if fparts is not None else None
-    torch.cuda.synchronize(env.device)
     on_end = getattr(env, "on_end", "continue")
     limit = limit_of_game_play if limit_of_game_play is not None else (getattr(env, "limit", 0) or steps)
-    games = chunk_to_games(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, priority_scale,
-                           limit_of_game_play=limit, ignore_termination=ignore_termination,
-                           keep_partial=on_end != "reset", after_end="new_game" if on_end == "reset" else "drop",
-                           observations=frames, observation_shape=getattr(env, "frame", None))
-    rewards = []
-    for g in games:
-        if replay_buffer is not None:
-            replay_buffer.save_game(g)
-        rewards.append(sum(g.rewards))
+    kw = dict(limit_of_game_play=limit, ignore_termination=ignore_termination, keep_partial=on_end != "reset",
+              after_end="new_game" if on_end == "reset" else "drop", observations=frames,
+              observation_shape=getattr(env, "frame", None))
+    if records == "array":
+        if td_steps is None:
+            td_steps = getattr(replay_buffer, "td_steps", None)
+        games = chunk_to_records(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, priority_scale, td_steps=td_steps, **kw)
+    else:
+        torch.cuda.synchronize(env.device)
+        games = chunk_to_games(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, priority_scale, **kw)
+    if replay_buffer is not None:
+        save = replay_buffer.save_game
+        for g in games:
+            save(g)
+    rewards = _reward_sums(games)
     return games, (sum(rewards) / len(rewards) if rewards else float("nan"))
+
+
+def _reward_sums(games):
+    """[sum(game.rewards) for game in games] for ArrayGameRecords without touching their lists: one sequential cumulative sum
+    per env over the shared host copy (bit-identical to Python's left-to-right sum for a game that starts at the chunk's first
+    row, within an ulp for later games of the env).  Records whose reward list became a real list are summed the slow way."""
+    out, cs = [], {}
+    for g in games:
+        if isinstance(g, ArrayGameRecord) and g._pristine("rewards"):
+            src = g._src
+            c = cs.get(id(src))
+            if c is None:
+                c = cs[id(src)] = np.cumsum(src.rec[:, :, src.o], axis=1)
+            row = c[g._e]
+            out.append(float(row[g._t1 - 1] - (row[g._t0 - 1] if g._t0 else 0.0)) if g._t1 > g._t0 else 0.0)
+        else:
+            out.append(sum(g.rewards))
+    return out
 
 
 def learning_cycle(number_of_iteration=10000, number_of_self_play_before_training=1, number_of_training_before_self_play=1,
@@ -437,7 +609,10 @@ def learning_cycle(number_of_iteration=10000, number_of_self_play_before_trainin
         learner = True
         if batched:
             steps = steps_per_iteration or getattr(gameplay, "limit", 0) or 500
-            game, _ = self_play_iteration(gameplay, muzero_model, monte_carlo_tree_search, temperature, steps, gather=gather)
+            # (the games are stored by self_play_iteration itself -- replay_buffer.save_game per game, self_play.py:266-268 --
+            #  and their mean reward comes back with them)
+            game, batched_reward = self_play_iteration(gameplay, muzero_model, monte_carlo_tree_search, temperature, steps,
+                                                       replay_buffer=replay_buffer, gather=gather)
             learner = game is not None        # with `gather`, only the learner rank receives the games (self_play.py:240-256)
             game = game or []
         else:
@@ -446,9 +621,12 @@ def learning_cycle(number_of_iteration=10000, number_of_self_play_before_trainin
                     for _ in range(number_of_self_play_before_training)]
         cache_reward, cache_loss = [], []
         if learner:
-            for g in game:
-                replay_buffer.save_game(g)
-                cache_reward.append(sum(g.rewards))
+            if batched:
+                cache_reward = [batched_reward] if game else []
+            else:
+                for g in game:
+                    replay_buffer.save_game(g)
+                    cache_reward.append(sum(g.rewards))
             # (the reference divides by zero when an iteration yields no game; a chunk of on_end="reset" envs may hold no
             # FINISHED game: nan, which never equals max(reward), so nothing is saved for it)
             reward.append(sum(cache_reward) / len(cache_reward) if cache_reward else float("nan"))

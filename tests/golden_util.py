@@ -8,7 +8,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SEARCH_FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
                          if not os.path.basename(p).startswith(("weights_", "selfplay", "temperature_", "visionnet_", "mlpnet_", "reanalyse",
-                                                                 "game_")))
+                                                                 "game_", "decode_floor")))
 SELFPLAY_FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "selfplay*.npz")))
 TEMPERATURES = (0.0, 0.2, 0.5, 1.0)
 

@@ -88,8 +88,9 @@ def test_resize_into_selected_rows_of_a_batch():
         lib.check(lib.load().smz_frames_resize_u8(None, 1, 4, 4, 2, 2, None, C.c_void_p(out.data_ptr()), None))
 
 
+@pytest.mark.parametrize("upload,workers", [("frames", 0), ("taps", 0), ("taps", 3)])
 @pytest.mark.parametrize("on_end", ["reset", "mask"])
-def test_host_envs_observed_through_rendered_frames_drive_the_vision_heads(on_end):
+def test_host_envs_observed_through_rendered_frames_drive_the_vision_heads(on_end, upload, workers):
     """envs.HostImageVecEnv over host CartPoles with a renderer: every recorded observation is the resize of the frame the env
     showed AFTER the recorded action (a pure host replay of the recorded actions reproduces all of them), the search of the
     next step sees the reset frame when a game ended, and the float32 frames are stored outside the float64 record."""
@@ -97,8 +98,10 @@ def test_host_envs_observed_through_rendered_frames_drive_the_vision_heads(on_en
     B, T, sims, limit, hw = 12, 7, 6, 3, (80, 120)
     model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, "visionnet_L1_seed0.npz"))
     heads = model.heads("cuda:0")
+    # upload="taps": only the pixels the resize reads go up (smz_frames_resize_taps_u8); workers: the envs step and render in
+    # child processes that write into the shared page-locked block -- the observations must not depend on either
     env = envs_mod.HostImageVecEnv([envs_mod.HostCartPoleRender(hw) for _ in range(B)], hw, 2, "cuda:0", env_seed=11,
-                                   limit=limit, on_end=on_end, first_env=5)
+                                   limit=limit, on_end=on_end, first_env=5, upload=upload, workers=workers)
     env.reset()
     first = env.obs.cpu().numpy().copy()
     m = mcts_mod.BatchedMCTS(B, num_simulations=sims, discount=0.999, root_exploration_fraction=0.1, use_graph=False)
@@ -135,7 +138,9 @@ def test_host_envs_observed_through_rendered_frames_drive_the_vision_heads(on_en
                               observation_shape=(3, 98, 98), after_end="new_game" if on_end == "reset" else "drop",
                               keep_partial=False)
     assert len(games) == n_ends and all(tuple(g.observations[0].shape) == (1, 3, 98, 98) for g in games)
-    assert env.upload_bytes >= (T + 1) * B * hw[0] * hw[1] * 3
+    assert env.upload_bytes >= (T + 1) * B * (hw[0] * hw[1] * 3 if upload == "frames" else 4 * 98 * 98 * 3)
+    assert env.record_obs is None          # no full-batch record copy -- the representation launch records, ended rows are patched
+    env.close()
 
 
 def test_representation_launch_appends_the_frames_it_reads_to_the_record():

@@ -1,0 +1,140 @@
+"""Host-resident envs: the rules around env.step (host_envs.HostSlice, game.py:96-131, 223-273) and the parallel
+stepper -- worker processes over a shared block -- against the serial adapter, env by env.  CPU tests (device "cpu": the
+transfers are plain copies); the GPU side is tests/test_gpu_host_envs.py."""
+import os
+import subprocess
+import sys
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+import stochastic_muzero_amd  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _envs():
+    return import_module("stochastic-muzero_amd.envs")
+
+
+def _he():
+    return import_module("stochastic-muzero_amd.host_envs")
+
+
+class Picky(import_module("stochastic-muzero_amd.host_envs").HostCartPole):
+    """A CartPole that refuses action 1 on every third step (the illegal-move rule, game.py:123-131) -- a module-level class of
+    this test file, so the worker processes must import it by name (the tests directory is the workers' working directory)."""
+
+    def __init__(self):
+        super().__init__()
+        self.n = 0
+
+    def step(self, action):
+        self.n += 1
+        if self.n % 3 == 0 and action == 1:
+            raise ValueError("illegal")
+        return super().step(action)
+
+
+def _run(env, T, seed):
+    r = np.random.RandomState(seed)
+    out = [env.reset().clone()]
+    for t in range(T):
+        a = torch.from_numpy(r.randint(0, 2, env.B).astype(np.int32))
+        obs, rew, flag = env.step(a)
+        out.append((obs.clone(), rew.clone(), flag.clone(), env.record_obs.clone(),
+                    None if env.active is None else env.active.clone()))
+    return out
+
+
+@pytest.mark.parametrize("on_end,limit", [("reset", 5), ("mask", 7), ("reset", 0)])
+def test_parallel_stepper_equals_the_serial_adapter_env_by_env(on_end, limit, monkeypatch):
+    monkeypatch.chdir(os.path.join(ROOT, "tests"))
+    envs_mod = _envs()
+    B, T = 23, 14
+    res = []
+    for workers in (0, 3, 5):
+        env = envs_mod.HostVecEnv([Picky() for _ in range(B)], 4, 2, "cpu", env_seed=11, limit=limit, on_end=on_end,
+                                  first_env=100, workers=workers)
+        try:
+            res.append(_run(env, T, 4))
+        finally:
+            env.close()
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0])
+        for a, b in zip(res[0][1:], other[1:]):
+            for x, y in zip(a, b):
+                assert (x is None and y is None) or torch.equal(x, y)
+    flags = torch.stack([s[2] for s in res[0][1:]])
+    assert (flags == 2).any() or limit == 0
+    rewards = torch.stack([s[1] for s in res[0][1:]])
+    assert (rewards < 0).any()                                 # illegal moves happened (and got the rule's reward)
+
+
+def test_record_keeps_the_post_step_observation_of_an_env_that_was_reset():
+    """on_end="reset": the next search sees the fresh observation, the record the post-step one (game.py:264)."""
+    envs_mod, he = _envs(), _he()
+    env = envs_mod.HostVecEnv([he.HostCartPole() for _ in range(6)], 4, 2, "cpu", env_seed=0, limit=3, on_end="reset")
+    env.reset()
+    twin = [he.HostCartPole() for _ in range(6)]
+    for i, e in enumerate(twin):
+        e.reset(seed=i)
+    for t in range(3):
+        a = torch.zeros(6, dtype=torch.int32)
+        obs, rew, flag = env.step(a)
+        post = np.stack([e.step(0)[0] for e in twin])
+        assert np.array_equal(env.record_obs.numpy(), post)
+    assert (flag == 2).all()
+    fresh = np.stack([he.HostCartPole().reset(seed=i + 1000003)[0] for i in range(6)])
+    assert np.array_equal(obs.numpy(), fresh) and not np.array_equal(fresh, post)
+    env.close()
+
+
+def test_workers_never_import_torch_and_exit_with_their_parent_object():
+    envs_mod, he = _envs(), _he()
+    env = envs_mod.HostVecEnv([he.HostCartPole for _ in range(8)], 4, 2, "cpu", workers=2)      # callables: built in the worker
+    pids = [p.pid for p in env._procs]
+    maps = open(f"/proc/{pids[0]}/maps").read()
+    assert "libtorch" not in maps and "libamdhip64" not in maps and "smz_hostenv_" in maps
+    env.reset()
+    env.step(torch.ones(8, dtype=torch.int32))
+    env.close()
+    assert all(p.poll() is not None for p in env._procs) or not env._procs
+    for pid in pids:
+        assert not os.path.exists(f"/proc/{pid}") or open(f"/proc/{pid}/stat").read().split()[2] == "Z"
+
+
+def test_tap_index_is_atens_source_index_rule():
+    he = _he()
+    for n_in, n_out in ((400, 98), (600, 98), (210, 98), (160, 98), (97, 98), (133, 98), (98, 98), (7, 3)):
+        idx = he.tap_index(n_in, n_out).reshape(n_out, 2)
+        # the same rule through torch's own CPU kernel: resizing a ramp picks exactly these source positions
+        ramp = torch.arange(n_in, dtype=torch.float32).view(1, 1, 1, n_in)
+        out = torch.nn.functional.interpolate(ramp, size=(1, n_out), mode="bilinear", align_corners=False).view(-1).numpy()
+        scale = np.float32(n_in) / np.float32(n_out)
+        src = np.maximum((np.float64(scale) * (np.arange(n_out) + 0.5) - 0.5).astype(np.float32), 0)
+        l1 = np.clip(src - idx[:, 0].astype(np.float32), 0, 1)
+        want = idx[:, 0] * (1 - l1) + idx[:, 1] * l1
+        np.testing.assert_allclose(out, want, rtol=2e-6, atol=1e-4)
+        assert (idx[:, 0] <= idx[:, 1]).all() and idx.max() == n_in - 1 or n_in > 2 * n_out
+
+
+def test_frame_adapter_taps_are_the_pixels_the_resize_reads():
+    he = _he()
+    H, W = 40, 60
+    frame = np.random.RandomState(0).randint(0, 256, (H, W, 3)).astype(np.uint8)
+
+    class E:
+        def render(self):
+            return frame
+    taps = he.FrameAdapter((H, W), (9, 11), upload="taps").observe(E(), None).reshape(18, 22, 3)
+    iy, ix = he.tap_index(H, 9), he.tap_index(W, 11)
+    for oy in range(9):
+        for ox in range(11):
+            for r in range(2):
+                for q in range(2):
+                    assert np.array_equal(taps[2 * oy + r, 2 * ox + q], frame[iy[2 * oy + r], ix[2 * ox + q]])
+    full = he.FrameAdapter((H, W), (9, 11), upload="frames").observe(E(), None)
+    assert np.array_equal(full.reshape(H, W, 3), frame)
