@@ -127,10 +127,28 @@ def algorithmic_bytes(stats, A, K, S, launches):
 
 
 def host_cores():
+    """Cores this process can actually USE: its affinity mask, capped by the container's CPU quota (cgroup v2 cpu.max / v1
+    cfs_quota_us) -- the bench box shows 256 hardware threads and grants 16 CPUs' worth of time; threads beyond the quota only
+    get the others throttled."""
     try:
-        return len(os.sched_getaffinity(0))               # cores this process may actually run on
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                quota = q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
 
 
 def cpu_baseline_mlp(wl, weights_path, seconds_target=15.0):
@@ -166,7 +184,7 @@ def cpu_baseline_mlp(wl, weights_path, seconds_target=15.0):
                 sample=f"{n_env} envs x {steps} steps x {wl['sims']} sims of the same {what} workload, C oracle "
                        f"(oracle/smz_oracle.c) with plain-C MLP heads, {cores} threads (one game per thread), "
                        f"{dt:.1f} s wall = {dt * cores:.0f} core-seconds; one thread alone: {single:.0f} simulations/s "
-                       f"(os.cpu_count() = {os.cpu_count()})")
+                       f"(os.cpu_count() = {os.cpu_count()}; cores = affinity mask capped by the cgroup CPU quota)")
 
 
 def cpu_baseline_vision(wl, model, seconds_target=12.0):
@@ -283,8 +301,10 @@ def main():
                          "host-buffer variant: 'python' = envs.HostVecEnv over Python CartPoles (measures the Python), 'native' = "
                          "envs.HostCartPoleVec (compiled host step, smz_host_cartpole_step)")
     ap.add_argument("--host-workers", type=int, default=None,
-                    help="--host-env python: env worker processes per GPU, split over the env groups (default min(64, host cores / 2); "
+                    help="--host-env python: env worker processes per env group (default min(64, 3 x usable host cores); "
                          "0 = step the envs serially in this process)")
+    ap.add_argument("--gather-slices", type=int, default=4,
+                    help="N > 1: parts a K-step block's trajectory gather is cut into (each part's transfer overlaps the next part's search)")
     ap.add_argument("--frame-upload", default="taps", choices=["taps", "frames"],
                     help="--host-env on the vision workload: upload only the pixels the 98x98 resize reads (taps) or whole frames")
     args = ap.parse_args()
@@ -348,7 +368,10 @@ def main():
     G = args.groups if args.groups > 0 else (2 if ((B >= 262144 or args.host_env == "python") and B % 2 == 0) else 1)
     host_workers = 0
     if args.host_env == "python":
-        host_workers = args.host_workers if args.host_workers is not None else min(64, max(1, host_cores() // 2))
+        # worker processes PER ENV GROUP: idle workers sleep in the kernel (futex), so while one group's envs step, the other
+        # group's workers cost nothing and every group may use all usable cores; 3 x the cores hides the wake-up latencies
+        # (measured on the 16-CPU-quota bench box: 14 workers 76 M, 16 113 M, 24 135 M simulations/s with one group)
+        host_workers = args.host_workers if args.host_workers is not None else min(64, max(1, 3 * host_cores()))
     assert B % G == 0, "--groups must divide the env count"
     Bg = B // G
     groups = []
@@ -358,14 +381,14 @@ def main():
             env = envs_mod.HostCartPoleVec(Bg, dev, seed=0, first_env=glo)
         elif wl["env"] == "cartpole" and args.host_env:
             env = envs_mod.HostVecEnv([envs_mod.HostCartPole for _ in range(Bg)], 4, 2, dev, env_seed=0, limit=0,
-                                      on_end="reset", first_env=glo, workers=host_workers // G)
+                                      on_end="reset", first_env=glo, workers=host_workers)
         elif wl["env"] == "cartpole":
             env = envs_mod.CartPoleVec(Bg, dev, seed=0, first_env=glo, total_envs=total)
         elif wl["env"] == "image" and args.host_env:
             # host envs observed through rendered 400x600x3 uint8 frames (CartPole-v1's render size), uploaded
             # through pinned memory and resized to 98x98 on the engine's stream (smz_frames_resize_u8)
             env = envs_mod.HostImageVecEnv([envs_mod.HostCartPoleRender((400, 600)) for _ in range(Bg)], (400, 600), wl["A"], dev,
-                                           env_seed=0, limit=0, on_end="reset", first_env=glo, workers=host_workers // G,
+                                           env_seed=0, limit=0, on_end="reset", first_env=glo, workers=host_workers,
                                            upload=args.frame_upload)
         elif wl["env"] == "image":
             env = envs_mod.ImageVec(Bg, wl["A"], dev, seed=0, first_env=glo, total_envs=total)
@@ -392,29 +415,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def gather_chunks(chunks, n):
-        """The finished chunk of this rank -> learner rank: the float64 records and, for image workloads, the float32 frames."""
-        gather_mod.gather_to_learner(torch.cat([c.data[:n] for c in chunks], dim=1))
-        if chunks[0].obs is not None:
-            gather_mod.gather_to_learner(torch.cat([c.obs[:n] for c in chunks], dim=1))
+    # N > 1: the chunk is played in `--gather-slices` slices; every finished slice's rows go to rank 0 on a side stream (compact
+    # wire format) while the next slice is searched (gather.TrajectoryGather) -- only the last slice's transfer is exposed
+    tg = gather_mod.TrajectoryGather(groups[0].chunk.rec_obs_dim, wl["A"], slices=args.gather_slices) if world > 1 else None
+    exposed = []
+
+    def rows(chunks, name, t0, t1):
+        parts = [getattr(c, name)[t0:t1] for c in chunks]
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
+    def play_and_gather(n):
+        """n env steps of every group; with N > 1 in slices, each slice's rows handed to the overlapped gather."""
+        if tg is None:
+            return sp.play_games_grouped(groups, args.temperature, n)
+        k = max(1, min(tg.slices, n))
+        cuts = [n * i // k for i in range(k + 1)]
+        for i in range(k):
+            chunks = sp.play_games_grouped(groups, args.temperature, cuts[i + 1] - cuts[i], t0=cuts[i])
+            tg.start(rows(chunks, "data", cuts[i], cuts[i + 1]),
+                     rows(chunks, "obs", cuts[i], cuts[i + 1]) if chunks[0].obs is not None else None)
+        tg.finish()
+        return chunks
 
     def timed_block():
         """EXACTLY K steps (+ the trajectory gather when N > 1) between two barrier + synchronize pairs; max over ranks."""
         barrier()
         t0 = time.perf_counter()
-        chunks = sp.play_games_grouped(groups, args.temperature, args.steps)
-        if world > 1:
-            gather_chunks(chunks, args.steps)
+        play_and_gather(args.steps)
         barrier()
-        return max_over_ranks(time.perf_counter() - t0)
+        dt_block = max_over_ranks(time.perf_counter() - t0)
+        if tg is not None and tg.exposed_gather_ms() is not None:
+            exposed.append(tg.exposed_gather_ms())
+        return dt_block
 
     sink = ReplaySink(td_steps=50)                            # config/experiment_421_config.json: td_steps 50
     e2e_parts = []
     if args.end_to_end:
         assert G == 1, "--end-to-end times self_play_iteration: one env group"
-
-        def gather_fn(x):
-            return gather_mod.gather_to_learner(x)
 
         def timed_block():                                    # noqa: F811  (replaces the search-only block)
             """ONE self_play_iteration of K steps -- play, (gather,) transfer, Game records, save_game x games -- between two
@@ -423,7 +460,7 @@ def main():
             barrier()
             t0 = time.perf_counter()
             games, _ = sp.self_play_iteration(env, model, mcts, args.temperature, args.steps, replay_buffer=sink,
-                                              gather=gather_fn if world > 1 else None, ignore_termination=True)
+                                              gather=tg if world > 1 else None, ignore_termination=True)
             barrier()
             dt_block = max_over_ranks(time.perf_counter() - t0)
             if rank == 0:
@@ -441,9 +478,8 @@ def main():
     gc.collect()
     gc.freeze()
     gc.disable()
-    chunks = sp.play_games_grouped(groups, args.temperature, args.warmup)                 # W untimed warm-up steps
-    if world > 1:      # the first grouped send/recv builds the RCCL communicators: keep that out of the timed region
-        gather_chunks(chunks, max(1, args.warmup))
+    # W untimed warm-up steps (with N > 1 the first grouped send / recv builds the RCCL communicators here, outside the timed region)
+    chunks = play_and_gather(max(1, args.warmup) if world > 1 else args.warmup)
     first = timed_block()                                      # block 1 (timed like the others; also sizes R)
     R = int(min(args.max_blocks, max(1, np.ceil(args.min_timed_seconds / max(first, 1e-6)))))
     blocks = [first] + [timed_block() for _ in range(R - 1)]
@@ -467,7 +503,8 @@ def main():
         for _ in range(5):
             barrier()
             t0 = time.perf_counter()
-            gather_chunks(chunks, args.steps)
+            tg.start(rows(chunks, "data", 0, args.steps), rows(chunks, "obs", 0, args.steps) if chunks[0].obs is not None else None)
+            tg.finish()
             barrier()
             gts.append(max_over_ranks(time.perf_counter() - t0))
         gather_ms = 1e3 * float(np.median(gts))
@@ -488,9 +525,9 @@ def main():
                         ("step-wise kernels" + ("" if args.no_graph else ", one HIP graph per env step")),
               "stream_groups": G, "heads": type(groups[0].heads).__name__,
               "env": ("host, compiled step (envs.HostCartPoleVec: pinned-memory action download + observation upload per step)" if args.host_env == "native"
-                      else f"host, Python envs rendering 400x600x3 uint8 frames (envs.HostImageVecEnv: {host_workers} worker processes over {G} env group(s), page-locked shared block, "
+                      else f"host, Python envs rendering 400x600x3 uint8 frames (envs.HostImageVecEnv: {host_workers} worker processes for each of {G} env group(s), page-locked shared block, "
                            f"upload = {args.frame_upload}: " + ("115 KB of resize taps per frame + smz_frames_resize_taps_u8" if args.frame_upload == "taps" else "720 KB frames + smz_frames_resize_u8") + " per step)" if (args.host_env and wl["env"] == "image")
-                      else f"host, Python envs (envs.HostVecEnv: {host_workers} worker processes over {G} env group(s) writing into a page-locked shared block; action download + observation upload per step; "
+                      else f"host, Python envs (envs.HostVecEnv: {host_workers} worker processes for each of {G} env group(s) (sleeping on a futex while idle) writing into a page-locked shared block; action download + observation upload per step; "
                            "one group's search overlaps the other's host step)" if args.host_env else "device"),
               "host_workers": host_workers if args.host_env == "python" else None,
               "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}
@@ -539,8 +576,15 @@ def main():
     if per_rank_rate is not None:
         out["per_rank_simulations_per_s"] = per_rank_rate
         out["timing"]["gather_ms_median"] = gather_ms
-        out["timing"]["gather_bytes_per_rank"] = int(sum(c.data[:args.steps].numel() * 8 + (c.obs[:args.steps].numel() * 4 if c.obs is not None else 0)
-                                                         for c in chunks))
+        rec_bytes = sum(sum(m.numel() * m.element_size() for m in gather_mod.pack_records(c.data[:args.steps], c.rec_obs_dim, wl["A"]))
+                        for c in chunks)
+        out["timing"]["gather_bytes_per_rank"] = int(rec_bytes + sum(c.obs[:args.steps].numel() * 4 for c in chunks if c.obs is not None))
+        out["timing"]["gather_overlap"] = {
+            "slices": tg.slices, "exposed_ms_median": float(np.median(exposed)) if exposed else None,
+            "how": "the K-step block is played in `slices` parts; each finished part's rows travel to rank 0 on a side stream "
+                   "(float32 for observations / flags / actions / root values, float64 for rewards / policies / child visits) while "
+                   "the next part is searched; exposed = device time between the end of the last search and the end of the exchange "
+                   "(None: host-staged gloo exchange); gather_ms_median = one whole K-step chunk exchanged alone"}
 
     # ---- roofline (rank 0) --------------------------------------------------------------------------------------
     if rank == 0 and not args.no_roofline:

@@ -206,7 +206,7 @@ class HostVecEnv:
     Observations are flattened float32 vectors (game.py:145-167); rendered RGB frames: HostImageVecEnv."""
 
     def __init__(self, envs, obs_dim, num_actions, device, action_map=None, env_seed=0, limit=0, on_end="reset", first_env=0,
-                 transform=None, workers=0, _adapter=None):
+                 transform=None, workers=0, spin=50, _adapter=None):
         assert on_end in ("mask", "reset")
         self.lib = _lib.load()
         self.B = len(envs)
@@ -216,6 +216,7 @@ class HostVecEnv:
         self.env_seed, self.limit, self.on_end, self.first_env = int(env_seed), int(limit), on_end, int(first_env)
         self.adapter = _adapter if _adapter is not None else _he.VectorAdapter(self.obs_dim, transform)
         self.workers = int(min(max(0, workers), self.B))
+        self.spin = int(spin)        # polls of a shared word before a waiter sleeps in the kernel (futex); 0 on a CPU-quota'd box is fine
         B, row, dtype = self.B, self.adapter.row, self.adapter.dtype
         lay = _he.block_layout(B, row, dtype)
         self._procs, self._block, self._registered, self._seq = [], None, False, 0
@@ -230,6 +231,7 @@ class HostVecEnv:
             self._base = torch.zeros(lay["total"], dtype=torch.uint8, pin_memory=self.device.type != "cpu")
             buf = memoryview(self._base.numpy())
         self._arr, self._ctrl, self._lay = _he.map_arrays(buf, B, row, dtype, max(1, self.workers))
+        self._words = _he.control_words(buf)
         self._host_ptr = self._base.data_ptr()
         tdt = torch.float32 if dtype is np.float32 else torch.uint8
         self._d_action = torch.zeros(B, dtype=torch.int32, device=self.device)
@@ -343,7 +345,7 @@ class HostVecEnv:
             spec = dict(block_path=self._block.path, nbytes=self._block.nbytes, B=B, row=self.adapter.row, dtype=self.adapter.dtype,
                         workers=W, worker=w, lo=cuts[w], envs=list(envs[cuts[w]:cuts[w + 1]]), adapter=self.adapter,
                         action_map=self.action_map, env_seed=self.env_seed, limit=self.limit, on_end=self.on_end,
-                        first_env=self.first_env, parent_pid=os.getpid())
+                        first_env=self.first_env, parent_pid=os.getpid(), spin=self.spin)
             f = tempfile.NamedTemporaryFile(prefix="smz_hostenv_spec_", suffix=".pkl", delete=False)
             pickle.dump(spec, f, protocol=pickle.HIGHEST_PROTOCOL)
             f.close()
@@ -371,14 +373,23 @@ class HostVecEnv:
             return
         self._seq += 1
         self._ctrl[1] = cmd
-        self._ctrl[0] = self._seq
+        self._words[_he.GO] = self._seq
+        _he.futex_wake_all(self._words, _he.GO)
 
     def _wait_workers(self):
+        """Sleeps on the completion bell until every worker has finished the current command."""
         if self._slice is not None:
             return
-        alive = lambda: all(p.poll() is None for p in self._procs)           # noqa: E731
-        for w in range(self.workers):
-            _he.wait_for(self._ctrl, 8 + w, self._seq, spin=20000, alive=alive)
+        done, seq, words = self._ctrl[8:8 + self.workers], self._seq, self._words
+        n = 0
+        while True:
+            bell = int(words[_he.NOTIFY])
+            if (done == seq).all():
+                return
+            _he.futex_wait_change(words, _he.NOTIFY, bell, timeout_s=0.01, spin=self.spin)
+            n += 1
+            if n % 50 == 0 and not all(p.poll() is None for p in self._procs):
+                raise RuntimeError("a host-env worker process died (its traceback is above)")
 
     # ---- the loop's interface --------------------------------------------------------------------------------------------
     def reset(self):
@@ -422,7 +433,8 @@ class HostVecEnv:
             try:
                 self._seq += 1
                 self._ctrl[1] = _he.CMD_EXIT
-                self._ctrl[0] = self._seq
+                self._words[_he.GO] = self._seq
+                _he.futex_wake_all(self._words, _he.GO)
             except Exception:
                 pass
             for p in self._procs:

@@ -9,8 +9,32 @@ import torch
 import torch.distributed as dist
 
 
+_PEER_SIZES = {}
+
+
+def peer_sizes(n_local, device, group=None):
+    """Env count (dim 1 of a slab) of every rank's shard.  Shards may differ by one env (shard_range), so the learner cannot
+    size its receive buffers from its own slab: the sizes are exchanged ONCE per (group, local size) with a tiny all_gather and
+    remembered -- every rank calls the gather in the same order, so the caches stay in step."""
+    key = (id(group), int(n_local))
+    got = _PEER_SIZES.get(key)
+    if got is None:
+        world = dist.get_world_size(group)
+        mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+        out = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(out, mine, group=group)
+        got = _PEER_SIZES[key] = [int(t.item()) for t in out]
+    return got
+
+
+def _like(slab, n_envs):
+    shape = list(slab.shape)
+    shape[1] = n_envs
+    return torch.empty(shape, dtype=slab.dtype, device=slab.device)
+
+
 def gather_to_learner(slab, dst=0, group=None):
-    """Returns the list of every rank's slab on rank `dst` (rank order), None elsewhere."""
+    """Returns the list of every rank's slab [T][B_rank][...] on rank `dst` (rank order), None elsewhere."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return [slab]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -18,8 +42,9 @@ def gather_to_learner(slab, dst=0, group=None):
     if dist.get_backend(group) == "gloo" and slab.is_cuda:     # functional runs without RCCL: stage through the host
         parts = gather_to_learner(slab.cpu(), dst, group)
         return None if parts is None else [p.to(slab.device) for p in parts]
+    sizes = peer_sizes(slab.shape[1], slab.device, group)
     if rank == dst:
-        parts = [slab if r == dst else torch.empty_like(slab) for r in range(world)]
+        parts = [slab if r == dst else _like(slab, sizes[r]) for r in range(world)]
         ops = [dist.P2POp(dist.irecv, parts[r], r, group) for r in range(world) if r != dst]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
@@ -30,10 +55,136 @@ def gather_to_learner(slab, dst=0, group=None):
 
 
 def shard_range(total_envs, rank, world):
-    """Contiguous env shard of a rank: env i keeps its seed and initial state whatever the world size."""
-    per = (total_envs + world - 1) // world
-    lo = min(total_envs, rank * per)
-    return lo, min(total_envs, lo + per)
+    """Contiguous env shard of a rank: env i keeps its seed and initial state whatever the world size.  Shards differ by at
+    most one env; a job with fewer envs than ranks is refused -- an engine for
+    zero trees cannot be built, and a rank without work would still sit in every collective."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside a world of {world}")
+    if total_envs < world:
+        raise ValueError(f"{total_envs} envs cannot be sharded over {world} ranks: every rank needs at least one env")
+    return total_envs * rank // world, total_envs * (rank + 1) // world
+
+
+def pack_records(data, obs_dim, A):
+    """Wire format of a [..., F] float64 trajectory record (F = obs_dim + 3 A + 3: observation | reward | flag | policy |
+    action one-hot | root value | child visits): the fields that ARE float32 values or small integers -- observation (the env's
+    float32 row), flag, one-hot action, root value (numpy float32 in the reference, game.py:172) -- travel as float32, the
+    float64 ones (reward: a Python float from the env; policy, child visits: numpy float64, game.py:184-209) stay float64.
+    CartPole: 8 x 4 + 5 x 8 = 72 bytes per env step instead of 13 x 8 = 104.  Lossless (unpack_records inverts it bit for bit)."""
+    o = int(obs_dim)
+    narrow = torch.cat([data[..., :o], data[..., o + 1:o + 2], data[..., o + 2 + A:o + 3 + 2 * A]], -1).to(torch.float32)
+    wide = torch.cat([data[..., o:o + 1], data[..., o + 2:o + 2 + A], data[..., o + 3 + 2 * A:]], -1).contiguous()
+    return narrow, wide
+
+
+def unpack_records(narrow, wide, obs_dim, A):
+    o = int(obs_dim)
+    n = narrow.to(torch.float64)
+    return torch.cat([n[..., :o], wide[..., :1], n[..., o:o + 1], wide[..., 1:1 + A], n[..., o + 1:o + 2 + A], wide[..., 1 + A:]], -1)
+
+
+class TrajectoryGather:
+    """The trajectory exchange as an object: compact wire format and overlap with the search.
+
+        tg = TrajectoryGather(obs_dim, A, slices=4)
+        for each slice of the chunk's steps:   play the slice;  tg.start(chunk.data[t0:t1] [, chunk.obs[t0:t1]])
+        parts = tg.finish()                    # learner: (records [T][B_total][F] float64, frames or None); actors: None
+
+    start() returns at once: on a side stream that first waits for the current (search) stream, the rows are packed
+    (pack_records) and handed to the grouped send / receive, so slice k's transfer over xGMI runs while the search of slice
+    k + 1 computes; only the last slice's transfer is exposed.  finish() makes the current stream wait for everything and
+    assembles the learner's tensors.  With "gloo" (functional runs: ranks sharing a GPU, CPU tests) the same calls go
+    through the host synchronously.  Usable wherever a plain `gather(slab) -> parts` callable is (it is one: the whole
+    slab as a single slice)."""
+
+    def __init__(self, obs_dim, A, dst=0, group=None, slices=4, compact=True):
+        self.o, self.A, self.dst, self.group, self.slices, self.compact = int(obs_dim), int(A), dst, group, max(1, int(slices)), compact
+        self._side, self._pending = None, []
+        self.exposed_ms = None
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def start(self, data, frames=None):
+        if not self._active():
+            self._pending.append(((data, None), frames, None))
+            return
+        nccl = dist.get_backend(self.group) == "nccl" and data.is_cuda
+        if not nccl:                                             # gloo: staged through the host, synchronous
+            msgs = list(pack_records(data, self.o, self.A)) if self.compact else [data.contiguous()]
+            if frames is not None:
+                msgs.append(frames.contiguous())
+            got = [gather_to_learner(m, self.dst, self.group) for m in msgs]
+            self._pending.append((None, None, got))
+            return
+        cur = torch.cuda.current_stream(data.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=data.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            msgs = list(pack_records(data, self.o, self.A)) if self.compact else [data.contiguous()]
+            if frames is not None:
+                msgs.append(frames.contiguous())
+            for m in msgs:
+                m.record_stream(self._side)
+            world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+            sizes = peer_sizes(data.shape[1], data.device, self.group)
+            if rank == self.dst:
+                bufs = [[m if r == rank else _like(m, sizes[r]) for r in range(world)] for m in msgs]
+                ops = [dist.P2POp(dist.irecv, b[r], r, self.group) for b in bufs for r in range(world) if r != rank]
+            else:
+                bufs, ops = None, [dist.P2POp(dist.isend, m, self.dst, self.group) for m in msgs]
+            works = dist.batch_isend_irecv(ops)
+        self._pending.append((works, msgs, bufs))
+
+    def finish(self):
+        """Learner: (records, frames) gathered over ranks (dim 1) and slices (dim 0); other ranks: None."""
+        pend, self._pending = self._pending, []
+        if not pend:
+            return None
+        if not self._active():
+            data = torch.cat([p[0][0] for p in pend], 0)
+            frames = torch.cat([p[1] for p in pend], 0) if pend[0][1] is not None else None
+            return data, frames
+        learner = dist.get_rank(self.group) == self.dst
+        staged = pend[0][0] is None
+        if not staged:
+            dev = pend[0][1][0].device
+            cur = torch.cuda.current_stream(dev)
+            t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+            t0.record(cur)
+            with torch.cuda.stream(self._side):
+                for works, _, _ in pend:
+                    for w in works:
+                        w.wait()
+            cur.wait_stream(self._side)
+            t1.record(cur)
+            self._exposed = (t0, t1)
+        if not learner:
+            return None
+        rows, frame_rows = [], []
+        for _, _, bufs in pend:
+            if bufs is None or bufs[0] is None:
+                return None
+            k = 0
+            if self.compact:
+                rows.append(torch.cat([unpack_records(n, w, self.o, self.A) for n, w in zip(bufs[0], bufs[1])], 1))
+                k = 2
+            else:
+                rows.append(torch.cat(list(bufs[0]), 1))
+                k = 1
+            if len(bufs) > k:
+                frame_rows.append(torch.cat(list(bufs[k]), 1))
+        return torch.cat(rows, 0), (torch.cat(frame_rows, 0) if frame_rows else None)
+
+    def exposed_gather_ms(self):
+        """After a synchronisation: device time between the end of the search and the end of the exchange in the last finish()
+        (what of the transfer the search did not hide); None for staged (gloo) exchanges."""
+        ev = getattr(self, "_exposed", None)
+        return None if ev is None else float(ev[0].elapsed_time(ev[1]))
+
+    def __call__(self, slab):                                    # the plain-callable protocol: one slab, one slice, list of parts
+        return gather_to_learner(slab, self.dst, self.group)
 
 
 def broadcast_model(model, src=0, group=None, device=None):

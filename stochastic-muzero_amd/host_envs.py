@@ -14,6 +14,7 @@ parent registers the mapping with the HIP runtime (page-locked), so rows written
 they lie.  Hand-off is by sequence numbers in shared memory (spin, then short sleeps): a step of 4096 CartPoles is ~0.1 ms of
 work per worker, less than a pipe round trip.
 """
+import ctypes
 import mmap
 import os
 import pickle
@@ -139,11 +140,33 @@ class FrameAdapter:
         self.H, self.W = int(frame_hw[0]), int(frame_hw[1])
         self.out_h, self.out_w = int(out_hw[0]), int(out_hw[1])
         self.frame_source, self.upload = frame_source, upload
-        if upload == "taps":
-            self._ix = np.ix_(tap_index(self.H, self.out_h), tap_index(self.W, self.out_w))
-            self.row = 2 * self.out_h * 2 * self.out_w * 3
-        else:
-            self.row = self.H * self.W * 3
+        self.row = 2 * self.out_h * 2 * self.out_w * 3 if upload == "taps" else self.H * self.W * 3
+        self._lib = None
+
+    def __getstate__(self):                                 # (sent to a worker process: the library handle is per process)
+        d = dict(self.__dict__)
+        d["_lib"] = None
+        return d
+
+    def _taps(self, frame):
+        """The gather runs in libsmzhost.so (plain C, smzh_gather_taps_u8: ~12 us per 400 x 600 frame; numpy's fancy indexing
+        needs 90-600 us for the same 115 KB) -- the one native piece a worker loads, and not a GPU library."""
+        if self._lib is None:
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsmzhost.so")
+            if not os.path.exists(path):
+                raise RuntimeError(f"{path} is missing: build it with `make -C stochastic-muzero_amd/csrc host`")
+            lib = ctypes.CDLL(path)
+            lib.smzh_gather_taps_u8.restype = ctypes.c_int
+            lib.smzh_gather_taps_u8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+            self._iy, self._ix = tap_index(self.H, self.out_h), tap_index(self.W, self.out_w)
+            self._buf = np.empty(self.row, np.uint8)
+            self._lib = lib
+        frame = np.ascontiguousarray(frame)
+        rc = self._lib.smzh_gather_taps_u8(frame.ctypes.data, self.H, self.W, self._iy.ctypes.data, self._iy.size,
+                                           self._ix.ctypes.data, self._ix.size, self._buf.ctypes.data)
+        assert rc == 0
+        return self._buf                                    # (reused from call to call: HostSlice copies it into the env's row)
 
     def observe(self, env, obs):
         frame = env.render() if self.frame_source == "render" else (obs[0] if isinstance(obs, tuple) else obs)
@@ -151,7 +174,7 @@ class FrameAdapter:
         assert frame.shape == (self.H, self.W, 3), f"frame {frame.shape}, expected {(self.H, self.W, 3)}"
         frame = frame.astype(np.uint8, copy=False)          # (the reference: x.copy().astype(np.uint8), game.py:84)
         if self.upload == "taps":
-            return frame[self._ix].reshape(-1)
+            return self._taps(frame)
         return frame.reshape(-1)
 
 
@@ -265,9 +288,15 @@ def map_arrays(buf, B, row, dtype, workers):
                ended=np.frombuffer(buf, np.uint8, B, lay["ended"]),
                obs=np.frombuffer(buf, dtype, B * row, lay["obs"]).reshape(B, row),
                rec=np.frombuffer(buf, dtype, B * row, lay["rec"]).reshape(B, row))
-    ctrl = np.frombuffer(buf, np.int64, CTRL_BYTES // 8, 0)      # [0] go sequence, [1] command, [8 + w] done sequence of worker w
+    # control page: int32 words [GO] step sequence (futex), [NOTIFY] completion bell (futex); int64 slots [1] command,
+    # [8 + w] sequence number worker w has finished (-1: attached, nothing done yet)
+    ctrl = np.frombuffer(buf, np.int64, CTRL_BYTES // 8, 0)
     assert 8 + workers <= ctrl.size
     return arr, ctrl, lay
+
+
+def control_words(buf):
+    return np.frombuffer(buf, np.int32, CTRL_BYTES // 4, 0)
 
 
 class SharedBlock:
@@ -292,20 +321,46 @@ class SharedBlock:
             self.path = None
 
 
-def wait_for(ctrl, index, value, spin=2000, timeout=None, alive=None):
-    """Waits until ctrl[index] >= value: a short spin (a step is tens of microseconds away), then sleeps that grow to 0.2 ms."""
-    n, nap = 0, 20e-6
-    t0 = time.perf_counter() if timeout is not None else 0.0
-    while ctrl[index] < value:
-        n += 1
-        if n > spin:
-            time.sleep(nap)
-            nap = min(nap * 1.5, 200e-6)
-            if n % 64 == 0:
-                if alive is not None and not alive():
-                    raise RuntimeError("host-env worker died")
-                if timeout is not None and time.perf_counter() - t0 > timeout:
-                    raise TimeoutError("host-env worker did not answer")
+# ---- blocking hand-off: futex words in the control page ------------------------------------------------------------------------
+# Spinning workers are the wrong default: a container's CPU quota (cgroup cpu.max: 16 CPUs' worth on the 256-thread bench box)
+# is burnt by every spinner, and throttling then stalls everybody -- measured: 16 spinning workers 1.9 ms per step, 64 workers
+# 6.0 ms, 128 workers 12.4 ms.  Waiters sleep in the kernel on a 32-bit word of the shared control page instead (futex: a
+# syscall only when there is something to wait for or somebody to wake) after a spin of a few microseconds.
+#   word GO     (ctrl32[0]) step sequence number, written by the parent; workers wait for it to change
+#   word NOTIFY (ctrl32[2]) bumped by every worker that finishes; the parent waits for it to change, then looks at the flags
+_SYS_FUTEX, _FUTEX_WAIT, _FUTEX_WAKE = 202, 0, 1          # x86-64 Linux; shared (not PRIVATE) futexes: the waiters are other processes
+_libc = None
+
+
+class _Timespec(ctypes.Structure):
+    _fields_ = [("tv_sec", ctypes.c_long), ("tv_nsec", ctypes.c_long)]
+
+
+def _futex(addr, op, val, timeout_s=None):
+    global _libc
+    if _libc is None:
+        _libc = ctypes.CDLL(None, use_errno=True)
+        _libc.syscall.restype = ctypes.c_long
+    ts = None
+    if timeout_s is not None:
+        ts = ctypes.byref(_Timespec(int(timeout_s), int((timeout_s % 1.0) * 1e9)))
+    return _libc.syscall(_SYS_FUTEX, ctypes.c_void_p(addr), ctypes.c_int(op), ctypes.c_int(val), ts, None, ctypes.c_int(0))
+
+
+def futex_wait_change(words, index, seen, timeout_s=0.05, spin=50):
+    """Waits until words[index] != seen or the timeout has passed once (a short spin, then ONE kernel wait on the word: the
+    caller re-checks and calls again -- spurious wake-ups and time-outs look the same to it)."""
+    for _ in range(spin):
+        if words[index] != seen:
+            return
+    _futex(words.ctypes.data + 4 * index, _FUTEX_WAIT, int(seen), timeout_s)
+
+
+def futex_wake_all(words, index):
+    _futex(words.ctypes.data + 4 * index, _FUTEX_WAKE, 0x7fffffff)
+
+
+GO, NOTIFY = 0, 4                                       # int32 word indices into the control page (= int64 slots 0 and 2; slot 1 is the command)
 
 
 def worker_main(spec_path):
@@ -321,14 +376,18 @@ def worker_main(spec_path):
     envs = [build_env(e) for e in spec["envs"]]
     sl = HostSlice(envs, spec["lo"], spec["adapter"], arr, spec["action_map"], spec["env_seed"], spec["limit"], spec["on_end"],
                    spec["first_env"])
+    words = control_words(mm)
     w, parent = spec["worker"], spec["parent_pid"]
     seq = 0
     ctrl[8 + w] = -1                                       # attached (the parent waits for every worker's -1 -> then unlinks the file)
-    alive = lambda: os.getppid() == parent                 # noqa: E731  (an orphaned worker exits instead of spinning for ever)
     try:
         while True:
-            seq += 1
-            wait_for(ctrl, 0, seq, spin=spec.get("spin", 20000), alive=alive)
+            futex_wait_change(words, GO, seq, timeout_s=0.25, spin=spec.get("spin", 50))
+            if words[GO] == seq:
+                if os.getppid() != parent:                 # an orphaned worker exits instead of waiting for ever
+                    break
+                continue
+            seq = int(words[GO])
             cmd = int(ctrl[1])
             if cmd == CMD_EXIT:
                 break
@@ -337,8 +396,8 @@ def worker_main(spec_path):
             else:
                 sl.step_all()
             ctrl[8 + w] = seq
-    except RuntimeError:
-        pass
+            words[NOTIFY] += 1                             # (racy across workers on purpose: any change rings the bell)
+            futex_wake_all(words, NOTIFY)
     finally:
         sl.close()
     return 0

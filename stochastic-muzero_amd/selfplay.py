@@ -343,14 +343,14 @@ def _play_step(env, heads, mcts, chunk, t, temperature, train=True):
     _record_phase(env, chunk, t, _search_phase(env, heads, mcts, chunk, t, temperature, train))
 
 
-def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True):
-    """Plays `steps` env steps of all env.B environments; returns the TrajectoryChunk (device resident).
-    Everything is enqueued asynchronously on the current stream; the caller synchronises."""
+def play_games(env, heads, mcts, temperature, steps, chunk=None, train=True, t0=0):
+    """Plays `steps` env steps of all env.B environments into rows [t0, t0 + steps) of the TrajectoryChunk (device resident)
+    and returns it.  Everything is enqueued asynchronously on the current stream; the caller synchronises."""
     if chunk is None:
-        chunk = TrajectoryChunk(steps, env.B, env.obs_dim, env.num_actions, env.device)
-    assert chunk.T >= steps and chunk.B == env.B
+        chunk = TrajectoryChunk(t0 + steps, env.B, env.obs_dim, env.num_actions, env.device)
+    assert chunk.T >= t0 + steps and chunk.B == env.B
     _sync_active(env, mcts)
-    for t in range(steps):
+    for t in range(t0, t0 + steps):
         _play_step(env, heads, mcts, chunk, t, temperature, train)
     if getattr(chunk, "owed_obs", None) is not None:
         chunk.flush_obs()
@@ -372,7 +372,7 @@ class StreamGroup:
         self.chunk = TrajectoryChunk(steps, env.B, env.obs_dim, env.num_actions, env.device)
 
 
-def play_games_grouped(groups, temperature, steps, train=True):
+def play_games_grouped(groups, temperature, steps, train=True, t0=0):
     """play_games for several StreamGroups concurrently: step t of every group is enqueued before step t+1 of any,
     each on its group's stream; the caller's stream waits for all of them at the end.  Per group it is play_games' own
     step (_play_step), so the chunks equal the ungrouped ones env by env."""
@@ -380,7 +380,7 @@ def play_games_grouped(groups, temperature, steps, train=True):
     cur = torch.cuda.current_stream(dev)
     for g in groups:
         g.stream.wait_stream(cur)
-        assert g.chunk.T >= steps
+        assert g.chunk.T >= t0 + steps
         _sync_active(g.env, g.mcts)
     # software pipeline: the search of step t + 1 of a group is enqueued right after its step t, BEFORE the host turns to the
     # next group -- while the host waits for / steps the envs of one group (host envs: envs.HostVecEnv.step_end), the GPU runs
@@ -388,12 +388,12 @@ def play_games_grouped(groups, temperature, steps, train=True):
     pend = []
     for g in groups:
         with torch.cuda.stream(g.stream):
-            pend.append(_search_phase(g.env, g.heads, g.mcts, g.chunk, 0, temperature, train) if steps > 0 else None)
-    for t in range(steps):
+            pend.append(_search_phase(g.env, g.heads, g.mcts, g.chunk, t0, temperature, train) if steps > 0 else None)
+    for t in range(t0, t0 + steps):
         for k, g in enumerate(groups):
             with torch.cuda.stream(g.stream):
                 _record_phase(g.env, g.chunk, t, pend[k])
-                if t + 1 < steps:
+                if t + 1 < t0 + steps:
                     pend[k] = _search_phase(g.env, g.heads, g.mcts, g.chunk, t + 1, temperature, train)
     for g in groups:
         if getattr(g.chunk, "owed_obs", None) is not None:
@@ -516,8 +516,23 @@ def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None
     device; records="lists": chunk_to_games' per-step Python lists (the checker; ~100x slower at 4096 envs x 64 steps)."""
     heads = model.heads(env.device)
     env.reset()
-    chunk = play_games(env, heads, mcts, temperature, steps)
-    data, frames = chunk.data, chunk.obs
+    if hasattr(gather, "start"):
+        # gather.TrajectoryGather: the chunk is played in slices and every finished slice's rows travel to the learner on a side
+        # stream while the next slice is searched; only the last slice's transfer is exposed
+        n = max(1, min(gather.slices, steps))
+        cuts = [steps * k // n for k in range(n + 1)]
+        chunk = TrajectoryChunk(steps, env.B, env.obs_dim, env.num_actions, env.device)
+        for k in range(n):
+            play_games(env, heads, mcts, temperature, cuts[k + 1] - cuts[k], chunk=chunk, t0=cuts[k])
+            gather.start(chunk.data[cuts[k]:cuts[k + 1]], None if chunk.obs is None else chunk.obs[cuts[k]:cuts[k + 1]])
+        got = gather.finish()
+        if got is None:
+            return None, None
+        data, frames = got
+        gather = None
+    else:
+        chunk = play_games(env, heads, mcts, temperature, steps)
+        data, frames = chunk.data, chunk.obs
     if gather is not None:
         parts = gather(data)
         fparts = gather(frames) if frames is not None else None      # image observations: a float32 message of their own

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--sims", type=int, default=8)
     ap.add_argument("--limit", type=int, default=4)
+    ap.add_argument("--overlap", type=int, default=0, help="slices of gather.TrajectoryGather (0: one gather_to_learner call)")
     a = ap.parse_args()
     rank, world, local = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
     n_dev = torch.cuda.device_count()
@@ -51,15 +52,28 @@ def main():
     m = mcts_mod.BatchedMCTS(hi - lo, num_simulations=a.sims, discount=0.999, root_exploration_fraction=0.1, device=dev.index,
                              use_graph=False)
     m.seed(np.arange(lo, hi, dtype=np.uint64))
-    chunk = sp.play_games(env, heads, m, 1.0, a.steps)
-    parts = g.gather_to_learner(chunk.data)
+    if a.overlap:
+        # the overlapped exchange: the chunk is played in slices, every finished slice's rows travel (compact wire format) while
+        # the next slice is searched; the learner reassembles the chunk
+        tg = g.TrajectoryGather(env.obs_dim, env.num_actions, slices=a.overlap)
+        k = min(a.overlap, a.steps)
+        cuts = [a.steps * i // k for i in range(k + 1)]
+        chunk = sp.TrajectoryChunk(a.steps, env.B, env.obs_dim, env.num_actions, env.device)
+        for i in range(k):
+            sp.play_games(env, heads, m, 1.0, cuts[i + 1] - cuts[i], chunk=chunk, t0=cuts[i])
+            tg.start(chunk.data[cuts[i]:cuts[i + 1]])
+        got = tg.finish()
+        parts = None if got is None else [got[0]]
+    else:
+        chunk = sp.play_games(env, heads, m, 1.0, a.steps)
+        parts = g.gather_to_learner(chunk.data)
     torch.cuda.synchronize(dev)
     ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(ones)                                           # the rank count as the collective itself sees it
     single = [None] * world
     dist.all_gather_object(single, m._single is True)
     if rank == 0:
-        assert parts is not None and len(parts) == world
+        assert parts is not None and len(parts) == (1 if a.overlap else world)
         torch.save(dict(data=torch.cat([p.cpu() for p in parts], dim=1), backend=backend, world=world,
                         ranks_seen_by_collective=int(ones.item()), single_launch=single,
                         weights=heads.weights.cpu()), os.path.join(a.out, "gathered.pt"))

@@ -77,9 +77,79 @@ def test_shard_ranges_cover_every_env_once():
     for total in (1, 7, 4096, 32768, 1000):
         for world in (1, 2, 3, 4, 8):
             seen = []
+            if total < world:          # no empty shards -- an engine for zero trees cannot be built
+                with pytest.raises(ValueError):
+                    g.shard_range(total, 0, world)
+                continue
+            sizes = []
             for r in range(world):
                 lo, hi = g.shard_range(total, r, world)
-                assert 0 <= lo <= hi <= total
+                assert 0 <= lo < hi <= total
                 seen += list(range(lo, hi))
-            assert seen == list(range(total))
+                sizes.append(hi - lo)
+            assert seen == list(range(total)) and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        g.shard_range(8, 8, 8)
     assert g.gather_to_learner(torch.zeros(2, 2))[0].shape == (2, 2)     # no process group: identity
+
+
+def _record(T, B, o, A, seed):
+    r = np.random.RandomState(seed)
+    d = np.zeros((T, B, o + 3 * A + 3))
+    d[..., :o] = r.randn(T, B, o).astype(np.float32)
+    d[..., o] = r.randn(T, B)                                   # rewards: full float64 values
+    d[..., o + 1] = r.randint(0, 4, (T, B))
+    d[..., o + 2:o + 2 + A] = r.rand(T, B, A)
+    d[..., o + 2 + A:o + 2 + 2 * A] = np.eye(A)[r.randint(0, A, (T, B))]
+    d[..., o + 2 + 2 * A] = (10 * r.randn(T, B)).astype(np.float32)
+    d[..., o + 3 + 2 * A:] = r.rand(T, B, A)
+    return torch.from_numpy(d)
+
+
+def _tg_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import stochastic_muzero_amd  # noqa: F401
+    g = import_module("stochastic-muzero_amd.gather")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, total, o, A = 9, 11, 4, 3
+    full = _record(T, total, o, A, 0)
+    frames = torch.arange(T * total * 6, dtype=torch.float32).reshape(T, total, 6)
+    lo, hi = g.shard_range(total, rank, world)
+    for compact in (True, False):
+        tg = g.TrajectoryGather(o, A, slices=4, compact=compact)
+        cuts = [T * k // 4 for k in range(5)]
+        for k in range(4):                                      # slice after slice, as self_play_iteration plays them
+            tg.start(full[cuts[k]:cuts[k + 1], lo:hi], frames[cuts[k]:cuts[k + 1], lo:hi])
+        got = tg.finish()
+        if rank == 0:
+            assert torch.equal(got[0], full) and torch.equal(got[1], frames), compact
+        else:
+            assert got is None
+    if rank == 0:
+        torch.save(torch.ones(1), os.path.join(out_dir, "ok.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sliced_compact_trajectory_gather_world_size_2(tmp_path):
+    """gather.TrajectoryGather: slices of a chunk sent one after the other in the compact wire format (float32 for what is
+    float32, float64 for rewards / policies / child visits) reassemble to the chunk bit for bit on the learner."""
+    port = 27500 + (os.getpid() % 2000)
+    mp.spawn(_tg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "ok.pt"))
+
+
+def test_compact_wire_format_is_lossless_and_smaller():
+    sys.path.insert(0, ROOT)
+    import stochastic_muzero_amd  # noqa: F401
+    g = import_module("stochastic-muzero_amd.gather")
+    for o, A in ((4, 2), (8, 4), (0, 2)):
+        d = _record(6, 5, o, A, o + A)
+        n, w = g.pack_records(d, o, A)
+        assert n.dtype == torch.float32 and w.dtype == torch.float64
+        assert torch.equal(g.unpack_records(n, w, o, A), d)
+        assert n.numel() * 4 + w.numel() * 8 < d.numel() * 8
+    n, w = g.pack_records(_record(1, 1, 4, 2, 0), 4, 2)
+    assert n.numel() * 4 + w.numel() * 8 == 72                   # CartPole: 72 bytes per env step instead of 104

@@ -29,7 +29,9 @@ def _ref_scale(x):
 
 def _within_the_floor(out, exact64):
     steps = gu.decode_steps(out.cpu().numpy(), exact64.cpu().numpy())
-    assert steps.max() <= gu.DECODE_FLOOR_STEPS, f"{steps.max():.3f} stairs from the exact value of the formula"
+    # random logits: the bound of the formula's own float32 roundings (on the reference's recorded logits the device is held to
+    # the reference's own observed distance, tests/test_gpu_decode_floor.py)
+    assert steps.max() <= gu.DECODE_BOUND_STEPS, f"{steps.max():.3f} stairs from the exact value of the formula"
 
 
 def _s():
@@ -48,10 +50,10 @@ def test_support_decode(B, S):
     logits = (torch.randn(B, S, generator=g) * 3).cuda()
     out = torch.empty(B, device="cuda")
     smz._lib.check(lib.smz_support_decode(_p(logits), S, _p(out), B, _s()))
-    # the float32 formula is a staircase in the support expectation (golden_util.DECODE_STEP); the reference's own float32
-    # result is up to 0.752 stairs from the exact value (tests/test_decode_floor.py): the device must be no further
+    # the float32 formula is a staircase in the support expectation (golden_util.DECODE_STEP): any float32 evaluation is within
+    # about one stair of the exact value; the reference's own float32 results were seen up to 0.752 stairs away
     _within_the_floor(out, _ref_decode(logits.double()))
-    assert gu.decode_steps(out.cpu().numpy(), _ref_decode(logits).cpu().numpy()).max() <= 2 * gu.DECODE_FLOOR_STEPS   # torch-ROCm float32
+    assert gu.decode_steps(out.cpu().numpy(), _ref_decode(logits).cpu().numpy()).max() <= 2 * gu.DECODE_BOUND_STEPS   # torch-ROCm float32
 
 
 @pytest.mark.parametrize("B,A", [(4096, 2), (513, 4), (100, 18)])

@@ -33,11 +33,14 @@ def _env():
     return e
 
 
-def test_two_ranks_reproduce_the_single_rank_self_play(tmp_path):
-    total, steps, sims, limit = 96, 6, 8, 4
+@pytest.mark.parametrize("overlap", [0, 3])
+def test_two_ranks_reproduce_the_single_rank_self_play(tmp_path, overlap):
+    """overlap = 3: gather.TrajectoryGather -- the chunk played in 3 slices, each slice's rows sent in the compact wire format
+    while the next slice is searched (VERDICT r3 #7) -- must deliver the very same chunk.  97 envs: unequal shards."""
+    total, steps, sims, limit = 96 + (1 if overlap else 0), 6, 8, 4
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "tests", "dist_selfplay_worker.py"), "--out", str(tmp_path),
-           "--total", str(total), "--steps", str(steps), "--sims", str(sims), "--limit", str(limit)]
+           "--total", str(total), "--steps", str(steps), "--sims", str(sims), "--limit", str(limit), "--overlap", str(overlap)]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     got = torch.load(os.path.join(tmp_path, "gathered.pt"))
@@ -67,9 +70,10 @@ def test_c5_shape_eight_ranks_of_4096_envs_x_100_simulations_equal_one_32768_env
     a single-process run of all 32 768 envs (step-wise kernels there: 32 768 trees are beyond the single launch's range, and
     the two paths are bit-identical).  shard_range at world 8, the 8-way concatenation order, 8 engines on one device."""
     total, steps, sims, limit, world = 32768, 4, 100, 3, 8
+    # (round 4: through the overlapped, sliced exchange -- gather.TrajectoryGather, 2 slices of 2 steps)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "tests", "dist_selfplay_worker.py"), "--out", str(tmp_path),
-           "--total", str(total), "--steps", str(steps), "--sims", str(sims), "--limit", str(limit)]
+           "--total", str(total), "--steps", str(steps), "--sims", str(sims), "--limit", str(limit), "--overlap", "2"]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     got = torch.load(os.path.join(tmp_path, "gathered.pt"))
@@ -103,6 +107,7 @@ def test_bench_starts_its_own_ranks():
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and len(out["per_rank_simulations_per_s"]) == 2
     assert out["value"] > 0 and out["scaling"] == "weak" and out["timing"]["blocks"] >= 1
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
+    assert out["timing"]["gather_overlap"]["slices"] == 4 and out["timing"]["gather_ms_median"] > 0
     # a launcher / flag mismatch is an error, not a silent single-GPU run
     bad = dict(_env(), WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=bad, capture_output=True, text=True,

@@ -129,7 +129,7 @@ def test_frame_adapter_taps_are_the_pixels_the_resize_reads():
     class E:
         def render(self):
             return frame
-    taps = he.FrameAdapter((H, W), (9, 11), upload="taps").observe(E(), None).reshape(18, 22, 3)
+    taps = he.FrameAdapter((H, W), (9, 11), upload="taps").observe(E(), None).reshape(18, 22, 3).copy()
     iy, ix = he.tap_index(H, 9), he.tap_index(W, 11)
     for oy in range(9):
         for ox in range(11):
@@ -138,3 +138,28 @@ def test_frame_adapter_taps_are_the_pixels_the_resize_reads():
                     assert np.array_equal(taps[2 * oy + r, 2 * ox + q], frame[iy[2 * oy + r], ix[2 * ox + q]])
     full = he.FrameAdapter((H, W), (9, 11), upload="frames").observe(E(), None)
     assert np.array_equal(full.reshape(H, W, 3), frame)
+    assert np.array_equal(taps, frame[np.ix_(iy, ix)])          # the C gather (libsmzhost.so) == numpy's fancy indexing
+
+
+def test_host_library_exports_what_its_header_declares():
+    import ctypes
+    import re
+    header = open(os.path.join(ROOT, "include", "smz_host.h")).read()
+    names = re.findall(r"^(?:int|void)\s+(smzh_\w+)\s*\(", header, re.M)
+    assert "smzh_gather_taps_u8" in names and "smzh_abi_version" in names
+    lib = ctypes.CDLL(os.path.join(ROOT, "stochastic-muzero_amd", "libsmzhost.so"))
+    for n in names:
+        getattr(lib, n)
+    assert lib.smzh_abi_version() == 1
+    lib.smzh_gather_taps_u8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    out = np.zeros(12, np.uint8)
+    bad = np.array([0, 5], np.int32); ok = np.array([0, 1], np.int32)
+    fr = np.zeros((2, 2, 3), np.uint8)
+    assert lib.smzh_gather_taps_u8(fr.ctypes.data, 2, 2, bad.ctypes.data, 2, ok.ctypes.data, 2, out.ctypes.data) == -1
+    # the last pixel of the frame and of every row (the 4-byte moves must not run past either), guard bytes around the output
+    fr = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    iy, ix = np.array([4, 4, 0, 3], np.int32), np.array([6, 6, 0, 6, 5], np.int32)
+    out = np.full(4 * 5 * 3 + 8, 0xEE, np.uint8)
+    assert lib.smzh_gather_taps_u8(fr.ctypes.data, 5, 7, iy.ctypes.data, 4, ix.ctypes.data, 5, out[4:].ctypes.data) == 0
+    assert np.array_equal(out[4:-4].reshape(4, 5, 3), fr[np.ix_(iy, ix)]) and (out[:4] == 0xEE).all() and (out[-4:] == 0xEE).all()
