@@ -371,7 +371,10 @@ def main():
         # worker processes PER ENV GROUP: idle workers sleep in the kernel (futex), so while one group's envs step, the other
         # group's workers cost nothing and every group may use all usable cores; 3 x the cores hides the wake-up latencies
         # (measured on the 16-CPU-quota bench box: 14 workers 76 M, 16 113 M, 24 135 M simulations/s with one group)
-        host_workers = args.host_workers if args.host_workers is not None else min(64, max(1, 3 * host_cores()))
+        # (rendering envs keep a core busy for ~130 us per step: there 1.5 x the cores is the measured optimum -- 7.5 M against 5.9 M
+        #  simulations/s with 3 x on the 16-CPU-quota box; 4 us CartPole steps want the 3 x: 182-200 M against 161 M)
+        per_core = 1.5 if wl["env"] == "image" else 3
+        host_workers = args.host_workers if args.host_workers is not None else min(64, max(1, int(per_core * host_cores())))
     assert B % G == 0, "--groups must divide the env count"
     Bg = B // G
     groups = []
