@@ -176,7 +176,7 @@ def cpu_baseline_mlp(wl, weights_path, seconds_target=15.0):
     single = sims / dt
     sims, dt = run(2 * cores, steps, cores)                    # calibration pass (also warms the thread pool)
     rate = sims / dt
-    n_env = int(max(cores, min(64 * cores, rate * seconds_target / (steps * wl["sims"]))))
+    n_env = int(max(cores, rate * seconds_target / (steps * wl["sims"])))
     n_env -= n_env % cores
     sims, dt = run(n_env, steps, cores)
     what = "CartPole" if cart else f"N(0,1)-observation (obs {wl['obs']}, {wl['A']} actions)"
