@@ -284,11 +284,11 @@ def main():
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SMZ_STREAM_GROUPS", "0")),
                     help="independent env groups per GPU, each on its own HIP stream (0 = 2 groups from 262 144 envs on -- "
                          "one group's tree kernel overlaps the other's network kernel: +6..14 % measured -- else 1)")
-    ap.add_argument("--min-timed-seconds", type=float, default=8.0,
-                    help="repeat the K-step block until this much is timed (default 8 s: ~900 blocks of the headline workload, so "
+    ap.add_argument("--min-timed-seconds", type=float, default=10.0,
+                    help="repeat the K-step block until this much is timed (default 10 s: ~1400 blocks of the headline workload, so "
                          "that the timed region is the larger part of the command's run time)")
     ap.add_argument("--max-blocks", type=int, default=4000)
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=6.0, help="wall-clock budget of the cpu_baseline sample (all host cores)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0, help="wall-clock budget of the cpu_baseline sample (all host cores)")
     ap.add_argument("--end-to-end", action="store_true",
                     help="time selfplay.self_play_iteration, the function learning_cycle calls (self_play.py:245-271): K env steps, the "
                          "chunk's transfer to the host, Game records (selfplay.chunk_to_records) and replay_buffer.save_game of every "
