@@ -200,7 +200,14 @@ extern __shared__ float4 smz_vsearch_lds4[];
 // AEQ: the action count equals its bucket MAXA -- a compile-time constant then for everything inlined below (the per-action
 // arrays of the root level stay in registers instead of scratch memory)
 template <int MAXA, bool AEQ>
-__global__ void __launch_bounds__(kVW *kWave) k_search_vision(Params Pin, smz_vision_desc d, const float *__restrict__ weights,
+// -DSMZ_VISION_WPE=2 (A/B builds only, tools/vision_wpe_ab.sh): register-allocate for TWO wavefronts per SIMD (256 registers a
+// lane instead of 512; the tower weights no longer fit and spill) -- the measurement behind DESIGN 9.3's occupancy argument
+#ifdef SMZ_VISION_WPE
+#define SMZ_VISION_OCC __attribute__((amdgpu_waves_per_eu(SMZ_VISION_WPE, SMZ_VISION_WPE)))
+#else
+#define SMZ_VISION_OCC
+#endif
+__global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Params Pin, smz_vision_desc d, const float *__restrict__ weights,
                                                               const float *__restrict__ hidden0, const float *__restrict__ policy0,
                                                               int train, ActOut act) {
     constexpr int KS = 2, VT = 1;
