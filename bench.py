@@ -427,10 +427,18 @@ def main():
         parts = [getattr(c, name)[t0:t1] for c in chunks]
         return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
+    gather_mode = {"kind": "overlapped"}
+
     def play_and_gather(n):
         """n env steps of every group; with N > 1 in slices, each slice's rows handed to the overlapped gather."""
         if tg is None:
             return sp.play_games_grouped(groups, args.temperature, n)
+        if gather_mode["kind"] == "plain":         # (fallback, see the warm-up below) whole chunk, one synchronous grouped send / recv
+            chunks = sp.play_games_grouped(groups, args.temperature, n)
+            gather_mod.gather_to_learner(rows(chunks, "data", 0, n))
+            if chunks[0].obs is not None:
+                gather_mod.gather_to_learner(rows(chunks, "obs", 0, n))
+            return chunks
         k = max(1, min(tg.slices, n))
         cuts = [n * i // k for i in range(k + 1)]
         for i in range(k):
@@ -482,7 +490,16 @@ def main():
     gc.freeze()
     gc.disable()
     # W untimed warm-up steps (with N > 1 the first grouped send / recv builds the RCCL communicators here, outside the timed region)
-    chunks = play_and_gather(max(1, args.warmup) if world > 1 else args.warmup)
+    try:
+        chunks = play_and_gather(max(1, args.warmup) if world > 1 else args.warmup)
+        torch.cuda.synchronize(dev)
+    except Exception as e:                         # the overlapped exchange has never met real RCCL (no multi-GPU box to build on):
+        if tg is None:                             # if its first use fails HERE, outside the timed region, fall back to the plain gather
+            raise
+        print(f"bench.py: overlapped trajectory gather failed at warm-up ({type(e).__name__}: {e}); using the plain gather", file=sys.stderr)
+        gather_mode.update(kind="plain", error=f"{type(e).__name__}: {e}")
+        tg._pending = []
+        chunks = play_and_gather(max(1, args.warmup))
     first = timed_block()                                      # block 1 (timed like the others; also sizes R)
     R = int(min(args.max_blocks, max(1, np.ceil(args.min_timed_seconds / max(first, 1e-6)))))
     blocks = [first] + [timed_block() for _ in range(R - 1)]
@@ -506,8 +523,11 @@ def main():
         for _ in range(5):
             barrier()
             t0 = time.perf_counter()
-            tg.start(rows(chunks, "data", 0, args.steps), rows(chunks, "obs", 0, args.steps) if chunks[0].obs is not None else None)
-            tg.finish()
+            if gather_mode["kind"] == "plain":
+                gather_mod.gather_to_learner(rows(chunks, "data", 0, args.steps))
+            else:
+                tg.start(rows(chunks, "data", 0, args.steps), rows(chunks, "obs", 0, args.steps) if chunks[0].obs is not None else None)
+                tg.finish()
             barrier()
             gts.append(max_over_ranks(time.perf_counter() - t0))
         gather_ms = 1e3 * float(np.median(gts))
@@ -583,7 +603,7 @@ def main():
                         for c in chunks)
         out["timing"]["gather_bytes_per_rank"] = int(rec_bytes + sum(c.obs[:args.steps].numel() * 4 for c in chunks if c.obs is not None))
         out["timing"]["gather_overlap"] = {
-            "slices": tg.slices, "exposed_ms_median": float(np.median(exposed)) if exposed else None,
+            "mode": gather_mode, "slices": tg.slices, "exposed_ms_median": float(np.median(exposed)) if exposed else None,
             "how": "the K-step block is played in `slices` parts; each finished part's rows travel to rank 0 on a side stream "
                    "(float32 for observations / flags / actions / root values, float64 for rewards / policies / child visits) while "
                    "the next part is searched; exposed = device time between the end of the last search and the end of the exchange "

@@ -437,6 +437,14 @@ int vision_check(const smz_vision_desc *d, const void *w) {
 
 }  // namespace
 
+extern thread_local char smz_g_err[512];     // the library's last-error text (smz_kernels.hip)
+namespace {
+int verr(int code, const char *text) {
+    snprintf(smz_g_err, sizeof(smz_g_err), "%s", text);
+    return code;
+}
+}  // namespace
+
 extern "C" {
 
 int smz_vision_layout(smz_vision_desc *d) {
@@ -447,9 +455,11 @@ int smz_vision_layout(smz_vision_desc *d) {
 
 int smz_vision_initial_record(const smz_vision_desc *d, const float *weights_dev, const float *frames_dev, float *frames_copy_dev,
                               float *hidden_out_dev, float *policy_out_dev, int B, smz_stream stream) {
-    if (vision_check(d, weights_dev) != SMZ_OK || !frames_dev || !hidden_out_dev || !policy_out_dev || B < 1) return SMZ_ERR_INVALID;
+    if (vision_check(d, weights_dev) != SMZ_OK || !frames_dev || !hidden_out_dev || !policy_out_dev || B < 1)
+        return verr(SMZ_ERR_INVALID, "smz_vision_initial: bad argument (descriptor / weights / null pointer / B < 1)");
     // (8-byte loads of pixel pairs; 16-byte pieces of the frame copy; a frame is 7203 of them)
-    if (((uintptr_t)frames_dev & 7) || (frames_copy_dev && (((uintptr_t)frames_dev | (uintptr_t)frames_copy_dev) & 15))) return SMZ_ERR_INVALID;
+    if (((uintptr_t)frames_dev & 7) || (frames_copy_dev && (((uintptr_t)frames_dev | (uintptr_t)frames_copy_dev) & 15)))
+        return verr(SMZ_ERR_INVALID, "smz_vision_initial: frames must be 8-byte aligned (16-byte aligned, both pointers, with a record copy)");
     hipLaunchKernelGGL(k_vision_initial, dim3(B), dim3(kRepThreads), 0, (hipStream_t)stream, *d, weights_dev, frames_dev,
                        frames_copy_dev, hidden_out_dev, policy_out_dev);
     return hipGetLastError() == hipSuccess ? SMZ_OK : SMZ_ERR_HIP;

@@ -160,6 +160,9 @@ class TrajectoryGather:
             cur.wait_stream(self._side)
             t1.record(cur)
             self._exposed = (t0, t1)
+            for _, msgs, bufs in pend:             # allocated / filled under the side stream, consumed on the current one
+                for t in list(msgs) + ([b for bl in bufs for b in bl] if bufs else []):
+                    t.record_stream(cur)
         if not learner:
             return None
         rows, frame_rows = [], []
