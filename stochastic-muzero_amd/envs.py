@@ -544,14 +544,16 @@ class HostCartPoleVec:
         self.obs.copy_(self._h_obs, non_blocking=True)
         return self.obs
 
-    def step(self, action):
-        import time
+    def step_begin(self, action):
+        """Enqueues the download of this step's actions (the split lets play_games_grouped search another env group meanwhile)."""
         stream = torch.cuda.current_stream(self.device)
         self._h_action.copy_(action, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(stream)
+        self._pending = torch.cuda.Event()
+        self._pending.record(stream)
+
+    def step_end(self):
         t0 = time.perf_counter()
-        ev.synchronize()                                  # the search of this step has to finish before the env can move
+        self._pending.synchronize()                       # the search of this step has to finish before the env can move
         self.transfer_seconds += time.perf_counter() - t0
         P = lambda t: C.c_void_p(t.data_ptr())
         _lib.check(self.lib.smz_host_cartpole_step(P(self._state), P(self._h_action), P(self._h_obs), P(self._h_reward),
@@ -560,3 +562,7 @@ class HostCartPoleVec:
         self.reward.copy_(self._h_reward, non_blocking=True)
         self.terminated.copy_(self._h_flag, non_blocking=True)
         return self.obs, self.reward, self.terminated
+
+    def step(self, action):
+        self.step_begin(action)
+        return self.step_end()

@@ -12,6 +12,7 @@ python bench.py $S --steps 8 --warmup 2 --workload vision_resnet_1024x50 2>/dev/
 python bench.py $S --rng philox --no-cpu-baseline 2>/dev/null > $O/${TAG}_bench_philox.json
 python bench.py $S --end-to-end --no-cpu-baseline 2>/dev/null > $O/${TAG}_bench_end_to_end.json
 python bench.py $S --steps 8 --warmup 2 --host-env native --no-cpu-baseline --no-roofline 2>/dev/null > $O/${TAG}_bench_hostenv_native.json
+python bench.py $S --steps 8 --warmup 2 --host-env native --groups 2 --no-cpu-baseline --no-roofline 2>/dev/null > $O/${TAG}_bench_hostenv_native_2groups.json
 python bench.py $S --host-env python --no-cpu-baseline --no-roofline 2>/dev/null > $O/${TAG}_bench_hostenv_python.json
 python bench.py $S --host-env python --host-workers 0 --groups 1 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null > $O/${TAG}_bench_hostenv_python_serial.json
 python bench.py $S --workload vision_resnet_1024x50 --steps 8 --warmup 2 --host-env python --no-cpu-baseline --no-roofline 2>/dev/null > $O/${TAG}_bench_vision_hostenv.json
