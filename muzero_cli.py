@@ -67,10 +67,14 @@ def make_env(name, num_envs, device, seed, limit=0, on_end="continue"):
     except ImportError:
         raise Exception(f"environment {name!r} needs gymnasium, which is not installed here; built-in: CartPole-v1 "
                         "(host environments go through stochastic-muzero_amd.envs.HostVecEnv)")
-    made = [gym.make(name) for _ in range(num_envs)]
-    obs_dim = int(np_prod(made[0].observation_space.shape))
-    return envs.HostVecEnv(made, obs_dim, int(made[0].action_space.n), device, env_seed=seed, limit=limit,
-                           on_end="reset" if on_end == "continue" else on_end)
+    import functools
+    import os
+    probe = gym.make(name)                                 # the spaces; the envs themselves are built inside the worker processes
+    obs_dim, n_actions = int(np_prod(probe.observation_space.shape)), int(probe.action_space.n)
+    probe.close()
+    workers = int(os.environ.get("SMZ_HOST_WORKERS", min(64, 3 * len(os.sched_getaffinity(0))))) if num_envs >= 64 else 0
+    return envs.HostVecEnv([functools.partial(gym.make, name) for _ in range(num_envs)], obs_dim, n_actions, device, env_seed=seed,
+                           limit=limit, on_end="reset" if on_end == "continue" else on_end, workers=workers)
 
 
 def np_prod(shape):
