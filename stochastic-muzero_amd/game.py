@@ -173,8 +173,8 @@ class ArrayGameRecord(GameRecord):
     arrays when they were computed for the same td_steps and the game's lists have not been modified; otherwise by
     GameRecord's own loops over the lists."""
 
-    def __init__(self, src, e, t0, t1, done):
-        self._src, self._e, self._t0, self._t1 = src, e, t0, t1
+    def __init__(self, src, e, t0, t1, done, top=None):
+        self._src, self._e, self._t0, self._t1, self._top = src, e, t0, t1, top      # top: max priority of the window (or None)
         self.done, self.reanalyzed, self.env = done, False, None
 
     def __getattr__(self, name):                      # only reached for attributes not set yet
@@ -209,7 +209,11 @@ class ArrayGameRecord(GameRecord):
 
     def _pristine(self, *names):
         d = self.__dict__
-        return all(n not in d or (isinstance(d[n], _Column) and d[n]._list is None) for n in names)
+        for n in names:
+            c = d.get(n)
+            if c is not None and not (isinstance(c, _Column) and c._list is None):
+                return False
+        return True
 
     @property
     def game_length(self):
@@ -218,11 +222,11 @@ class ArrayGameRecord(GameRecord):
         return self._t1 - self._t0
 
     def make_priority(self, td_steps):
-        src = self._src
+        src, d = self._src, self.__dict__
         if src.prio is not None and td_steps == src.td_steps and td_steps >= 1 and self._t1 > self._t0 and \
-                self.priority_scale == src.priority_scale and self._pristine("rewards", "root_values"):
+                "priority_scale" not in d and self._pristine("rewards", "root_values"):
             pos = src.prio[self._e, self._t0:self._t1]
-            return pos, np.max(pos)
+            return pos, (np.max(pos) if self._top is None else self._top)
         return super().make_priority(td_steps)
 
     def make_target(self, state_index, num_unroll, td_steps):

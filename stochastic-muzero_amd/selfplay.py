@@ -261,7 +261,18 @@ def records_from_host_copy(rec, game_end, obs_dim, A, discount, priority_scale=1
         game_end[odd] = -1
     e, t0, t1, last = _segments(flags, game_end, keep_partial)
     done = (last == 1) & ((t1 - t0) != limit_of_game_play)                      # game.py:270-271
-    games = [ArrayGameRecord(src, *w) for w in zip(e.tolist(), t0.tolist(), t1.tolist(), done.tolist())]
+    if src.prio is not None and len(e):
+        # every game's largest priority (make_priority's second result) in one pass: maxima over the flat [B * T] ranges
+        # [start, end) of the windows -- reduceat over the interleaved (start, end) indices, every other result
+        flat = src.prio.reshape(-1)
+        lo, hi = e.astype(np.int64) * T + t0, e.astype(np.int64) * T + t1
+        idx = np.stack([lo, hi], 1).reshape(-1)
+        if idx[-1] >= flat.size:
+            idx = idx[:-1]
+        tops = [np.float64(v) for v in np.maximum.reduceat(flat, idx)[::2].tolist()]
+    else:
+        tops = [None] * len(e)
+    games = [ArrayGameRecord(src, *w) for w in zip(e.tolist(), t0.tolist(), t1.tolist(), done.tolist(), tops)]
     if odd.any():                                                              # the rare envs: the general loop, merged in env order
         merged, k, envs = [], 0, e.tolist()
         for env in np.nonzero(odd)[0].tolist():
