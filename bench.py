@@ -300,6 +300,9 @@ def main():
                     help="cartpole workloads: step the envs on the HOST -- the PCIe-inclusive rate of the boundary's "
                          "host-buffer variant: 'python' = envs.HostVecEnv over Python CartPoles (measures the Python), 'native' = "
                          "envs.HostCartPoleVec (compiled host step, smz_host_cartpole_step)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="--end-to-end: iterations per timed block through selfplay.self_play_iterations (the search of iteration k + 1 is "
+                         "enqueued before the host builds and stores iteration k's games); 1 = one synchronous self_play_iteration per block")
     ap.add_argument("--host-workers", type=int, default=None,
                     help="--host-env python: env worker processes per env group (default min(64, 3 x usable host cores); "
                          "0 = step the envs serially in this process)")
@@ -470,12 +473,19 @@ def main():
             sink.clear()
             barrier()
             t0 = time.perf_counter()
-            games, _ = sp.self_play_iteration(env, model, mcts, args.temperature, args.steps, replay_buffer=sink,
-                                              gather=tg if world > 1 else None, ignore_termination=True)
+            if args.pipeline > 1:
+                n_games = 0
+                for games, _ in sp.self_play_iterations(env, model, mcts, args.temperature, args.steps, args.pipeline, replay_buffer=sink,
+                                                        gather=tg if world > 1 else None, ignore_termination=True):
+                    n_games += len(games or ())
+            else:
+                games, _ = sp.self_play_iteration(env, model, mcts, args.temperature, args.steps, replay_buffer=sink,
+                                                  gather=tg if world > 1 else None, ignore_termination=True)
+                n_games = len(games or ())
             barrier()
             dt_block = max_over_ranks(time.perf_counter() - t0)
             if rank == 0:
-                e2e_parts.append((len(games), sink.positions))
+                e2e_parts.append((n_games // max(1, args.pipeline), sink.positions // max(1, args.pipeline)))
             return dt_block
 
     # one priming step outside everything: code-object upload, LDS opt-in and allocator warm-up are initialisation, not
@@ -531,7 +541,8 @@ def main():
             barrier()
             gts.append(max_over_ranks(time.perf_counter() - t0))
         gather_ms = 1e3 * float(np.median(gts))
-    sims_total = total * wl["sims"] * args.steps
+    block_steps = args.steps * (args.pipeline if args.end_to_end else 1)      # env steps inside one timed block
+    sims_total = total * wl["sims"] * block_steps
     headline = (args.workload == "cartpole_mlp_4096x50" and B == 4096 and not args.host_env and args.rng == "mt19937"
                 and not args.end_to_end)
     single = getattr(mcts, "_single", None) is True
@@ -562,12 +573,13 @@ def main():
     out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs \u00d7 50 sims" if headline else
                      f"MCTS simulations/sec (whole node), {args.workload} at {B} envs/GPU" + (" (host-resident envs)" if args.host_env else "")
                      + (" (Philox throughput-mode random streams)" if args.rng == "philox" else "")
-                     + (" (END TO END: self_play_iteration = search + transfer + Game records + save_game)" if args.end_to_end else ""),
-           "value": sims_total / dt, "unit": "simulations/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+                     + (" (END TO END: self_play_iteration = search + transfer + Game records + save_game)" if args.end_to_end else "")
+                     + (f" (pipelined: {args.pipeline} iterations per block, the next search enqueued before a chunk's host half)" if args.end_to_end and args.pipeline > 1 else ""),
+           "value": sims_total / dt, "unit": "simulations/s", "n_gpus": world, "steps": block_steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * dt / block_steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32 (tree values, heads) + f64 (pUCT scores, root priors) + i32 (counts)",
            "data": data_note, "config": config,
-           "timing": {"blocks": R, "steps_per_block": args.steps, "block_ms_median": 1e3 * dt,
+           "timing": {"blocks": R, "steps_per_block": block_steps, "block_ms_median": 1e3 * dt,
                       "block_ms_min": 1e3 * float(np.min(blocks)), "block_ms_max": 1e3 * float(np.max(blocks)),
                       "block_ms_p10_p90": [1e3 * float(np.percentile(blocks, 10)), 1e3 * float(np.percentile(blocks, 90))],
                       "timed_region_s": float(np.sum(blocks)),

@@ -229,20 +229,69 @@ def chunk_to_records(chunk_data, obs_dim, A, discount, priority_scale=1, limit_o
     T, B, F = chunk_data.shape
     o = int(obs_dim)
     assert F == o + 3 * A + 3, f"record of {F} floats is not obs_dim {o} + 3 * {A} + 3 (image observations live in chunk.obs: obs_dim 0)"
-    td = 0 if td_steps is None else int(td_steps)
-    _, target, err, game_end = chunk_targets(chunk_data, o, A, discount, td, ignore_termination, after_end, return_game_end=True)
-    # env-major on the device (a game's rows become one contiguous window), then to the host
-    rec = chunk_data.permute(1, 0, 2).contiguous().cpu().numpy()
-    game_end = game_end.t().contiguous().cpu().numpy()
-    if td_steps is not None:
-        target, err = target.t().contiguous().cpu().numpy(), err.t().contiguous().cpu().numpy()
-    else:
-        target = err = None
-    if observations is not None:
-        assert o == 0
-        observations = observations.permute(1, 0, 2).contiguous().to(torch.float32).cpu()
-    return records_from_host_copy(rec, game_end, o, A, discount, priority_scale, limit_of_game_play, ignore_termination,
-                                  keep_partial, after_end, observations, observation_shape, td_steps, target, err)
+    job = RecordsJob(chunk_data, o, A, discount, td_steps, ignore_termination, after_end, observations)
+    return job.finish(priority_scale, limit_of_game_play, keep_partial, observation_shape)
+
+
+_STAGING = {}
+
+
+def _staging(shape, dtype, slot):
+    """Page-locked staging buffers for the transfers of a RecordsJob, two per (shape, dtype): job k + 2 reuses job k's."""
+    key = (tuple(shape), dtype, slot & 1)
+    buf = _STAGING.get(key)
+    if buf is None:
+        buf = _STAGING[key] = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+    return buf
+
+
+class RecordsJob:
+    """chunk_to_records in two halves.  The constructor ENQUEUES the device half on the current stream and returns at once: game
+    ends + n-step targets + priorities (smz_traj_targets_games), the env-major transposes, and asynchronous copies into page-locked
+    staging buffers, closed by an event.  finish() waits for that event only -- not for work enqueued later, e.g. the next
+    iteration's search -- copies the staging buffers into arrays the records own, and builds the ArrayGameRecords.  Between the
+    two a caller can enqueue more GPU work: the host half of iteration k then runs while the GPU searches iteration k + 1
+    (self_play_iterations).  At most two jobs may be open at a time (the staging buffers are double-buffered)."""
+    _count = 0
+
+    def __init__(self, chunk_data, obs_dim, A, discount, td_steps=None, ignore_termination=False, after_end="drop",
+                 observations=None):
+        self.o, self.A, self.discount, self.td_steps = int(obs_dim), int(A), discount, td_steps
+        self.ignore_termination, self.after_end = ignore_termination, after_end
+        td = 0 if td_steps is None else int(td_steps)
+        _, target, err, game_end = chunk_targets(chunk_data, self.o, A, discount, td, ignore_termination, after_end, return_game_end=True)
+        slot = RecordsJob._count
+        RecordsJob._count += 1
+        # env-major on the device (a game's rows become one contiguous window), then to the host
+        dev = [chunk_data.permute(1, 0, 2).contiguous(), game_end.t().contiguous()]
+        if td_steps is not None:
+            dev += [target.t().contiguous(), err.t().contiguous()]
+        self.big_obs = None
+        if observations is not None:
+            assert self.o == 0
+            frames = observations.permute(1, 0, 2).contiguous().to(torch.float32)
+            if frames.numel() * 4 > (1 << 30):             # gigabytes of frames: no page-locked staging, a plain (synchronous) copy
+                self.big_obs = frames.cpu()
+            else:
+                dev.append(frames)
+        self.has_obs = observations is not None and self.big_obs is None
+        self.host = [_staging(d.shape, d.dtype, slot) for d in dev]
+        for h, d in zip(self.host, dev):
+            h.copy_(d, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(chunk_data.device))
+        self._dev = dev                                    # (kept alive until the copies have run)
+
+    def finish(self, priority_scale=1, limit_of_game_play=float("inf"), keep_partial=True, observation_shape=None):
+        self.event.synchronize()
+        self._dev = None
+        arrays = [h.numpy().copy() for h in self.host[:4 if self.td_steps is not None else 2]]      # the records own these
+        rec, game_end = arrays[0], arrays[1]
+        target, err = (arrays[2], arrays[3]) if self.td_steps is not None else (None, None)
+        observations = self.host[-1].clone() if self.has_obs else self.big_obs
+        return records_from_host_copy(rec, game_end, self.o, self.A, self.discount, priority_scale, limit_of_game_play,
+                                      self.ignore_termination, keep_partial, self.after_end, observations, observation_shape,
+                                      self.td_steps, target, err)
 
 
 def records_from_host_copy(rec, game_end, obs_dim, A, discount, priority_scale=1, limit_of_game_play=float("inf"),
@@ -515,17 +564,8 @@ def play_game(environment=None, model=None, monte_carlo_tree_search=None, temper
     return environment
 
 
-def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None, gather=None, priority_scale=1,
-                        ignore_termination=False, limit_of_game_play=None, td_steps=None, records="array"):
-    """Self-play half of one learning_cycle iteration (self_play.py:245-271): play, gather to the learner rank,
-    hand the games to replay_buffer.save_game, return (games, mean reward) on the learner rank.
-    An env built with on_end="reset" plays game after game inside the chunk (only finished games are handed on, the
-    unfinished tail is dropped); on_end="mask" plays one game per env and stops searching it when it ends.
-
-    records="array" (default): the games are ArrayGameRecord windows into one host copy of the chunk (chunk_to_records), with
-    the value targets and priorities of `td_steps` (default: replay_buffer.td_steps when the buffer has one) computed on the
-    device; records="lists": chunk_to_games' per-step Python lists (the checker; ~100x slower at 4096 envs x 64 steps)."""
-    heads = model.heads(env.device)
+def _play_and_gather(env, heads, mcts, temperature, steps, gather):
+    """env.reset + `steps` env steps (+ the exchange): (records [T][B_all][F], frames | None, chunk) on the learner, None on actors."""
     env.reset()
     if hasattr(gather, "start"):
         # gather.TrajectoryGather: the chunk is played in slices and every finished slice's rows travel to the learner on a side
@@ -537,38 +577,91 @@ def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None
             play_games(env, heads, mcts, temperature, cuts[k + 1] - cuts[k], chunk=chunk, t0=cuts[k])
             gather.start(chunk.data[cuts[k]:cuts[k + 1]], None if chunk.obs is None else chunk.obs[cuts[k]:cuts[k + 1]])
         got = gather.finish()
-        if got is None:
-            return None, None
-        data, frames = got
-        gather = None
-    else:
-        chunk = play_games(env, heads, mcts, temperature, steps)
-        data, frames = chunk.data, chunk.obs
+        return None if got is None else (got[0], got[1], chunk)
+    chunk = play_games(env, heads, mcts, temperature, steps)
+    data, frames = chunk.data, chunk.obs
     if gather is not None:
         parts = gather(data)
         fparts = gather(frames) if frames is not None else None      # image observations: a float32 message of their own
         if parts is None:
-            return None, None
+            return None
         data = torch.cat([p for p in parts], dim=1)
         frames = torch.cat([p for p in fparts], dim=1) if fparts is not None else None
+    return data, frames, chunk
+
+
+def _cut_rules(env, steps, ignore_termination, limit_of_game_play):
     on_end = getattr(env, "on_end", "continue")
     limit = limit_of_game_play if limit_of_game_play is not None else (getattr(env, "limit", 0) or steps)
-    kw = dict(limit_of_game_play=limit, ignore_termination=ignore_termination, keep_partial=on_end != "reset",
-              after_end="new_game" if on_end == "reset" else "drop", observations=frames,
-              observation_shape=getattr(env, "frame", None))
-    if records == "array":
-        if td_steps is None:
-            td_steps = getattr(replay_buffer, "td_steps", None)
-        games = chunk_to_records(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, priority_scale, td_steps=td_steps, **kw)
-    else:
-        torch.cuda.synchronize(env.device)
-        games = chunk_to_games(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, priority_scale, **kw)
+    return dict(limit_of_game_play=limit, ignore_termination=ignore_termination, keep_partial=on_end != "reset",
+                after_end="new_game" if on_end == "reset" else "drop", observation_shape=getattr(env, "frame", None))
+
+
+def _store(games, replay_buffer):
     if replay_buffer is not None:
         save = replay_buffer.save_game
         for g in games:
             save(g)
     rewards = _reward_sums(games)
     return games, (sum(rewards) / len(rewards) if rewards else float("nan"))
+
+
+def self_play_iteration(env, model, mcts, temperature, steps, replay_buffer=None, gather=None, priority_scale=1,
+                        ignore_termination=False, limit_of_game_play=None, td_steps=None, records="array"):
+    """Self-play half of one learning_cycle iteration (self_play.py:245-271): play, gather to the learner rank,
+    hand the games to replay_buffer.save_game, return (games, mean reward) on the learner rank.
+    An env built with on_end="reset" plays game after game inside the chunk (only finished games are handed on, the
+    unfinished tail is dropped); on_end="mask" plays one game per env and stops searching it when it ends.
+
+    records="array" (default): the games are ArrayGameRecord windows into one host copy of the chunk (chunk_to_records), with
+    the value targets and priorities of `td_steps` (default: replay_buffer.td_steps when the buffer has one) computed on the
+    device; records="lists": chunk_to_games' per-step Python lists (the checker; ~100x slower at 4096 envs x 64 steps).
+    `gather`: a callable slab -> parts (gather.gather_to_learner) or a gather.TrajectoryGather (sliced, overlapped exchange)."""
+    got = _play_and_gather(env, model.heads(env.device), mcts, temperature, steps, gather)
+    if got is None:
+        return None, None
+    data, frames, chunk = got
+    kw = _cut_rules(env, steps, ignore_termination, limit_of_game_play)
+    if records == "array":
+        if td_steps is None:
+            td_steps = getattr(replay_buffer, "td_steps", None)
+        games = chunk_to_records(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, priority_scale, td_steps=td_steps,
+                                 observations=frames, **kw)
+    else:
+        torch.cuda.synchronize(env.device)
+        games = chunk_to_games(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, priority_scale, observations=frames, **kw)
+    return _store(games, replay_buffer)
+
+
+def self_play_iterations(env, model, mcts, temperature, steps, iterations, replay_buffer=None, gather=None, priority_scale=1,
+                         ignore_termination=False, limit_of_game_play=None, td_steps=None):
+    """`iterations` x self_play_iteration as a generator of (games, mean reward), PIPELINED: the search of iteration k + 1 is
+    enqueued before the host turns iteration k's chunk into games and stores them, so the host half (transfer, records,
+    save_game: ~8 ms for 64 x 4096) hides behind the ~29 ms of search -- the loop then runs at the search kernel's rate.
+
+    For callers whose networks do not change between iterations -- actor ranks, evaluation, number_of_training_before_self_play
+    = 0: iteration k + 1 is already running with the weights of the moment it was enqueued when iteration k's games are yielded
+    (the reference's Ray fan-out has the same property inside one iteration: every task of it carries the model pickled at its
+    start, self_play.py:249-256).  `temperature` may be a callable iteration -> temperature.  Actor ranks yield (None, None)."""
+    heads_of = lambda: model.heads(env.device)                                   # noqa: E731  (re-packed if the weights changed)
+    if td_steps is None:
+        td_steps = getattr(replay_buffer, "td_steps", None)
+    kw = _cut_rules(env, steps, ignore_termination, limit_of_game_play)
+    cut = {k: kw[k] for k in ("limit_of_game_play", "keep_partial", "observation_shape")}
+    job = None
+    for it in range(int(iterations)):
+        T = temperature(it) if callable(temperature) else temperature
+        got = _play_and_gather(env, heads_of(), mcts, T, steps, gather)
+        new = None
+        if got is not None:
+            data, frames, chunk = got
+            new = RecordsJob(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, td_steps, kw["ignore_termination"],
+                             kw["after_end"], frames)
+        if it > 0:
+            yield (None, None) if job is None else _store(job.finish(priority_scale, **cut), replay_buffer)
+        job = new
+    if int(iterations) > 0:
+        yield (None, None) if job is None else _store(job.finish(priority_scale, **cut), replay_buffer)
 
 
 def _reward_sums(games):

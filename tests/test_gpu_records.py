@@ -140,3 +140,31 @@ def test_records_of_the_headline_chunk_in_tens_of_milliseconds():
           f"(make_priority + bookkeeping) {save_ms:.1f} ms")
     assert len(games) == B and buf.total == T * B
     assert rec_ms < 60 and save_ms < 60                    # (measured ~15 / ~10 ms; the list records: 3.4 s)
+
+
+def test_pipelined_iterations_yield_the_games_of_the_synchronous_calls():
+    """self_play_iterations (iteration k + 1's search enqueued before iteration k's host half) == self_play_iteration x n:
+    same games in the same order, same buffer contents, every iteration."""
+    envs_mod, sp, mcts_mod = _pkg("envs"), _pkg("selfplay"), _pkg("mcts")
+    model = _model()
+    n_it, B, T = 4, 160, 12
+
+    def setup():
+        env = envs_mod.CartPoleVec(B, "cuda:0", seed=2, on_end="reset", limit=5)
+        m = mcts_mod.BatchedMCTS(B, num_simulations=5, discount=0.999, root_exploration_fraction=0.1, use_graph=False)
+        m.seed(np.arange(B, dtype=np.uint64))
+        return env, m, Buffer(3, 4)
+    env, m, buf_a = setup()
+    sync = [sp.self_play_iteration(env, model, m, 1.0, T, replay_buffer=buf_a) for _ in range(n_it)]
+    env, m, buf_b = setup()
+    piped = list(sp.self_play_iterations(env, model, m, 1.0, T, n_it, replay_buffer=buf_b))
+    assert len(piped) == n_it
+    for (ga, ma), (gb, mb) in zip(sync, piped):
+        assert len(ga) == len(gb) > B and ma == mb
+        for a, b in zip(ga, gb):
+            same_game(a, b, 3)
+    assert buf_a.total == buf_b.total and buf_a.prio_game == buf_b.prio_game
+    # the games of an earlier iteration are untouched by the later ones (their host arrays are their own, not the staging buffers)
+    first = piped[0][0][0]
+    again = sync[0][0][0]
+    assert list(first.rewards) == list(again.rewards) and np.array_equal(np.array(first.policies), np.array(again.policies))
