@@ -106,6 +106,20 @@ class TrajectoryChunk:
                     child_visits=d[..., o + 3 + 2 * A:o + 3 + 3 * A])
 
 
+_POWERS = {}
+
+
+def _discount_powers(discount, td_steps, device):
+    """discount ** i for i = 0 .. td_steps (Python's pow, as game.py:300-305 evaluates it) on the device, uploaded once per
+    (discount, td_steps, device): an upload from pageable memory waits for the stream to drain, which would serialise a caller
+    that has just enqueued a search (self_play_iterations)."""
+    key = (discount, td_steps, str(device))
+    t = _POWERS.get(key)
+    if t is None:
+        t = _POWERS[key] = torch.tensor([discount ** i for i in range(td_steps + 1)], dtype=torch.float64).to(device)
+    return t
+
+
 def chunk_targets(chunk_data, obs_dim, A, discount, td_steps, ignore_termination=False, after_end="drop",
                   return_game_end=False):
     """Vectorised replay ingest on the device (smz_traj_targets_games): for a [T][B][F] chunk returns
@@ -127,7 +141,7 @@ def chunk_targets(chunk_data, obs_dim, A, discount, td_steps, ignore_termination
     assert F == lib.smz_traj_floats(int(obs_dim), int(A)), \
         f"a record of {F} floats is not obs_dim {obs_dim} + 3 * {A} + 3 (image observations: pass the TrajectoryChunk or obs_dim=0)"
     dev = chunk_data.device
-    pows = torch.tensor([discount ** i for i in range(int(td_steps) + 1)], dtype=torch.float64).to(dev)   # Python's pow
+    pows = _discount_powers(float(discount), int(td_steps), dev)
     length = torch.empty(B, dtype=torch.int32, device=dev)
     game_end = torch.empty(T, B, dtype=torch.int32, device=dev)
     target = torch.empty(T, B, dtype=torch.float64, device=dev)
@@ -236,9 +250,10 @@ def chunk_to_records(chunk_data, obs_dim, A, discount, priority_scale=1, limit_o
 _STAGING = {}
 
 
-def _staging(shape, dtype, slot):
-    """Page-locked staging buffers for the transfers of a RecordsJob, two per (shape, dtype): job k + 2 reuses job k's."""
-    key = (tuple(shape), dtype, slot & 1)
+def _staging(shape, dtype, slot, index):
+    """Page-locked staging buffers for the transfers of a RecordsJob, two sets (job k + 2 reuses job k's); `index` tells the
+    arrays of one job apart (targets and priorities have the same shape and type)."""
+    key = (tuple(shape), dtype, slot & 1, index)
     buf = _STAGING.get(key)
     if buf is None:
         buf = _STAGING[key] = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
@@ -275,7 +290,7 @@ class RecordsJob:
             else:
                 dev.append(frames)
         self.has_obs = observations is not None and self.big_obs is None
-        self.host = [_staging(d.shape, d.dtype, slot) for d in dev]
+        self.host = [_staging(d.shape, d.dtype, slot, i) for i, d in enumerate(dev)]
         for h, d in zip(self.host, dev):
             h.copy_(d, non_blocking=True)
         self.event = torch.cuda.Event()
