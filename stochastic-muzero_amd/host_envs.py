@@ -328,7 +328,12 @@ class SharedBlock:
 # syscall only when there is something to wait for or somebody to wake) after a spin of a few microseconds.
 #   word GO     (ctrl32[0]) step sequence number, written by the parent; workers wait for it to change
 #   word NOTIFY (ctrl32[2]) bumped by every worker that finishes; the parent waits for it to change, then looks at the flags
-_SYS_FUTEX, _FUTEX_WAIT, _FUTEX_WAKE = 202, 0, 1          # x86-64 Linux; shared (not PRIVATE) futexes: the waiters are other processes
+import platform  # noqa: E402
+
+# SYS_futex of this machine (None: unknown architecture -> waiters fall back to short sleeps); shared (not PRIVATE) futexes: the
+# waiters are other processes
+_SYS_FUTEX = {"x86_64": 202, "aarch64": 98, "arm64": 98}.get(platform.machine()) if sys.platform.startswith("linux") else None
+_FUTEX_WAIT, _FUTEX_WAKE = 0, 1
 _libc = None
 
 
@@ -338,6 +343,10 @@ class _Timespec(ctypes.Structure):
 
 def _futex(addr, op, val, timeout_s=None):
     global _libc
+    if _SYS_FUTEX is None:                                  # no futex here: a wait is a nap (the caller re-checks), a wake is nothing
+        if op == _FUTEX_WAIT:
+            time.sleep(min(timeout_s or 100e-6, 100e-6))
+        return 0
     if _libc is None:
         _libc = ctypes.CDLL(None, use_errno=True)
         _libc.syscall.restype = ctypes.c_long

@@ -555,6 +555,86 @@ def reanalyse_replay_games(games, model, mcts, device, temperature=0.0, train=Tr
     return [out[gi] for gi in sorted(out)]
 
 
+def reanalyse_replay_records(games, model, mcts, device, temperature=0.0, train=True, td_steps=None):
+    """reanalyse_replay_games for stored ArrayGameRecords, without a Python step per position: the observations of all
+    positions are gathered from the records' shared host arrays into one batch, searched, and the reanalysed games come back
+    as ArrayGameRecords over ONE new host block (rows: observations[i + 1], rewards[action + 1] -- indexed by the ACTION,
+    game.py:255 --, the new policy / action / root value / child visits; the game ends with the step for which
+    i + 2 >= n - 1, game.py:256; at most limit_of_game_play steps).  Same games as reanalyse_replay_games, field by field
+    (tests/test_gpu_records.py); records that are not pristine ArrayGameRecords go through reanalyse_replay_games."""
+    fast = all(isinstance(g, ArrayGameRecord) and g._pristine(*("observations", "rewards")) and g._src.observations is None
+               for g in games)
+    if not fast or not games:
+        return reanalyse_replay_games(games, model, mcts, device, temperature, train)
+    heads = model.heads(device)
+    src0 = games[0]._src
+    o, A = src0.o, src0.A
+    F = o + 3 * A + 3
+    n = np.array([g._t1 - g._t0 for g in games])
+    limit = np.array([min(g.limit_of_game_play, 1 << 40) for g in games], np.int64)
+    steps = np.minimum(np.maximum(n - 2, 0), limit)                 # positions searched (and rows produced) per game
+    keep = np.nonzero(steps > 0)[0]
+    if not len(keep):
+        return []
+    # position k <-> (game, step i): game-major, as reanalyse_replay_games orders its trees
+    gi = np.repeat(keep, steps[keep])
+    first = np.cumsum(steps[keep]) - steps[keep]
+    step = np.arange(len(gi)) - np.repeat(first, steps[keep])
+    # NB reanalyse_replay_games searches n - 2 positions per game even when the limit cuts the replay earlier (tree k's stream
+    # belongs to position k of THAT numbering): positions are numbered over min(.., limit) here only when no game is cut
+    full = np.maximum(n - 2, 0)
+    if (steps != full).any():
+        return reanalyse_replay_games(games, model, mcts, device, temperature, train)
+    rows = [g._src.rec[g._e, g._t0:g._t1] for g in games]              # views [n_g, F]
+    obs = np.concatenate([rows[g][:steps[g], :o] for g in keep]).astype(np.float32)
+    P = len(obs)
+    B = mcts.num_trees
+    a = np.empty(P, np.int64); pol = np.empty((P, A)); cv = np.empty((P, A)); rv = np.empty(P, np.float32)
+    for lo in range(0, P, B):
+        part = obs[lo:lo + B]
+        batch = torch.from_numpy(np.concatenate([part, np.repeat(part[-1:], B - len(part), 0)]) if len(part) < B else part)
+        eng = mcts.run(batch.to(device).contiguous(), heads, train=train, act_temperature=temperature)
+        action, policy, child_visits, root_value = eng.act(temperature)
+        torch.cuda.synchronize(device)
+        m = len(part)
+        a[lo:lo + m] = action.cpu().numpy()[:m]; pol[lo:lo + m] = policy.cpu().numpy()[:m]
+        cv[lo:lo + m] = child_visits.cpu().numpy()[:m]; rv[lo:lo + m] = root_value.cpu().numpy()[:m]
+    # the new records, one env-major block [G][Tmax][F]
+    G, Tmax = len(keep), int(steps[keep].max())
+    rec = np.zeros((G, Tmax, F))
+    rec[:, :, o + 1] = 3                                                  # rows behind a game's end: "no step"
+    slot = np.repeat(np.arange(G), steps[keep])
+    flat = np.concatenate([rows[g] for g in keep])                        # all stored rows of the kept games, game-major
+    base = np.repeat(np.cumsum(n[keep]) - n[keep], steps[keep])           # first stored row of position k's game
+    if (a + 1 >= np.repeat(n[keep], steps[keep])).any():
+        raise IndexError("rewards[action + 1] past the end of a stored game (game.py:255 indexes the rewards by the action)")
+    out = np.zeros((P, F))
+    out[:, :o] = flat[base + step + 1, :o]
+    out[:, o] = flat[base + a + 1, o]
+    last = step == np.repeat(steps[keep], steps[keep]) - 1
+    out[:, o + 1] = np.where(last, 1, 0)
+    out[:, o + 2:o + 2 + A] = pol
+    out[np.arange(P), o + 2 + A + a] = 1.0
+    out[:, o + 2 + 2 * A] = rv
+    out[:, o + 3 + 2 * A:] = cv
+    rec[slot, step] = out
+    game_end = np.full((G, Tmax), -1, np.int32)
+    game_end[slot, step] = np.repeat(steps[keep], steps[keep]).astype(np.int32)
+    target = err = None
+    g0 = games[int(keep[0])]
+    if td_steps is not None:
+        dev_chunk = torch.from_numpy(np.ascontiguousarray(rec.transpose(1, 0, 2))).to(device)
+        _, t_dev, e_dev = chunk_targets(dev_chunk, o, A, g0.discount, td_steps)
+        torch.cuda.synchronize(device)
+        target, err = np.ascontiguousarray(t_dev.cpu().numpy().T), np.ascontiguousarray(e_dev.cpu().numpy().T)
+    # (one ChunkHostCopy: discount / priority scale / limit of the first game -- stored games of one buffer share them)
+    new = records_from_host_copy(rec, game_end, o, A, g0.discount, g0.priority_scale, g0.limit_of_game_play, td_steps=td_steps,
+                                 target=target, abs_td=err)
+    for g in new:
+        g.reanalyzed = True
+    return new
+
+
 def play_game(environment=None, model=None, monte_carlo_tree_search=None, temperature=1, replay_buffer=None):
     """The reference's per-game loop (self_play.py:63-98) with its exact call sequence, for ONE game: `environment` is a
     Game (this package's or the reference's), `monte_carlo_tree_search` any object with run(observation=, model=, train=)

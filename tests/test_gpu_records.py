@@ -168,3 +168,28 @@ def test_pipelined_iterations_yield_the_games_of_the_synchronous_calls():
     first = piped[0][0][0]
     again = sync[0][0][0]
     assert list(first.rewards) == list(again.rewards) and np.array_equal(np.array(first.policies), np.array(again.policies))
+
+
+def test_vectorised_reanalyse_of_array_records_equals_the_per_position_loop():
+    """reanalyse_replay_records (stored ArrayGameRecords, no Python step per position) == reanalyse_replay_games (the reference's
+    reanalyse branch, pinned by goldens in test_gpu_selfplay_seam.py) on the same stored games with the same tree seeds."""
+    sp, mcts_mod = _pkg("selfplay"), _pkg("mcts")
+    _, env, chunk = _play("reset", B=64, T=30, sims=5, limit=11)
+    model = _model()
+    kw = dict(limit_of_game_play=11, after_end="new_game", keep_partial=False)
+    stored_lists = sp.chunk_to_games(chunk.data, 4, 2, 0.999, **kw)
+    stored_arrays = sp.chunk_to_records(chunk, None, 2, 0.999, td_steps=4, **kw)
+    assert len(stored_arrays) == len(stored_lists) > 64
+    n_pos = sum(max(0, g.game_length - 2) for g in stored_lists)
+
+    def searcher():
+        m = mcts_mod.BatchedMCTS(256, num_simulations=6, discount=0.999, root_exploration_fraction=0.1, use_graph=False)
+        m.seed(np.arange(256, dtype=np.uint64))
+        return m
+    want = sp.reanalyse_replay_games(stored_lists, model, searcher(), "cuda:0", temperature=1.0, train=True)
+    got = sp.reanalyse_replay_records(stored_arrays, model, searcher(), "cuda:0", temperature=1.0, train=True, td_steps=4)
+    assert n_pos > 256 and len(want) == len(got) > 0                # several batches of 256 trees
+    assert all(isinstance(g, sp.ArrayGameRecord) and g.reanalyzed for g in got)
+    for a, b in zip(want, got):
+        same_game(a, b, 4)
+        assert a.done and b.done
