@@ -250,3 +250,32 @@ def test_stale_observation_width_fails_loudly():
         sp.chunk_to_games(d, 65, 2, 0.97)
     with pytest.raises(AssertionError):
         sp.chunk_to_games(d[..., :8], 65, 2, 0.97)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_chunks_cut_the_same_way_as_the_checker(seed):
+    """Randomised: chunk shape, end-flag density, masked tails, envs switched off from the start, off-and-on envs, every cutting
+    rule -- the array records are the checker's games, in its order."""
+    r = np.random.RandomState(1000 + seed)
+    T, B, A = int(r.randint(1, 20)), int(r.randint(1, 14)), int(r.randint(2, 5))
+    o = int(r.choice([0, 1, 4, 9]))
+    d = make_chunk(T, B, o, A, seed=seed, p_end=float(r.choice([0.0, 0.05, 0.3, 0.9])), mask_tail=bool(r.randint(2)),
+                   odd_env=int(r.randint(B)) if (T >= 6 and r.rand() < 0.4) else None)
+    if r.rand() < 0.3:
+        d[:, r.randint(B), o + 1] = 3                       # an env that never played
+    kw = dict(after_end=str(r.choice(["drop", "new_game"])), keep_partial=bool(r.randint(2)),
+              ignore_termination=bool(r.rand() < 0.2))
+    if r.rand() < 0.5:
+        kw["limit_of_game_play"] = int(r.randint(1, 6))
+    want, got = build(d, o, A, td=int(r.randint(1, 7)), **kw) if o else (None, None)
+    if o == 0:                                              # observations outside the record
+        sp = _sp()
+        frames = torch.from_numpy(r.rand(T, B, 6).astype(np.float32))
+        flags = np.zeros((T, B), np.int64) if kw["ignore_termination"] else d[..., 1].astype(np.int64)
+        ge = game_ends(flags, kw["after_end"] == "new_game")
+        want = sp.chunk_to_games(d, 0, A, 0.97, observations=frames, observation_shape=(2, 3), **kw)
+        got = sp.records_from_host_copy(np.ascontiguousarray(d.transpose(1, 0, 2)), np.ascontiguousarray(ge.T), 0, A, 0.97,
+                                        observations=frames.permute(1, 0, 2).contiguous(), observation_shape=(2, 3), **kw)
+    assert len(want) == len(got)
+    for a, b in zip(want, got):
+        same_game(a, b, 3)
