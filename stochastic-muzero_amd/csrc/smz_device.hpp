@@ -740,6 +740,140 @@ __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const Tr
     return L;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Block-parallel selection (round 4; two children per expansion block).  What a level of the descent draws does not depend
+// on the path: a decision-flagged node draws one uniform per child (A at the root, K below), a chance-flagged one draws one,
+// and the flag is a function of the depth alone (depth_flag).  So the words level d reads sit at a FIXED offset behind the
+// stream position the descent starts from (select_words), and the pick of every node -- given its block, its depth, the
+// tree's MinMax bounds and those words -- can be computed without knowing whether the descent will come by: one lane per
+// block evaluates ALL blocks of the tree at once (select_block: the arithmetic of select_tree's levels, term by term), and
+// the descent itself shrinks to a pointer chase over one 16-bit word per block.  A wavefront instruction costs the same for
+// 2 active lanes as for 64, so the ~5.5 dependent level evaluations of a descent become one.
+// Word per block: depth << 9 (kept from the expansion) | ok << 8 | pick << 6 | next block (0: the picked child is a leaf).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline int select_words(int d, int A) {          // random words consumed by levels 0 .. d-1 (K = 2 below the root)
+    if (d <= 0) return 0;
+    const int ch = 2 * (d >> 2) + ((d & 3) > 2 ? (d & 3) - 2 : 0);     // chance-flagged levels among 0 .. d-1
+    return 2 * A + (d - ch - 1) * 4 + ch * 2;
+}
+template <int N, bool YV, class RNG>
+__device__ inline int pick_decision_words(const Kids<N> &k, int cnt, double sp, bool norm, float mn, float span, float disc32,
+                                          const uint32_t *jw, const double *r64) {
+    double best = 0.0;
+    int pick = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        if (j < cnt) {
+            const double u = RNG::to_double(jw[2 * j], jw[2 * j + 1]);
+            const double score = puct_score<N, YV>(k, j, sp, norm, mn, span, disc32, u, r64);
+            if (j == 0 || score >= best) { best = score; pick = j; }  // exact tie -> larger action
+        }
+    }
+    return pick;
+}
+// the pick of block `b` (0 = root) whose node sits at `depth`; stage[used ..] = the words the descent starts from, `staged` of
+// them valid.  Returns ok << 8 | pick << 6 | next, or 0 when the level's words lie beyond the staged window.
+template <int MAXA, bool YV, class RNG>
+__device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int b, int depth, int root_visit, float mn, float mx,
+                                        const uint32_t *stage, int used, int staged, const double *pbc_sqrt) {
+    constexpr bool RY = YV && MAXA <= 8;
+    const int A = P.A;
+    const bool chance = depth_flag(depth) != 0;
+    const int w0 = used + select_words(depth, A), need = chance ? 2 : (b == 0 ? 2 * A : 4);
+    if (w0 + need > staged) return 0u;
+    const uint32_t *w = stage + w0;
+    const bool norm = mx > mn;
+    const float span = mx - mn;
+    const double *r64 = pbc_sqrt + P.sims + 2;
+    int pick = 0, c = 0;
+    if constexpr (MAXA == 2) {
+        // two actions: the root block has the expansion blocks' field offsets (A == K == 2), so the root is ONE code path with
+        // the decision-flagged blocks -- its float64 priors, its value terms and its visit count come from their own places
+        const bool root = b == 0;
+        const uint32_t *bp = root ? tb : tb + P.rb_words + (size_t)(b - 1) * P.eb_words;
+        const uint32_t *aux = root ? tb + (RY ? P.ry_off : 0) : tb + P.thr_off + (size_t)(b - 1) * P.thr_stride;
+        Kids<2> k;
+        load_kids_static<2>(bp, k);
+        if (chance) {
+            pick = (*reinterpret_cast<const double *>(aux) <= RNG::to_double(w[0], w[1])) ? 1 : 0;
+        } else {
+            if constexpr (YV) {
+                const uint2 y2 = *reinterpret_cast<const uint2 *>(aux);
+                k.yv[0] = __uint_as_float(y2.x); k.yv[1] = __uint_as_float(y2.y);
+            }
+            if (root) {
+                const double *rp = reinterpret_cast<const double *>(tb + P.rp_off);
+                k.pri64[0] = rp[0]; k.pri64[1] = rp[1];
+            }
+            // visits of the node that owns the block: its expansion + one per later descent through it, each of which went on to
+            // one of its children -- what the sequential descent carries along as the picked child's count
+            const int np = root ? root_visit : 1 + k.vis[0] + k.vis[1];
+            pick = pick_decision_words<2, YV, RNG>(k, 2, pbc_sqrt[np], norm, mn, span, P.disc32, w, r64);
+        }
+        c = pick ? k.chd[1] : k.chd[0];
+    } else if (b == 0) {
+        Kids<MAXA> k;
+        load_kids_dyn<MAXA>(tb, A, true, P.rp_off, k);
+        if constexpr (RY) {
+#pragma unroll
+            for (int j = 0; j < MAXA; j++) k.yv[j] = j < A ? __uint_as_float(tb[P.ry_off + j]) : 0.f;
+        }
+        pick = pick_decision_words<MAXA, RY, RNG>(k, A, pbc_sqrt[root_visit], norm, mn, span, P.disc32, w, r64);
+#pragma unroll
+        for (int j = 0; j < MAXA; j++) if (j == pick) c = k.chd[j];
+    } else {
+        const uint32_t *bp = tb + P.rb_words + (size_t)(b - 1) * P.eb_words;
+        Kids<2> k;
+        load_kids_static<2>(bp, k);
+        if (chance) {
+            const double t = *reinterpret_cast<const double *>(tb + P.thr_off + (size_t)(b - 1) * P.thr_stride);
+            pick = (t <= RNG::to_double(w[0], w[1])) ? 1 : 0;
+        } else {
+            if constexpr (YV) {
+                const uint2 y2 = *reinterpret_cast<const uint2 *>(tb + P.thr_off + (size_t)(b - 1) * P.thr_stride);
+                k.yv[0] = __uint_as_float(y2.x); k.yv[1] = __uint_as_float(y2.y);
+            }
+            pick = pick_decision_words<2, YV, RNG>(k, 2, pbc_sqrt[1 + k.vis[0] + k.vis[1]], norm, mn, span, P.disc32, w, r64);
+        }
+        c = pick ? k.chd[1] : k.chd[0];
+    }
+    return 0x100u | ((uint32_t)pick << 6) | (uint32_t)c;
+}
+// The descent over the evaluated blocks, in two steps.  (1) select_chase, by the tree's lane: follow sel[] from the root --
+// ONE dependent LDS read per level -- and leave (block << 8 | pick) of every level in `path`; returns the depth (0: a block on
+// the way was not evaluated).  (2) select_record, one lane per level: the path record of level d (the picked child's visit
+// count, value sum and reward, for the backup) from the block itself -- these reads are off the chain; select_leaf names the
+// leaf from the path's last two entries.
+// the leaf the path ends in, read back from the path (tracking it inside the chase loop instead costs the kernel its gain: the
+// register allocation of the whole kernel changes -- 453 against 462 M on one box, profiles/r04_bps_ab.txt)
+__device__ inline Leaf select_leaf(const Params &P, const uint32_t *tb, const uint16_t *path, int depth) {
+    const int A = P.A;
+    auto node = [&](int loc) { const int b = loc >> 8, pk = loc & 3; return b == 0 ? 1 + pk : 1 + A + (b - 1) * 2 + pk; };
+    const int last = path[depth - 1], lb = last >> 8, lp = last & 3;
+    Leaf L;
+    L.leaf_id = node(last);
+    L.parent_id = depth > 1 ? node(path[depth - 2]) : 0;
+    L.action = lb == 0 ? lp : (int)tb[P.rb_words + (size_t)(lb - 1) * P.eb_words + 5 * 2 + lp];
+    L.branch = depth_flag(depth - 1);
+    return L;
+}
+__device__ inline int select_chase(const uint16_t *sel, uint16_t *path) {
+    int b = 0, depth = 0;
+    for (;;) {
+        const uint32_t s = sel[b];
+        if (!(s & 0x100u)) return 0;
+        path[depth++] = (uint16_t)((b << 8) | ((s >> 6) & 3u));
+        b = (int)(s & 63u);
+        if (b == 0) return depth;
+    }
+}
+template <class REC>
+__device__ inline void select_record(const Params &P, const uint32_t *tb, const uint16_t *path, int d, REC rec) {
+    const int loc = path[d], b = loc >> 8, pick = loc & 3;
+    const uint32_t *bp = b == 0 ? tb : tb + P.rb_words + (size_t)(b - 1) * P.eb_words;
+    const uint2 vv = *reinterpret_cast<const uint2 *>(bp + 2 * pick);                     // (visit, value_sum) of the picked child
+    rec[d] = make_uint4((uint32_t)loc, vv.x, vv.y, bp[2 * (b == 0 ? P.A : 2) + pick]);
+}
 // YV kernels: the value term of the child in slot `sl` of block `b`, chosen at path level `level` (= the depth of the block's
 // node), goes beside the block -- unless that node samples its children (the two words hold its threshold then, and a value
 // term there would never be read).

@@ -633,11 +633,28 @@ __device__ inline void cartpole_env_step(const EnvStep &E, int e, int B, const i
 // ---------------------------------------------------------------------------------------------------------------
 extern __shared__ float4 smz_search_lds4[];
 
+#ifndef SMZ_SELECT_BLOCKS
+#define SMZ_SELECT_BLOCKS 1       // block-parallel selection in the kernels that keep their trees in LDS (A/B builds: 0)
+#endif
+// -DSMZ_BPS_PROBE (variant builds, tools/bps_probe.sh): s_memtime stamps inside the production LDS-resident kernel, summed
+// over waves into smz_read_stats' slots 8.. (expand + backup | select: prepare, evaluate, chase, records | networks | staging)
+#ifdef SMZ_BPS_PROBE
+#define SMZ_PROBE_DECL unsigned long long pb_t0 = 0, pb_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define SMZ_PROBE_START pb_t0 = __builtin_amdgcn_s_memtime();
+#define SMZ_PROBE(i) { const unsigned long long pb_t1 = __builtin_amdgcn_s_memtime(); pb_acc[i] += pb_t1 - pb_t0; pb_t0 = pb_t1; }
+#define SMZ_PROBE_FLUSH(stats) if ((stats) && lane == 0) { for (int pb_i = 0; pb_i < 7; pb_i++) atomicAdd(&(stats)[8 + pb_i], pb_acc[pb_i]); }
+#else
+#define SMZ_PROBE_DECL
+#define SMZ_PROBE_START
+#define SMZ_PROBE(i)
+#define SMZ_PROBE_FLUSH(stats)
+#endif
+
 // LDS map of k_search_mlp (floats): weights | pbc table (doubles) | per wave, every part padded to 16 bytes:
 //   mlp scratch | network inputs [tpw][K4in] | path records [tpw][P] uint4 | rng tile | head outputs
 struct MegaLds {
     int pbc_off, wave_off, per_wave;                       // float offsets from the LDS base
-    int x_off, pv_off, rng_off, out_off;                   // float offsets inside a wave's region
+    int x_off, pv_off, rng_off, out_off, sel_off, sel_n;   // float offsets inside a wave's region (sel: TLDS, block-parallel select)
     int trees_off, tree_words;                             // TLDS: the workgroup's trees (words per tree, blocks packed at 6 K words)
 };
 __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
@@ -650,7 +667,9 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
     m.pv_off = m.x_off + tpw * smz_mlp::up4(P.S + P.A);
     m.rng_off = m.pv_off + tpw * P.P * 4;
     m.out_off = m.rng_off + r4(tpw * kRngStride);
-    m.per_wave = m.out_off + r4(tpw * (P.A + 2));
+    m.sel_off = m.out_off + r4(tpw * (P.A + 2));
+    m.sel_n = (P.sims + 2 + 1) & ~1;                       // 16-bit words per tree: one per block (select_block / select_chase)
+    m.per_wave = m.sel_off + (tlds ? r4(tpw * m.sel_n) : 0);      // (picks per block + the path of the descent: 2 x tpw x sel_n 16-bit words)
     m.tree_words = r4(P.rb_words + P.sims * 6 * P.K + (P.K == 2 ? 2 * P.sims : 0));   // (+ the chance thresholds, one double per block;
                                                                                       //  trees stay 16-byte aligned)
     m.trees_off = m.wave_off + waves * m.per_wave;
@@ -782,8 +801,10 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
     constexpr int SU = 2;
     const bool split = P.tpw <= SU;
     if (P.sims > 0 && !(dbg & 8)) packed = wave_stage_rng_from<4, PHC>(P, tree, valid, rng_tile, packed, rng.block());
+    SMZ_PROBE_DECL
     for (int s = 0; s < P.sims; s++) {
         if (INSTR && prof) t0 = __builtin_amdgcn_s_memtime();
+        SMZ_PROBE_START
         Leaf L = {0, 0, 0, 0};
         __builtin_amdgcn_s_setprio(SMZ_PRIO_TREE);
         // Specialised kernel: the expansion runs in the tree's lane, the backup with one lane per path level
@@ -820,10 +841,68 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             }
         }
         SMZ_STAMP(t_expand)
+        SMZ_PROBE(0)
         // Specialised two-action kernel: the descent runs on lanes 0..3 -- lane t and its helper t + 2 score one child
         // each (pick_decision_pair).  The helper works on a copy of the tree lane's stream position and MinMax bounds.
         constexpr bool PAIR = AEX && MAXA == 2 && KS == 2 && !INSTR;
-        if constexpr (PAIR) {
+        // Trees in LDS: block-parallel selection (smz_device.hpp, select_block / select_chase) -- every block of the wave's two
+        // trees gets a lane that computes the block's pick from the words its level will read, then the tree's lane follows the
+        // picks.  SMZ_SELECT_BLOCKS=0 (-DSMZ_SELECT_BLOCKS=0 builds) keeps the level-by-level descent.
+        constexpr bool BPS = SMZ_SELECT_BLOCKS && AEX && KS == 2 && TLDS && !INSTR && MAXA == 2;   // (four actions: the root is a
+        // code path of its own beside the blocks' -- measured 409 against 458 M, profiles/r04_bps_ab.txt)
+        bool bps_done = false;
+        if constexpr (BPS) {
+            uint16_t *selw = reinterpret_cast<uint16_t *>(scratch + ml.sel_off);          // [tpw][sel_n]
+            const int SELN = ml.sel_n;
+            if (valid && s > 0) selw[lane * SELN + h.n_exp] = (uint16_t)(h.path_len << 9);   // depth of the node the expansion created
+            smz_mlp::lds_sync();
+            const int src = lane & 1;
+            const int nexp = pick_lane01(valid ? h.n_exp : -1, src), rvis = pick_lane01(h.root_visit, src);
+            const float bmn = pick_lane01(h.mn, src), bmx = pick_lane01(h.mx, src);
+            const int bused = pick_lane01(valid ? rng.used : 0, src), bstaged = pick_lane01(valid ? rng.staged : 0, src);
+            const int bstage = pick_lane01(valid ? (int)(rng.stage - rng_tile) : 0, src);   // the tree's staged words, as its lane reads them
+            const int nmax = max(__builtin_amdgcn_readlane(valid ? h.n_exp : -1, 0), __builtin_amdgcn_readlane(valid ? h.n_exp : -1, 1));
+            const uint32_t *stb = tree_base(P, tree0 + src);
+            SMZ_PROBE(1)
+            for (int base = 0; base <= nmax; base += kWave / 2) {
+                const int b = base + (lane >> 1);
+                if (b <= nexp) {
+                    const int depth = b == 0 ? 0 : (int)(selw[src * SELN + b] >> 9);
+                    const uint32_t r = select_block<MAXA, YV, RngT<PHC>>(P, stb, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged,
+                                                                        pbc_lds);
+                    selw[src * SELN + b] = (uint16_t)((depth << 9) | r);
+                }
+            }
+            smz_mlp::lds_sync();
+            SMZ_PROBE(2)
+            // the descent: the tree's lane follows the picks (one dependent LDS read per level) and leaves the path in the upper half
+            // of the tree's sel words (sel_n covers both); then one lane per level writes that level's path record
+            uint16_t *pathw = selw + tpw * SELN;                                        // [tpw][sel_n]
+            int len = 0;
+            if (valid) len = select_chase(selw + lane * SELN, pathw + lane * SELN);
+            smz_mlp::lds_sync();
+            SMZ_PROBE(3)
+            const int blen = pick_lane01(len, src);
+            for (int d = lane >> 1; d < blen; d += kWave / 2) select_record(P, stb, pathw + src * SELN, d, pvals + src * P.P);
+            if (valid && len > 0) {
+                L = select_leaf(P, stb, pathw + lane * SELN, len);
+                const int nw = select_words(len, A);                    // the words the descent's levels drew (all inside the staged window)
+                rng.used += nw; rng.ready -= nw; rng.idx += nw;
+                if (rng.idx >= kMtN) { rng.idx -= kMtN; rng.wrapped(); }
+                h.path_len = len;
+                packed = rng.pack();
+                bps_done = true;
+            }
+        }
+        if constexpr (BPS) {
+            // (a level's words beyond the staged window -- a very deep path, or a window nearly used up: the sequential descent)
+            if (valid && !bps_done) {
+                int len = 0;
+                L = select_tree<MAXA, KS, false, true, false, THR, YV>(P, tree, rng, h, pbc_lds, len, n_dec, n_chance, n_children, pvals + lane * P.P);
+                h.path_len = len;
+                packed = rng.pack();
+            }
+        } else if constexpr (PAIR) {
             const int src = lane & 1;
             const int pk = pick_lane01(valid ? rng.pack() : 0, src), us = pick_lane01(valid ? rng.used : 0, src);
 
@@ -854,6 +933,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             packed = rng.pack();
         }
         SMZ_STAMP(t_select)
+        SMZ_PROBE(4)
         __builtin_amdgcn_s_setprio(SMZ_PRIO_HEADS);
         // hidden rows written in earlier rounds (by any lane of this wave) may be this round's parent rows
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -917,10 +997,13 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         }
         smz_mlp::lds_sync();
         SMZ_STAMP(t_mlp)
+        SMZ_PROBE(5)
         if (!(dbg & 8)) packed = split ? stage_finish<SU, PHC>(P, tree, valid, rng_tile, packed, pre, rng.block())
                                        : wave_stage_rng_from<4, PHC>(P, tree, valid, rng_tile, packed, rng.block());
         SMZ_STAMP(t_stage)
+        SMZ_PROBE(6)
     }
+    SMZ_PROBE_FLUSH(Pin.stats)
 #undef SMZ_STAMP
 #undef SMZ_SLOT_VALID
     if (INSTR && prof && lane == 0) {
@@ -1813,6 +1896,9 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
         const size_t lds_t = ((size_t)mt.trees_off + (size_t)kWaves * tpw * mt.tree_words) * sizeof(float);
         const char *te = getenv("SMZ_SEARCH_TLDS");
         const bool tlds = fast && !(P.stats || P.dbg) && h->K == 2 && h->maxa <= 4 && lds_t <= 160 * 1024 && !(te && atoi(te) == 0);
+#ifdef SMZ_BPS_PROBE
+        if (tlds) P.stats = h->d_stats;              // (the production kernel carries no level statistics: only the probe's stamps land there)
+#endif
         if (tlds && (P.active || P.philox)) {        // masked / Philox handles: SMZ_PART 6
             const int rc = smz_internal_search_launch_tlds(h, desc, weights_dev, obs_dev, train, a, P, kWaves, blocks, lds_t, stream);
             if (rc != SMZ_OK) return rc;
@@ -2226,8 +2312,11 @@ int smz_read_stats(smz_handle *h, uint64_t levels_out[4], int reset) {
     for (int i = 0; i < 4; i++) levels_out[i] = (uint64_t)v[i];
     if (getenv("SMZ_DEBUG_SKIP") && (atoi(getenv("SMZ_DEBUG_SKIP")) & 16))
         fprintf(stderr, "[smz phase cycles, summed over waves] stage %llu expand %llu select %llu mlp %llu  (k_search_vision: tree, conv, wait, towers+tails)\n", v[4], v[5], v[6], v[7]);
-    if (getenv("SMZ_DEBUG_SKIP") && (atoi(getenv("SMZ_DEBUG_SKIP")) & 64) && v[8])
-        fprintf(stderr, "[smz k_search_mlp_reg phases] tree %llu inputs %llu networks %llu staging %llu\n", v[8], v[9], v[10], v[11]);
+#ifdef SMZ_BPS_PROBE
+    if (v[8])
+        fprintf(stderr, "[smz k_search_mlp probe, cycles summed over waves] expand+backup %llu | select: prepare %llu evaluate %llu chase %llu records+leaf %llu "
+                        "| networks %llu | staging %llu\n", v[8], v[9], v[10], v[11], v[12], v[13], v[14]);
+#endif
     if (getenv("SMZ_DEBUG_SKIP") && (atoi(getenv("SMZ_DEBUG_SKIP")) & 16) && v[8])
         fprintf(stderr, "[smz k_search_vision phases] tree %llu load %llu conv_transition %llu conv_prediction %llu wait %llu layer1 %llu hidden_out %llu tails_stage %llu\n",
                 v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
