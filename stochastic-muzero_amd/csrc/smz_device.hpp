@@ -749,7 +749,8 @@ __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const Tr
 // block evaluates ALL blocks of the tree at once (select_block: the arithmetic of select_tree's levels, term by term), and
 // the descent itself shrinks to a pointer chase over one 16-bit word per block.  A wavefront instruction costs the same for
 // 2 active lanes as for 64, so the ~5.5 dependent level evaluations of a descent become one.
-// Word per block: depth << 9 (kept from the expansion) | ok << 8 | pick << 6 | next block (0: the picked child is a leaf).
+// Word per block: depth << 9 (kept from the expansion) | ok << 8 | pick << 7 | next block (0: the picked child is a leaf):
+// two actions, at most 126 simulations (7-bit depths and block indices; the launcher keeps longer searches off this path).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline int select_words(int d, int A) {          // random words consumed by levels 0 .. d-1 (K = 2 below the root)
     if (d <= 0) return 0;
@@ -772,7 +773,7 @@ __device__ inline int pick_decision_words(const Kids<N> &k, int cnt, double sp, 
     return pick;
 }
 // the pick of block `b` (0 = root) whose node sits at `depth`; stage[used ..] = the words the descent starts from, `staged` of
-// them valid.  Returns ok << 8 | pick << 6 | next, or 0 when the level's words lie beyond the staged window.
+// them valid.  Returns ok << 8 | pick << 7 | next, or 0 when the level's words lie beyond the staged window.
 template <int MAXA, bool YV, class RNG>
 __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int b, int depth, int root_visit, float mn, float mx,
                                         const uint32_t *stage, int used, int staged, const double *pbc_sqrt) {
@@ -786,7 +787,7 @@ __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int
     const float span = mx - mn;
     const double *r64 = pbc_sqrt + P.sims + 2;
     int pick = 0, c = 0;
-    if constexpr (MAXA == 2) {
+    {
         // two actions: the root block has the expansion blocks' field offsets (A == K == 2), so the root is ONE code path with
         // the decision-flagged blocks -- its float64 priors, its value terms and its visit count come from their own places
         const bool root = b == 0;
@@ -811,33 +812,9 @@ __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int
             pick = pick_decision_words<2, YV, RNG>(k, 2, pbc_sqrt[np], norm, mn, span, P.disc32, w, r64);
         }
         c = pick ? k.chd[1] : k.chd[0];
-    } else if (b == 0) {
-        Kids<MAXA> k;
-        load_kids_dyn<MAXA>(tb, A, true, P.rp_off, k);
-        if constexpr (RY) {
-#pragma unroll
-            for (int j = 0; j < MAXA; j++) k.yv[j] = j < A ? __uint_as_float(tb[P.ry_off + j]) : 0.f;
-        }
-        pick = pick_decision_words<MAXA, RY, RNG>(k, A, pbc_sqrt[root_visit], norm, mn, span, P.disc32, w, r64);
-#pragma unroll
-        for (int j = 0; j < MAXA; j++) if (j == pick) c = k.chd[j];
-    } else {
-        const uint32_t *bp = tb + P.rb_words + (size_t)(b - 1) * P.eb_words;
-        Kids<2> k;
-        load_kids_static<2>(bp, k);
-        if (chance) {
-            const double t = *reinterpret_cast<const double *>(tb + P.thr_off + (size_t)(b - 1) * P.thr_stride);
-            pick = (t <= RNG::to_double(w[0], w[1])) ? 1 : 0;
-        } else {
-            if constexpr (YV) {
-                const uint2 y2 = *reinterpret_cast<const uint2 *>(tb + P.thr_off + (size_t)(b - 1) * P.thr_stride);
-                k.yv[0] = __uint_as_float(y2.x); k.yv[1] = __uint_as_float(y2.y);
-            }
-            pick = pick_decision_words<2, YV, RNG>(k, 2, pbc_sqrt[1 + k.vis[0] + k.vis[1]], norm, mn, span, P.disc32, w, r64);
-        }
-        c = pick ? k.chd[1] : k.chd[0];
     }
-    return 0x100u | ((uint32_t)pick << 6) | (uint32_t)c;
+    static_assert(MAXA == 2, "one bit for the pick: the block-parallel selection is built for two actions");
+    return 0x100u | ((uint32_t)pick << 7) | (uint32_t)c;
 }
 // The descent over the evaluated blocks, in two steps.  (1) select_chase, by the tree's lane: follow sel[] from the root --
 // ONE dependent LDS read per level -- and leave (block << 8 | pick) of every level in `path`; returns the depth (0: a block on
@@ -862,8 +839,8 @@ __device__ inline int select_chase(const uint16_t *sel, uint16_t *path) {
     for (;;) {
         const uint32_t s = sel[b];
         if (!(s & 0x100u)) return 0;
-        path[depth++] = (uint16_t)((b << 8) | ((s >> 6) & 3u));
-        b = (int)(s & 63u);
+        path[depth++] = (uint16_t)((b << 8) | ((s >> 7) & 1u));
+        b = (int)(s & 127u);
         if (b == 0) return depth;
     }
 }

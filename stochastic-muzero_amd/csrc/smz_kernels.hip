@@ -1895,7 +1895,8 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
         const MegaLds mt = mega_lds(*desc, P, tpw, true, kWaves);
         const size_t lds_t = ((size_t)mt.trees_off + (size_t)kWaves * tpw * mt.tree_words) * sizeof(float);
         const char *te = getenv("SMZ_SEARCH_TLDS");
-        const bool tlds = fast && !(P.stats || P.dbg) && h->K == 2 && h->maxa <= 4 && lds_t <= 160 * 1024 && !(te && atoi(te) == 0);
+        const bool tlds = fast && !(P.stats || P.dbg) && h->K == 2 && h->maxa <= 4 && lds_t <= 160 * 1024 && !(te && atoi(te) == 0) &&
+                          P.sims <= 126;      // (the block-parallel selection's 7-bit block indices; reachable with 4-wave workgroups only)
 #ifdef SMZ_BPS_PROBE
         if (tlds) P.stats = h->d_stats;              // (the production kernel carries no level statistics: only the probe's stamps land there)
 #endif

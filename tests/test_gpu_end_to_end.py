@@ -723,7 +723,8 @@ def test_vision_single_launch_search_with_more_actions_equals_stepwise(A, L, B, 
 
 @pytest.mark.parametrize("wname,B,sims,mode", [("weights_ckpt421", 2570, 50, "plain"), ("weights_lunar_L0", 4096, 30, "plain"),
                                                ("weights_ckpt421", 2049, 52, "plain"), ("weights_ckpt421", 4096, 40, "mask"),
-                                               ("weights_lunar_L0", 3000, 25, "mask"), ("weights_ckpt421", 4096, 40, "philox")])
+                                               ("weights_lunar_L0", 3000, 25, "mask"), ("weights_ckpt421", 4096, 40, "philox"),
+                                               ("weights_ckpt421", 1500, 100, "waves4"), ("weights_ckpt421", 1100, 120, "waves4")])
 def test_lds_resident_trees_equal_trees_in_global_memory(wname, B, sims, mode, monkeypatch):
     """k_search_mlp<..., TLDS> (round 3: the workgroup's trees live in LDS for the search, blocks packed at 48 bytes + 8 bytes of chance threshold each, weights in
     the compact LDS image, written back to the 64-byte-granule layout at the end) against the same kernel with the trees in
@@ -731,6 +732,11 @@ def test_lds_resident_trees_equal_trees_in_global_memory(wname, B, sims, mode, m
     that still fits -- visits, priors, values, every dumped tree array of sampled trees, path, action outputs and stream
     positions over two consecutive searches, bit for bit."""
     mcts_mod, model_mod, _, _ = _mods()
+    if mode == "waves4":
+        # four-wave workgroups hold 8 trees: 100+ simulation trees fit in LDS there, and the block-parallel selection (round 4:
+        # one lane per block, 7-bit block indices and depths) runs with more than 63 blocks per tree and several evaluation passes
+        monkeypatch.setenv("SMZ_SEARCH_WAVES", "4")
+        mode = "plain"
     model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, wname + ".npz"))
     heads = model.heads("cuda:0", backend="hip")
     obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(5)).mul(0.3).cuda()
