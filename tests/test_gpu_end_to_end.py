@@ -724,7 +724,7 @@ def test_vision_single_launch_search_with_more_actions_equals_stepwise(A, L, B, 
 @pytest.mark.parametrize("wname,B,sims,mode", [("weights_ckpt421", 2570, 50, "plain"), ("weights_lunar_L0", 4096, 30, "plain"),
                                                ("weights_ckpt421", 2049, 52, "plain"), ("weights_ckpt421", 4096, 40, "mask"),
                                                ("weights_lunar_L0", 3000, 25, "mask"), ("weights_ckpt421", 4096, 40, "philox"),
-                                               ("weights_ckpt421", 1500, 100, "waves4"), ("weights_ckpt421", 1100, 120, "waves4")])
+                                               ("weights_ckpt421", 1500, 100, "waves4"), ("weights_ckpt421", 1100, 108, "waves4")])
 def test_lds_resident_trees_equal_trees_in_global_memory(wname, B, sims, mode, monkeypatch):
     """k_search_mlp<..., TLDS> (round 3: the workgroup's trees live in LDS for the search, blocks packed at 48 bytes + 8 bytes of chance threshold each, weights in
     the compact LDS image, written back to the 64-byte-granule layout at the end) against the same kernel with the trees in
