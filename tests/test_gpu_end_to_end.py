@@ -246,6 +246,50 @@ def test_single_launch_search_equals_stepwise_search(wname, B, sims, K):
         assert np.array_equal(ra.random_sample(700), rb.random_sample(700))
 
 
+def test_block_parallel_selection_on_deep_paths_takes_the_sequential_descent_for_them(tmp_path, monkeypatch):
+    """Round 4: with the trees in LDS every block's pick is computed by its own lane from the random words its LEVEL will read
+    (fixed offsets behind the stream position: select_words) -- as long as those words lie inside the 64 staged ones.  A path
+    deeper than ~19 levels needs more: that tree's round must go through the sequential descent instead, with the same result.
+    Networks with one-sided policies (logits +8 / -8, everything else of checkpoint 421) make every search one long line: last
+    paths of 22+ levels.  LDS-resident (block-parallel) against trees in global memory (level by level), bit for bit."""
+    mcts_mod, model_mod, _, _ = _mods()
+    z = dict(np.load(os.path.join(gu.GOLDEN, "weights_ckpt421.npz")))
+    for head in ("pre", "apr"):
+        z[head + "_pol_w"] = np.zeros_like(z[head + "_pol_w"])
+        z[head + "_pol_b"] = np.array([8.0, -8.0], np.float32)
+    wpath = os.path.join(tmp_path, "one_sided.npz")
+    np.savez(wpath, **z)
+    model = model_mod.Muzero.from_arrays(wpath)
+    heads = model.heads("cuda:0", backend="hip")
+    # four-wave workgroups: 100-simulation trees fit in LDS there, and 100 simulations make lines of 25+ levels
+    monkeypatch.setenv("SMZ_SEARCH_WAVES", "4")
+    B, sims = 1100, 100
+    obs = torch.randn(B, 4, generator=torch.Generator().manual_seed(9)).mul(0.05).cuda()
+    res = []
+    for tlds in ("1", "0"):
+        monkeypatch.setenv("SMZ_SEARCH_TLDS", tlds)
+        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997, root_exploration_fraction=0.25,
+                                 use_graph=False, single_launch=True)
+        m.seed(np.arange(B, dtype=np.uint64) + 17)
+        e = m.run(obs, heads, train=True, act_temperature=1.0)
+        assert e.last_kernel().endswith("true>" if tlds == "1" else "false>"), e.last_kernel()
+        visits, priors, rv, cr = e.root_stats()
+        action, policy, cv, _ = e.act(1.0)
+        torch.cuda.synchronize()
+        dumps = [e.dump_tree(i) for i in range(0, B, 29)]
+        res.append(([t.cpu().numpy().copy() for t in (visits, priors, rv, cr, action, policy, cv)], dumps,
+                    [e.get_rng_state(i) for i in (0, 1, B - 1)]))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for da, db in zip(res[0][1], res[1][1]):
+        for k in da:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+    for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
+        assert np.array_equal(ka, kb) and pa == pb
+    depths = [len(d["path"]) for d in res[0][1]]
+    assert max(depths) >= 22, depths                     # deep enough that the staged window cannot cover the last levels
+
+
 def test_module_heads_with_image_shaped_hidden_states_and_action_planes():
     """The generic five-module path with a vision-shaped family: hidden state [B,3,7,7], action fed as a constant
     plane (a+1)/A (muzero_model.py:511-522).  Engine and per-tree oracle are fed the SAME module outputs, so every
