@@ -18,6 +18,13 @@ int smzh_abi_version(void);
 int smzh_gather_taps_u8(const uint8_t *frame, int H, int W, const int32_t *row_index, int n_rows, const int32_t *col_index,
                         int n_cols, uint8_t *taps);
 
+
+/* Hand-off words of the shared control page (host_envs.py: one `done` word per worker, written by that worker only, read by
+ * the parent): a release store after the worker's rows are written, an acquire load before the parent reads them -- the
+ * ordering numpy stores cannot express (they are enough on x86's total store order, not on aarch64). */
+void smzh_store_release_i32(int32_t *word, int32_t value);
+int32_t smzh_load_acquire_i32(const int32_t *word);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,10 @@
 
 #include <string.h>
 
-int smzh_abi_version(void) { return 1; }
+int smzh_abi_version(void) { return 2; }
+
+void smzh_store_release_i32(int32_t *word, int32_t value) { __atomic_store_n(word, value, __ATOMIC_RELEASE); }
+int32_t smzh_load_acquire_i32(const int32_t *word) { return __atomic_load_n(word, __ATOMIC_ACQUIRE); }
 
 int smzh_gather_taps_u8(const uint8_t *frame, int H, int W, const int32_t *row_index, int n_rows, const int32_t *col_index,
                         int n_cols, uint8_t *taps) {

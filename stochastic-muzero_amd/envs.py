@@ -206,7 +206,7 @@ class HostVecEnv:
     Observations are flattened float32 vectors (game.py:145-167); rendered RGB frames: HostImageVecEnv."""
 
     def __init__(self, envs, obs_dim, num_actions, device, action_map=None, env_seed=0, limit=0, on_end="reset", first_env=0,
-                 transform=None, workers=0, spin=50, _adapter=None):
+                 transform=None, workers=0, spin=50, _adapter=None, batch_step=True):
         assert on_end in ("mask", "reset")
         self.lib = _lib.load()
         self.B = len(envs)
@@ -216,6 +216,7 @@ class HostVecEnv:
         self.env_seed, self.limit, self.on_end, self.first_env = int(env_seed), int(limit), on_end, int(first_env)
         self.adapter = _adapter if _adapter is not None else _he.VectorAdapter(self.obs_dim, transform)
         self.workers = int(min(max(0, workers), self.B))
+        self.batch_step = bool(batch_step)    # envs whose class offers make_batch are stepped slice-wise (host_envs.CartPoleBatch)
         self.spin = int(spin)        # polls of a shared word before a waiter sleeps in the kernel (futex); 0 on a CPU-quota'd box is fine
         B, row, dtype = self.B, self.adapter.row, self.adapter.dtype
         lay = _he.block_layout(B, row, dtype)
@@ -251,7 +252,7 @@ class HostVecEnv:
         else:
             envs = [_he.build_env(e) for e in envs]
             self._slice = _he.HostSlice(envs, 0, self.adapter, self._arr, self.action_map, self.env_seed, self.limit, self.on_end,
-                                        self.first_env)
+                                        self.first_env, batch=self.batch_step)
         self.envs = self._slice.envs if self._slice is not None else None
 
     @property
@@ -345,7 +346,7 @@ class HostVecEnv:
             spec = dict(block_path=self._block.path, nbytes=self._block.nbytes, B=B, row=self.adapter.row, dtype=self.adapter.dtype,
                         workers=W, worker=w, lo=cuts[w], envs=list(envs[cuts[w]:cuts[w + 1]]), adapter=self.adapter,
                         action_map=self.action_map, env_seed=self.env_seed, limit=self.limit, on_end=self.on_end,
-                        first_env=self.first_env, parent_pid=os.getpid(), spin=self.spin)
+                        first_env=self.first_env, parent_pid=os.getpid(), spin=self.spin, batch=self.batch_step)
             f = tempfile.NamedTemporaryFile(prefix="smz_hostenv_spec_", suffix=".pkl", delete=False)
             pickle.dump(spec, f, protocol=pickle.HIGHEST_PROTOCOL)
             f.close()
@@ -353,7 +354,7 @@ class HostVecEnv:
             self._procs.append(subprocess.Popen([sys.executable, os.path.join(here, "host_worker.py"), f.name], env=env_vars))
         alive = lambda: all(p.poll() is None for p in self._procs)           # noqa: E731
         t0 = time.perf_counter()
-        while not all(self._ctrl[8 + w] == -1 for w in range(W)):            # every worker has mapped the block
+        while not all(self._words[_he.done_word(w)] == -1 for w in range(W)):   # every worker has mapped the block
             if not alive():
                 self.close()
                 raise RuntimeError("a host-env worker process exited while starting (its traceback is above)")
@@ -373,23 +374,25 @@ class HostVecEnv:
             return
         self._seq += 1
         self._ctrl[1] = cmd
-        self._words[_he.GO] = self._seq
+        _he.store_release(self._words, _he.GO, self._seq)      # (after the actions and the command)
         _he.futex_wake_all(self._words, _he.GO)
 
     def _wait_workers(self):
         """Sleeps on the completion bell until every worker has finished the current command."""
         if self._slice is not None:
             return
-        done, seq, words = self._ctrl[8:8 + self.workers], self._seq, self._words
+        seq, words = self._seq, self._words
         n = 0
-        while True:
-            bell = int(words[_he.NOTIFY])
-            if (done == seq).all():
-                return
-            _he.futex_wait_change(words, _he.NOTIFY, bell, timeout_s=0.01, spin=self.spin)
-            n += 1
-            if n % 50 == 0 and not all(p.poll() is None for p in self._procs):
-                raise RuntimeError("a host-env worker process died (its traceback is above)")
+        for w in range(self.workers):                  # in worker order: each word has ONE writer, so a value read here is final
+            idx = _he.done_word(w)
+            while True:
+                seen = _he.load_acquire(words, idx)
+                if seen == seq:
+                    break
+                _he.futex_wait_change(words, idx, seen, timeout_s=0.01, spin=self.spin)
+                n += 1
+                if n % 50 == 0 and not all(p.poll() is None for p in self._procs):
+                    raise RuntimeError("a host-env worker process died (its traceback is above)")
 
     # ---- the loop's interface --------------------------------------------------------------------------------------------
     def reset(self):
@@ -433,7 +436,7 @@ class HostVecEnv:
             try:
                 self._seq += 1
                 self._ctrl[1] = _he.CMD_EXIT
-                self._words[_he.GO] = self._seq
+                _he.store_release(self._words, _he.GO, self._seq)
                 _he.futex_wake_all(self._words, _he.GO)
             except Exception:
                 pass

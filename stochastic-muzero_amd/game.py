@@ -225,7 +225,9 @@ class ArrayGameRecord(GameRecord):
         src, d = self._src, self.__dict__
         if src.prio is not None and td_steps == src.td_steps and td_steps >= 1 and self._t1 > self._t0 and \
                 "priority_scale" not in d and self._pristine("rewards", "root_values"):
-            pos = src.prio[self._e, self._t0:self._t1]
+            # a fresh array per call, as the reference builds one (ReplayBuffer.update_value writes prio_position[game][h] in
+            # place, replay_buffer.py:222: a view would let it rewrite the chunk-wide array every record of the chunk reads)
+            pos = src.prio[self._e, self._t0:self._t1].copy()
             return pos, (np.max(pos) if self._top is None else self._top)
         return super().make_priority(td_steps)
 

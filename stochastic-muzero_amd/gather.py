@@ -9,22 +9,25 @@ import torch
 import torch.distributed as dist
 
 
-_PEER_SIZES = {}
-
-
-def peer_sizes(n_local, device, group=None):
+def peer_sizes(n_local, device, group=None, total_envs=None):
     """Env count (dim 1 of a slab) of every rank's shard.  Shards may differ by one env (shard_range), so the learner cannot
-    size its receive buffers from its own slab: the sizes are exchanged ONCE per (group, local size) with a tiny all_gather and
-    remembered -- every rank calls the gather in the same order, so the caches stay in step."""
-    key = (id(group), int(n_local))
-    got = _PEER_SIZES.get(key)
-    if got is None:
-        world = dist.get_world_size(group)
-        mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
-        out = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(out, mine, group=group)
-        got = _PEER_SIZES[key] = [int(t.item()) for t in out]
-    return got
+    size its receive buffers from its own slab.  Whether a collective is issued must NOT depend on anything rank-local
+    (a cache keyed on the local size let rank 0 skip the all_gather that rank 1 entered when a process gathered
+    for 9 envs and then for 8 -- shards 4|5, then 4|4):
+      * `total_envs` given: the sizes are shard_range's on every rank, no communication; a slab that is not this rank's
+        shard of that total is an error here, before any receive is posted;
+      * otherwise the sizes are exchanged with an 8-byte all_gather on EVERY call (every rank enters it)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if total_envs is not None:
+        sizes = [hi - lo for lo, hi in (shard_range(int(total_envs), r, world) for r in range(world))]
+        if sizes[rank] != int(n_local):
+            raise ValueError(f"rank {rank} holds {int(n_local)} envs, but its shard of {int(total_envs)} envs over {world} "
+                             f"ranks has {sizes[rank]} (gather.shard_range)")
+        return sizes
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return [int(t.item()) for t in out]
 
 
 def _like(slab, n_envs):
@@ -33,16 +36,18 @@ def _like(slab, n_envs):
     return torch.empty(shape, dtype=slab.dtype, device=slab.device)
 
 
-def gather_to_learner(slab, dst=0, group=None):
-    """Returns the list of every rank's slab [T][B_rank][...] on rank `dst` (rank order), None elsewhere."""
+def gather_to_learner(slab, dst=0, group=None, total_envs=None, sizes=None):
+    """Returns the list of every rank's slab [T][B_rank][...] on rank `dst` (rank order), None elsewhere.
+    `total_envs` (the job's env count) or `sizes` (every rank's shard size) spare the size exchange (peer_sizes)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return [slab]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     slab = slab.contiguous()
     if dist.get_backend(group) == "gloo" and slab.is_cuda:     # functional runs without RCCL: stage through the host
-        parts = gather_to_learner(slab.cpu(), dst, group)
+        parts = gather_to_learner(slab.cpu(), dst, group, total_envs, sizes)
         return None if parts is None else [p.to(slab.device) for p in parts]
-    sizes = peer_sizes(slab.shape[1], slab.device, group)
+    if sizes is None:
+        sizes = peer_sizes(slab.shape[1], slab.device, group, total_envs)
     if rank == dst:
         parts = [slab if r == dst else _like(slab, sizes[r]) for r in range(world)]
         ops = [dist.P2POp(dist.irecv, parts[r], r, group) for r in range(world) if r != dst]
@@ -97,24 +102,42 @@ class TrajectoryGather:
     through the host synchronously.  Usable wherever a plain `gather(slab) -> parts` callable is (it is one: the whole
     slab as a single slice)."""
 
-    def __init__(self, obs_dim, A, dst=0, group=None, slices=4, compact=True):
+    def __init__(self, obs_dim, A, dst=0, group=None, slices=4, compact=True, total_envs=None, loopback=False):
+        """`total_envs`: the job's env count -- every rank then derives the shard sizes itself (shard_range) and no size
+        exchange happens; without it the sizes are exchanged once per chunk (at the first start() after a finish(), an
+        8-byte all_gather every rank enters).  `loopback`: a world of ONE rank still goes through the exchange -- the rank
+        posts its isend and the matching irecv to itself in one group (RCCL executes a self send / receive inside a
+        group call), so the side stream, the grouped P2P and the record_stream bookkeeping run on a single-GPU box
+        (tests/test_gpu_rccl_loopback.py)."""
         self.o, self.A, self.dst, self.group, self.slices, self.compact = int(obs_dim), int(A), dst, group, max(1, int(slices)), compact
-        self._side, self._pending = None, []
+        self.total_envs, self.loopback = total_envs, bool(loopback)
+        self._side, self._pending, self._sizes = None, [], None
         self.exposed_ms = None
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1 or self.loopback
 
     def start(self, data, frames=None):
         if not self._active():
             self._pending.append(((data, None), frames, None))
             return
         nccl = dist.get_backend(self.group) == "nccl" and data.is_cuda
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        if self._sizes is None:                                  # once per chunk, on every rank alike
+            self._sizes = [int(data.shape[1])] if world == 1 else peer_sizes(data.shape[1], data.device, self.group, self.total_envs)
+        sizes = self._sizes
+        if sizes[rank] != int(data.shape[1]):
+            raise ValueError(f"slice with {int(data.shape[1])} envs inside a chunk that started with {sizes[rank]}")
         if not nccl:                                             # gloo: staged through the host, synchronous
             msgs = list(pack_records(data, self.o, self.A)) if self.compact else [data.contiguous()]
             if frames is not None:
                 msgs.append(frames.contiguous())
-            got = [gather_to_learner(m, self.dst, self.group) for m in msgs]
+            if world == 1:                                       # (loopback: what a receive from oneself yields)
+                got = [[m.clone()] for m in msgs]
+            else:
+                got = [gather_to_learner(m, self.dst, self.group, sizes=sizes) for m in msgs]
             self._pending.append((None, None, got))
             return
         cur = torch.cuda.current_stream(data.device)
@@ -127,9 +150,10 @@ class TrajectoryGather:
                 msgs.append(frames.contiguous())
             for m in msgs:
                 m.record_stream(self._side)
-            world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
-            sizes = peer_sizes(data.shape[1], data.device, self.group)
-            if rank == self.dst:
+            if world == 1:                                       # loopback: send to and receive from oneself, one group
+                bufs = [[_like(m, sizes[0])] for m in msgs]
+                ops = [dist.P2POp(dist.isend, m, 0, self.group) for m in msgs] + [dist.P2POp(dist.irecv, b[0], 0, self.group) for b in bufs]
+            elif rank == self.dst:
                 bufs = [[m if r == rank else _like(m, sizes[r]) for r in range(world)] for m in msgs]
                 ops = [dist.P2POp(dist.irecv, b[r], r, self.group) for b in bufs for r in range(world) if r != rank]
             else:
@@ -139,7 +163,7 @@ class TrajectoryGather:
 
     def finish(self):
         """Learner: (records, frames) gathered over ranks (dim 1) and slices (dim 0); other ranks: None."""
-        pend, self._pending = self._pending, []
+        pend, self._pending, self._sizes = self._pending, [], None
         if not pend:
             return None
         if not self._active():
@@ -187,7 +211,7 @@ class TrajectoryGather:
         return None if ev is None else float(ev[0].elapsed_time(ev[1]))
 
     def __call__(self, slab):                                    # the plain-callable protocol: one slab, one slice, list of parts
-        return gather_to_learner(slab, self.dst, self.group)
+        return gather_to_learner(slab, self.dst, self.group, self.total_envs)
 
 
 def broadcast_model(model, src=0, group=None, device=None):

@@ -28,6 +28,20 @@ import numpy as np
 # ---------------------------------------------------------------------------------------------------------------------------
 # built-in stand-ins (gymnasium is not part of this build)
 # ---------------------------------------------------------------------------------------------------------------------------
+_RS = None
+
+
+def _seeded_uniform4(seed):
+    """np.random.RandomState(seed).uniform(-0.05, 0.05, size=4), value for value, from ONE reseeded generator object per process:
+    constructing a RandomState costs ~130 us (it first seeds itself from the OS), reseeding one ~5 us -- with thousands of envs
+    the resets of finished games were most of a step."""
+    global _RS
+    if _RS is None:
+        _RS = np.random.RandomState(0)
+    _RS.seed(seed)
+    return _RS.uniform(-0.05, 0.05, size=4)
+
+
 class HostCartPole:
     """One CartPole-v1 shaped game on the host behind the gym call shape (reset(seed=) -> (obs, info); step(a) -> (obs,
     reward, terminated, truncated, info)): float64 Euler physics with CartPole-v1's published constants, the arithmetic
@@ -39,7 +53,7 @@ class HostCartPole:
         self.state = None
 
     def reset(self, seed=None):
-        self.state = np.random.RandomState(seed).uniform(-0.05, 0.05, size=4)
+        self.state = _seeded_uniform4(seed)
         return self.state.astype(np.float32), {}
 
     def step(self, action):
@@ -57,6 +71,58 @@ class HostCartPole:
 
     def close(self):
         pass
+
+    @classmethod
+    def make_batch(cls, envs):
+        """The batched-slice protocol (HostSlice): one object stepping all of a slice's envs with array arithmetic."""
+        return CartPoleBatch(envs)
+
+
+class CartPoleBatch:
+    """HostCartPole.step for a whole slice at once: the state of the slice's n envs is ONE [n][4] float64 array (every env
+    object's `state` becomes a row view of it) and a step is ~40 numpy operations whatever n is, instead of n Python calls of
+    ~4 us.  Operation by operation the arithmetic of HostCartPole.step (same association, same numpy cos / sin), so the
+    results are identical env by env -- the per-env path is the checker (tests/test_host_envs.py).
+
+    The protocol a HostSlice asks of an env class (`make_batch(envs)` defined ON the class itself: a subclass that overrides
+    step() without its own make_batch is stepped env by env):
+        reset_one(i, seed) -> observation of env i after reset(seed=seed)
+        step_batch(actions int64 [n], go bool [n]) -> (obs [n][...], reward float64 [n], terminated bool [n], illegal bool [n])
+            steps the envs with go[i] set; an env whose action is illegal does not move and is reported in `illegal`;
+            rows of envs that did not move are unspecified."""
+
+    def __init__(self, envs):
+        self.envs = list(envs)
+        self.state = np.zeros((len(self.envs), 4))
+        for i, e in enumerate(self.envs):
+            if e.state is not None:
+                self.state[i] = e.state
+            e.state = self.state[i]                           # a view: render() and friends keep seeing the env's state
+
+    def reset_one(self, i, seed):
+        self.state[i] = _seeded_uniform4(seed)
+        return self.state[i].astype(np.float32)
+
+    def step_batch(self, actions, go):
+        illegal = go & (actions != 0) & (actions != 1)
+        move = go & ~illegal
+        idx = np.nonzero(move)[0]
+        n = len(self.envs)
+        obs, reward, term = np.empty((n, 4), np.float32), np.zeros(n), np.zeros(n, bool)
+        if len(idx):
+            s = self.state[idx]
+            x, xd, th, thd = s[:, 0], s[:, 1], s[:, 2], s[:, 3]
+            force = np.where(actions[idx] == 1, 10.0, -10.0)
+            ct, sn = np.cos(th), np.sin(th)
+            temp = (force + 0.05 * thd * thd * sn) / 1.1
+            tha = (9.8 * sn - ct * temp) / (0.5 * (4.0 / 3.0 - 0.1 * ct * ct / 1.1))
+            xa = temp - 0.05 * tha * ct / 1.1
+            new = np.stack([x + 0.02 * xd, xd + 0.02 * xa, th + 0.02 * thd, thd + 0.02 * tha], 1)
+            self.state[idx] = new
+            obs[idx] = new.astype(np.float32)
+            reward[idx] = 1.0
+            term[idx] = (np.abs(new[:, 0]) > 2.4) | (np.abs(new[:, 2]) > 12 * 2 * np.pi / 360)
+        return obs, reward, term, illegal
 
 
 class HostCartPoleRender(HostCartPole):
@@ -191,7 +257,7 @@ class HostSlice:
       * on_end "mask": a finished env is switched off (`active`); "reset": it is reset at once -- `obs` gets the fresh
         observation for the next search, `rec` keeps the post-step one for the record and `ended` marks the row."""
 
-    def __init__(self, envs, lo, adapter, arrays, action_map, env_seed, limit, on_end, first_env):
+    def __init__(self, envs, lo, adapter, arrays, action_map, env_seed, limit, on_end, first_env, batch=True):
         self.envs, self.lo, self.n = list(envs), int(lo), len(envs)
         self.adapter, self.action_map = adapter, list(action_map)
         self.env_seed, self.limit, self.on_end, self.first_env = int(env_seed), int(limit), on_end, int(first_env)
@@ -201,10 +267,27 @@ class HostSlice:
         self.step_count = np.zeros(self.n, np.int64)
         self.episode = np.zeros(self.n, np.int64)
         self.done = np.zeros(self.n, bool)
+        self.batch = self._make_batch() if batch else None
+
+    def _make_batch(self):
+        """The slice's batch stepper, when its envs offer one (CartPoleBatch documents the protocol): all envs of ONE class that
+        defines make_batch itself, plain vector observations, an integer action map."""
+        if not self.envs or not isinstance(self.adapter, VectorAdapter) or self.adapter.transform is not None:
+            return None
+        cls = type(self.envs[0])
+        if any(type(e) is not cls for e in self.envs) or "make_batch" not in vars(cls):
+            return None
+        if not all(isinstance(a, (int, np.integer)) and not isinstance(a, bool) for a in self.action_map):
+            return None
+        self._amap = np.asarray(self.action_map, np.int64)
+        return cls.make_batch(self.envs)
 
     def _reset_one(self, i):
         seed = self.env_seed + self.first_env + self.lo + i + 1000003 * int(self.episode[i])
-        self.obs[i] = self.adapter.observe(self.envs[i], self.envs[i].reset(seed=seed))
+        if self.batch is not None:
+            self.obs[i] = np.asarray(self.batch.reset_one(i, seed), np.float32).reshape(-1)
+        else:
+            self.obs[i] = self.adapter.observe(self.envs[i], self.envs[i].reset(seed=seed))
         self.step_count[i] = 0
         self.done[i] = False
 
@@ -215,7 +298,43 @@ class HostSlice:
         self.active[:] = 1
         self.ended[:] = 0
 
+    def _step_all_batch(self):
+        """step_all's rules (below, env by env) as array operations around ONE batch.step_batch call."""
+        n, limit = self.n, self.limit
+        live = self.active.astype(bool)
+        acts = self.action.astype(np.int64)
+        in_map = (acts >= 0) & (acts < len(self._amap))       # (amap[acts[i]] raising IndexError is an illegal move too)
+        mapped = self._amap[np.where(in_map, acts, 0)]
+        seen, r, term, illegal = self.batch.step_batch(mapped, live & in_map)
+        illegal = live & (illegal | ~in_map)
+        moved = live & ~illegal
+        count = self.step_count
+        lim = float(limit) if limit > 0 else float("inf")
+        if illegal.any():                                     # game.py:123-131: the observation stays, termination flag unchanged
+            r = np.where(illegal, np.minimum(np.minimum(-count.astype(np.float64), -lim), -1.0), r)
+            term = np.where(illegal, self.done, term)
+        count[live] += 1
+        f = np.where((limit > 0) & (count == limit), 2, np.where(term, 1, 0)).astype(np.uint8)
+        self.done[live] = (term & (f != 2))[live]
+        self.reward[:] = np.where(live, r, 0.0)
+        self.flag[:] = np.where(live, f, 3)
+        self.ended[:] = 0
+        if moved.any():
+            self.obs[moved] = np.asarray(seen, np.float32).reshape(n, -1)[moved]
+        over = np.nonzero(live & (f != 0))[0]
+        if len(over):
+            if self.on_end == "reset":
+                self.rec[over] = self.obs[over]
+                self.ended[over] = 1
+                self.episode[over] += 1
+                for i in over.tolist():
+                    self._reset_one(i)
+            else:
+                self.active[over] = 0
+
     def step_all(self):
+        if self.batch is not None:
+            return self._step_all_batch()
         envs, amap, observe = self.envs, self.action_map, self.adapter.observe
         acts, rew, flag, active, ended = self.action.tolist(), self.reward, self.flag, self.active, self.ended
         obs, rec, count = self.obs, self.rec, self.step_count
@@ -288,11 +407,17 @@ def map_arrays(buf, B, row, dtype, workers):
                ended=np.frombuffer(buf, np.uint8, B, lay["ended"]),
                obs=np.frombuffer(buf, dtype, B * row, lay["obs"]).reshape(B, row),
                rec=np.frombuffer(buf, dtype, B * row, lay["rec"]).reshape(B, row))
-    # control page: int32 words [GO] step sequence (futex), [NOTIFY] completion bell (futex); int64 slots [1] command,
-    # [8 + w] sequence number worker w has finished (-1: attached, nothing done yet)
+    # control page: int32 word [GO] step sequence (futex, written by the parent); int64 slot [1] command; int32 words
+    # [done_word(w)] sequence number worker w has finished (-1: attached, nothing done yet) -- written by worker w ONLY, and the
+    # futex word the parent sleeps on while that worker is the one it is waiting for
     ctrl = np.frombuffer(buf, np.int64, CTRL_BYTES // 8, 0)
-    assert 8 + workers <= ctrl.size
+    assert done_word(workers) <= CTRL_BYTES // 4
     return arr, ctrl, lay
+
+
+def done_word(w):
+    """int32 index (control page) of worker w's `done` word: one 64-byte line per worker (no false sharing between workers)."""
+    return 64 + 16 * w
 
 
 def control_words(buf):
@@ -326,8 +451,13 @@ class SharedBlock:
 # is burnt by every spinner, and throttling then stalls everybody -- measured: 16 spinning workers 1.9 ms per step, 64 workers
 # 6.0 ms, 128 workers 12.4 ms.  Waiters sleep in the kernel on a 32-bit word of the shared control page instead (futex: a
 # syscall only when there is something to wait for or somebody to wake) after a spin of a few microseconds.
-#   word GO     (ctrl32[0]) step sequence number, written by the parent; workers wait for it to change
-#   word NOTIFY (ctrl32[2]) bumped by every worker that finishes; the parent waits for it to change, then looks at the flags
+#   word GO            (ctrl32[0]) step sequence number, written by the parent; workers wait for it to change
+#   word done_word(w)  the sequence number worker w has finished: ONE writer per word (a bell word that every worker
+#                      incremented was a non-atomic read-modify-write across processes and could go backwards, sending the parent
+#                      into a full 10 ms time-out).  The parent sleeps on the word of the first worker that is not done yet.
+# The store of a done word is a release store and the parent's read an acquire load (libsmzhost.so, smzh_store_release_i32 /
+# smzh_load_acquire_i32) so that a worker's rows are visible before its done word on every architecture; without the library
+# (not built) plain numpy stores are used, which is enough on x86's total store order.
 import platform  # noqa: E402
 
 # SYS_futex of this machine (None: unknown architecture -> waiters fall back to short sleeps); shared (not PRIVATE) futexes: the
@@ -369,7 +499,40 @@ def futex_wake_all(words, index):
     _futex(words.ctypes.data + 4 * index, _FUTEX_WAKE, 0x7fffffff)
 
 
-GO, NOTIFY = 0, 4                                       # int32 word indices into the control page (= int64 slots 0 and 2; slot 1 is the command)
+GO = 0                                                  # int32 word index into the control page (int64 slot 1 is the command)
+_sync_lib = False
+
+
+def _sync():
+    """libsmzhost.so's release / acquire helpers, or None when the library is not there."""
+    global _sync_lib
+    if _sync_lib is False:
+        _sync_lib = None
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsmzhost.so")
+        if os.path.exists(path):
+            try:
+                lib = ctypes.CDLL(path)
+                lib.smzh_store_release_i32.restype = None
+                lib.smzh_store_release_i32.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+                lib.smzh_load_acquire_i32.restype = ctypes.c_int32
+                lib.smzh_load_acquire_i32.argtypes = [ctypes.c_void_p]
+                _sync_lib = lib
+            except (OSError, AttributeError):
+                _sync_lib = None
+    return _sync_lib
+
+
+def store_release(words, index, value):
+    lib = _sync()
+    if lib is None:
+        words[index] = value
+    else:
+        lib.smzh_store_release_i32(words.ctypes.data + 4 * index, int(value))
+
+
+def load_acquire(words, index):
+    lib = _sync()
+    return int(words[index]) if lib is None else int(lib.smzh_load_acquire_i32(words.ctypes.data + 4 * index))
 
 
 def worker_main(spec_path):
@@ -384,11 +547,12 @@ def worker_main(spec_path):
     arr, ctrl, _ = map_arrays(mm, spec["B"], spec["row"], spec["dtype"], spec["workers"])
     envs = [build_env(e) for e in spec["envs"]]
     sl = HostSlice(envs, spec["lo"], spec["adapter"], arr, spec["action_map"], spec["env_seed"], spec["limit"], spec["on_end"],
-                   spec["first_env"])
+                   spec["first_env"], batch=spec.get("batch", True))
     words = control_words(mm)
     w, parent = spec["worker"], spec["parent_pid"]
     seq = 0
-    ctrl[8 + w] = -1                                       # attached (the parent waits for every worker's -1 -> then unlinks the file)
+    mine = done_word(w)
+    store_release(words, mine, -1)                         # attached (the parent waits for every worker's -1 -> then unlinks the file)
     try:
         while True:
             futex_wait_change(words, GO, seq, timeout_s=0.25, spin=spec.get("spin", 50))
@@ -396,7 +560,7 @@ def worker_main(spec_path):
                 if os.getppid() != parent:                 # an orphaned worker exits instead of waiting for ever
                     break
                 continue
-            seq = int(words[GO])
+            seq = load_acquire(words, GO)
             cmd = int(ctrl[1])
             if cmd == CMD_EXIT:
                 break
@@ -404,9 +568,8 @@ def worker_main(spec_path):
                 sl.reset_all()
             else:
                 sl.step_all()
-            ctrl[8 + w] = seq
-            words[NOTIFY] += 1                             # (racy across workers on purpose: any change rings the bell)
-            futex_wake_all(words, NOTIFY)
+            store_release(words, mine, seq)                # (this worker's own word: no read-modify-write shared with others)
+            futex_wake_all(words, mine)
     finally:
         sl.close()
     return 0

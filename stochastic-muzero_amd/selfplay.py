@@ -247,17 +247,28 @@ def chunk_to_records(chunk_data, obs_dim, A, discount, priority_scale=1, limit_o
     return job.finish(priority_scale, limit_of_game_play, keep_partial, observation_shape)
 
 
-_STAGING = {}
+class _StagingPool:
+    """Page-locked staging buffers for the transfers of RecordsJobs: one SET of buffers per open job (a process-wide
+    parity counter handed a third open job the first one's buffers).  A job acquires a set for its list of (shape, dtype)
+    in its constructor and releases it in finish(); released sets are kept for reuse, at most `keep` of them and only for the
+    most recent layouts (chunk shapes that no longer occur give their pinned memory back)."""
+
+    def __init__(self, keep=4, alloc=None):
+        self.keep, self.free = keep, []                   # free: [(layout, [buffers])], most recently released last
+        self.alloc = alloc or (lambda shape, dtype: torch.empty(shape, dtype=dtype, pin_memory=True))
+
+    def acquire(self, layout):
+        for i in range(len(self.free) - 1, -1, -1):
+            if self.free[i][0] == layout:
+                return self.free.pop(i)[1]
+        return [self.alloc(shape, dtype) for shape, dtype in layout]
+
+    def release(self, layout, bufs):
+        self.free.append((layout, bufs))
+        del self.free[:-self.keep]
 
 
-def _staging(shape, dtype, slot, index):
-    """Page-locked staging buffers for the transfers of a RecordsJob, two sets (job k + 2 reuses job k's); `index` tells the
-    arrays of one job apart (targets and priorities have the same shape and type)."""
-    key = (tuple(shape), dtype, slot & 1, index)
-    buf = _STAGING.get(key)
-    if buf is None:
-        buf = _STAGING[key] = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
-    return buf
+_STAGING = _StagingPool()
 
 
 class RecordsJob:
@@ -266,8 +277,7 @@ class RecordsJob:
     staging buffers, closed by an event.  finish() waits for that event only -- not for work enqueued later, e.g. the next
     iteration's search -- copies the staging buffers into arrays the records own, and builds the ArrayGameRecords.  Between the
     two a caller can enqueue more GPU work: the host half of iteration k then runs while the GPU searches iteration k + 1
-    (self_play_iterations).  At most two jobs may be open at a time (the staging buffers are double-buffered)."""
-    _count = 0
+    (self_play_iterations).  Every open job owns its staging buffers (_StagingPool); finish() (or close()) returns them."""
 
     def __init__(self, chunk_data, obs_dim, A, discount, td_steps=None, ignore_termination=False, after_end="drop",
                  observations=None):
@@ -275,8 +285,6 @@ class RecordsJob:
         self.ignore_termination, self.after_end = ignore_termination, after_end
         td = 0 if td_steps is None else int(td_steps)
         _, target, err, game_end = chunk_targets(chunk_data, self.o, A, discount, td, ignore_termination, after_end, return_game_end=True)
-        slot = RecordsJob._count
-        RecordsJob._count += 1
         # env-major on the device (a game's rows become one contiguous window), then to the host
         dev = [chunk_data.permute(1, 0, 2).contiguous(), game_end.t().contiguous()]
         if td_steps is not None:
@@ -290,7 +298,8 @@ class RecordsJob:
             else:
                 dev.append(frames)
         self.has_obs = observations is not None and self.big_obs is None
-        self.host = [_staging(d.shape, d.dtype, slot, i) for i, d in enumerate(dev)]
+        self._layout = tuple((tuple(d.shape), d.dtype) for d in dev)
+        self.host = _STAGING.acquire(self._layout)
         for h, d in zip(self.host, dev):
             h.copy_(d, non_blocking=True)
         self.event = torch.cuda.Event()
@@ -298,15 +307,24 @@ class RecordsJob:
         self._dev = dev                                    # (kept alive until the copies have run)
 
     def finish(self, priority_scale=1, limit_of_game_play=float("inf"), keep_partial=True, observation_shape=None):
+        assert self.host is not None, "RecordsJob.finish() called twice"
         self.event.synchronize()
         self._dev = None
         arrays = [h.numpy().copy() for h in self.host[:4 if self.td_steps is not None else 2]]      # the records own these
         rec, game_end = arrays[0], arrays[1]
         target, err = (arrays[2], arrays[3]) if self.td_steps is not None else (None, None)
         observations = self.host[-1].clone() if self.has_obs else self.big_obs
+        self.close()
         return records_from_host_copy(rec, game_end, self.o, self.A, self.discount, priority_scale, limit_of_game_play,
                                       self.ignore_termination, keep_partial, self.after_end, observations, observation_shape,
                                       self.td_steps, target, err)
+
+    def close(self):
+        """Returns the staging buffers (after the copies into them have run); finish() does it by itself."""
+        if self.host is not None:
+            self.event.synchronize()
+            _STAGING.release(self._layout, self.host)
+            self.host = self._dev = None
 
 
 def records_from_host_copy(rec, game_end, obs_dim, A, discount, priority_scale=1, limit_of_game_play=float("inf"),
@@ -760,20 +778,34 @@ def self_play_iterations(env, model, mcts, temperature, steps, iterations, repla
 
 
 def _reward_sums(games):
-    """[sum(game.rewards) for game in games] for ArrayGameRecords without touching their lists: one sequential cumulative sum
-    per env over the shared host copy (bit-identical to Python's left-to-right sum for a game that starts at the chunk's first
-    row, within an ulp for later games of the env).  Records whose reward list became a real list are summed the slow way."""
-    out, cs = [], {}
-    for g in games:
+    """[sum(game.rewards) for game in games] for ArrayGameRecords without touching their lists, bit for bit Python's
+    left-to-right sum: the windows of one shared host copy are accumulated together, step k of every game that has one in one
+    vector add (games ordered by length, so step k touches a prefix).  A window is never combined with another game's rows: a
+    non-finite reward (the reference's illegal-move reward is -inf when limit_of_game_play is unlimited) stays in its own game
+    (differences of a per-env cumulative sum turned inf - inf into nan for every later game of the env).  Records
+    whose reward list became a real list are summed the slow way."""
+    out = [None] * len(games)
+    by_src = {}
+    for i, g in enumerate(games):
         if isinstance(g, ArrayGameRecord) and g._pristine("rewards"):
-            src = g._src
-            c = cs.get(id(src))
-            if c is None:
-                c = cs[id(src)] = np.cumsum(src.rec[:, :, src.o], axis=1)
-            row = c[g._e]
-            out.append(float(row[g._t1 - 1] - (row[g._t0 - 1] if g._t0 else 0.0)) if g._t1 > g._t0 else 0.0)
+            by_src.setdefault(id(g._src), (g._src, []))[1].append(i)
         else:
-            out.append(sum(g.rewards))
+            out[i] = sum(g.rewards)
+    for src, idx in by_src.values():
+        T = src.rec.shape[1]
+        col = np.ascontiguousarray(src.rec[:, :, src.o]).reshape(-1)
+        lo = np.array([games[i]._e * T + games[i]._t0 for i in idx], np.int64)
+        n = np.array([max(0, games[i]._t1 - games[i]._t0) for i in idx], np.int64)
+        order = np.argsort(-n, kind="stable")
+        lo_s, n_s = lo[order], n[order]
+        acc = np.zeros(len(idx))
+        alive = len(idx) - np.searchsorted(n_s[::-1], np.arange(1, (int(n_s[0]) if len(n_s) else 0) + 1), side="left")
+        for k, m in enumerate(alive.tolist()):                 # m games have a step k
+            acc[:m] += col[lo_s[:m] + k]
+        sums = np.empty(len(idx))
+        sums[order] = acc
+        for j, i in enumerate(idx):
+            out[i] = float(sums[j])
     return out
 
 

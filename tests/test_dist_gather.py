@@ -141,6 +141,82 @@ def test_sliced_compact_trajectory_gather_world_size_2(tmp_path):
     assert os.path.exists(os.path.join(tmp_path, "ok.pt"))
 
 
+def _resize_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import stochastic_muzero_amd  # noqa: F401
+    g = import_module("stochastic-muzero_amd.gather")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from datetime import timedelta
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=60))
+    o, A, T = 4, 2, 4
+    # 9 envs (shards 4 | 5), then 8 (4 | 4): rank 0's local size does not change, rank 1's does
+    for use_total in (False, True):
+        for total in (9, 8, 9):
+            full = _record(T, total, o, A, total)
+            lo, hi = g.shard_range(total, rank, world)
+            parts = g.gather_to_learner(full[:, lo:hi].contiguous(), total_envs=total if use_total else None)
+            if rank == 0:
+                assert torch.equal(torch.cat(parts, 1), full), (use_total, total)
+        tg = g.TrajectoryGather(o, A, slices=2)                  # ONE object, chunks of different widths
+        for total in (9, 8):
+            full = _record(T, total, o, A, 100 + total)
+            lo, hi = g.shard_range(total, rank, world)
+            tg.total_envs = total if use_total else None
+            tg.start(full[:2, lo:hi]); tg.start(full[2:, lo:hi])
+            got = tg.finish()
+            if rank == 0:
+                assert torch.equal(got[0], full), (use_total, total)
+    # a slab that is not this rank's shard of the stated total fails before anything is posted (on every rank alike)
+    with pytest.raises(ValueError):
+        g.gather_to_learner(torch.zeros(T, 3, 5, dtype=torch.float64), total_envs=10)
+    if rank == 0:
+        torch.save(torch.ones(1), os.path.join(out_dir, "ok.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gathers_for_different_env_totals_in_one_process_stay_in_step(tmp_path):
+    """the size exchange was cached under the LOCAL shard size, so after a 9-env gather an 8-env one
+    deadlocked (rank 0: cache hit, irecv for a stale 5-env buffer; rank 1: all_gather).  Now every rank either derives the
+    sizes from the job's total or enters the size exchange on every call."""
+    port = 25500 + (os.getpid() % 2000)
+    mp.spawn(_resize_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "ok.pt"))
+
+
+def _loopback_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import stochastic_muzero_amd  # noqa: F401
+    g = import_module("stochastic-muzero_amd.gather")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    T, B, o, A = 6, 5, 4, 2
+    full = _record(T, B, o, A, 3)
+    frames = torch.arange(T * B * 6, dtype=torch.float32).reshape(T, B, 6)
+    for compact in (True, False):
+        tg = g.TrajectoryGather(o, A, slices=3, compact=compact, loopback=True, total_envs=B)
+        for k in range(3):
+            tg.start(full[2 * k:2 * k + 2], frames[2 * k:2 * k + 2])
+        got = tg.finish()
+        assert torch.equal(got[0], full) and torch.equal(got[1], frames)
+        assert got[0].data_ptr() != full.data_ptr()
+    plain = g.TrajectoryGather(o, A, slices=3)                   # world of one without the switch: pass-through
+    plain.start(full)
+    assert torch.equal(plain.finish()[0], full)
+    torch.save(torch.ones(1), os.path.join(out_dir, "ok.pt"))
+    dist.destroy_process_group()
+
+
+def test_loopback_exchange_in_a_world_of_one(tmp_path):
+    """The `loopback` switch of TrajectoryGather (the single-GPU RCCL test drives it with the nccl backend): a world of one
+    still packs, 'sends', 'receives' and reassembles."""
+    port = 23500 + (os.getpid() % 2000)
+    mp.spawn(_loopback_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "ok.pt"))
+
+
 def test_compact_wire_format_is_lossless_and_smaller():
     sys.path.insert(0, ROOT)
     import stochastic_muzero_amd  # noqa: F401

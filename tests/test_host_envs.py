@@ -150,7 +150,7 @@ def test_host_library_exports_what_its_header_declares():
     lib = ctypes.CDLL(os.path.join(ROOT, "stochastic-muzero_amd", "libsmzhost.so"))
     for n in names:
         getattr(lib, n)
-    assert lib.smzh_abi_version() == 1
+    assert lib.smzh_abi_version() == 2
     lib.smzh_gather_taps_u8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     out = np.zeros(12, np.uint8)
@@ -163,3 +163,53 @@ def test_host_library_exports_what_its_header_declares():
     out = np.full(4 * 5 * 3 + 8, 0xEE, np.uint8)
     assert lib.smzh_gather_taps_u8(fr.ctypes.data, 5, 7, iy.ctypes.data, 4, ix.ctypes.data, 5, out[4:].ctypes.data) == 0
     assert np.array_equal(out[4:-4].reshape(4, 5, 3), fr[np.ix_(iy, ix)]) and (out[:4] == 0xEE).all() and (out[-4:] == 0xEE).all()
+
+
+@pytest.mark.parametrize("on_end,limit", [("reset", 5), ("mask", 7), ("reset", 0), ("mask", 0)])
+def test_batched_slice_stepping_equals_the_per_env_path_env_by_env(on_end, limit):
+    """envs whose class offers make_batch (host_envs.CartPoleBatch) are stepped with array arithmetic, a
+    slice at a time; the per-env loop (batch_step=False) is the checker.  Action 2 maps to an illegal env action (the
+    illegal-move rule, game.py:123-131), action 3 lies outside the action map; long runs so that games end and restart."""
+    envs_mod, he = _envs(), _he()
+    B, T = 37, 60
+    res = []
+    for batch_step, workers in ((False, 0), (True, 0), (True, 3)):
+        env = envs_mod.HostVecEnv([he.HostCartPole for _ in range(B)], 4, 3, "cpu", action_map=[0, 1, 7], env_seed=5, limit=limit,
+                                  on_end=on_end, first_env=40, workers=workers, batch_step=batch_step)
+        try:
+            assert workers or (env._slice.batch is not None) == batch_step
+            r = np.random.RandomState(9)
+            out = [env.reset().clone()]
+            for t in range(T):
+                a = r.choice([0, 1, 2, 3], env.B, p=[0.46, 0.46, 0.05, 0.03]).astype(np.int32)
+                obs, rew, flag = env.step(torch.from_numpy(a))
+                out.append((obs.clone(), rew.clone(), flag.clone(), env.record_obs.clone(),
+                            None if env.active is None else env.active.clone()))
+            res.append(out)
+        finally:
+            env.close()
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0])
+        for t, (a, b) in enumerate(zip(res[0][1:], other[1:])):
+            for k, (x, y) in enumerate(zip(a, b)):
+                assert (x is None and y is None) or torch.equal(x, y), (t, k)
+    flags = torch.stack([s[2] for s in res[0][1:]])
+    rewards = torch.stack([s[1] for s in res[0][1:]])
+    assert (rewards < 0).any() and ((flags == 2).any() or limit == 0) and ((flags == 1).any() or limit > 0)
+    if limit == 0:
+        assert torch.isinf(rewards).any()                      # unlimited game length: the reference's -inf illegal-move reward
+
+
+def test_a_subclass_that_overrides_step_is_not_stepped_by_its_parents_batch():
+    he = _he()
+    arrays = {n: np.zeros((4,) + s, d) for n, s, d in (("action", (), np.int32), ("reward", (), np.float32), ("flag", (), np.uint8),
+                                                        ("active", (), np.uint8), ("ended", (), np.uint8), ("obs", (4,), np.float32),
+                                                        ("rec", (4,), np.float32))}
+    mk = lambda envs, **kw: he.HostSlice(envs, 0, he.VectorAdapter(4), arrays, [0, 1], 0, 0, "reset", 0, **kw)     # noqa: E731
+    assert mk([Picky() for _ in range(4)]).batch is None
+    assert mk([he.HostCartPole() for _ in range(4)]).batch is not None
+    assert mk([he.HostCartPole() for _ in range(3)] + [Picky()]).batch is None           # mixed classes: env by env
+    assert mk([he.HostCartPole() for _ in range(4)], batch=False).batch is None
+    sl = mk([he.HostCartPole() for _ in range(4)])
+    sl.reset_all()
+    assert all(e.state.base is sl.batch.state for e in sl.envs)                          # the env objects see the batch's state

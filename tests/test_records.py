@@ -279,3 +279,56 @@ def test_random_chunks_cut_the_same_way_as_the_checker(seed):
     assert len(want) == len(got)
     for a, b in zip(want, got):
         same_game(a, b, 3)
+
+
+def test_reward_sums_are_pythons_sums_game_by_game_even_with_non_finite_rewards():
+    """the per-game reward sums learning_cycle averages are sum(game.rewards) bit for bit, and a -inf reward (the
+    reference's illegal-move reward with an unlimited game length, game.py:123-131) stays inside its own game."""
+    sp = _sp()
+    d = make_chunk(14, 7, 4, 3, seed=3, p_end=0.25)
+    d[..., 4] += np.random.RandomState(0).rand(14, 7) * 1e-3             # rewards whose sum depends on the order of addition
+    d[2, 3, 4] = -np.inf                                                # one illegal move in env 3's first game
+    d[5, 1, 4] = np.inf
+    want, got = build(d, 4, 3, after_end="new_game")
+    sums = sp._reward_sums(got)
+    assert len(sums) == len(want) > 7
+    for g, s in zip(want, sums):
+        ref = sum(g.rewards)
+        assert (s == ref) or (np.isnan(s) and np.isnan(ref)), (s, ref)
+    assert sum(np.isinf(s) for s in sums) == 2 and not any(np.isnan(s) for s in sums)
+    # records whose list became a real list take the slow path and agree
+    got[0].rewards.append(1.5)
+    assert sp._reward_sums(got)[0] == sum(got[0].rewards)
+
+
+def test_make_priority_returns_an_array_the_caller_may_overwrite():
+    """ReplayBuffer.update_value writes prio_position[game][h] in place (replay_buffer.py:222); the array a record
+    hands out must not be a view of the chunk-wide priorities."""
+    d = make_chunk(12, 5, 4, 3, seed=11)
+    want, got = build(d, 4, 3, after_end="new_game")
+    g = got[0]
+    first, top = g.make_priority(5)
+    keep = first.copy()
+    first[:] = 123.0                                                    # what update_value does
+    again, top2 = g.make_priority(5)
+    assert np.array_equal(again, keep) and top2 == top
+    assert np.array_equal(want[0].make_priority(5)[0], keep)
+
+
+def test_every_open_records_job_owns_its_staging_buffers():
+    """three jobs open at once (a pipelined iteration + an evaluation chunk of the same shape) must not share
+    page-locked buffers; released sets are reused, and at most `keep` idle sets stay allocated."""
+    sp = _sp()
+    made = []
+    pool = sp._StagingPool(keep=2, alloc=lambda shape, dtype: made.append(shape) or torch.empty(shape, dtype=dtype))
+    lay = (((4, 3), torch.float64), ((4,), torch.int32))
+    a, b, c = pool.acquire(lay), pool.acquire(lay), pool.acquire(lay)
+    ptrs = {t.data_ptr() for s in (a, b, c) for t in s}
+    assert len(ptrs) == 6 and len(made) == 6
+    pool.release(lay, a)
+    assert pool.acquire(lay) is a and len(made) == 6                    # reused, nothing new allocated
+    other = (((2, 2), torch.float32),)
+    x = pool.acquire(other)
+    for s, l in ((a, lay), (b, lay), (c, lay), (x, other)):
+        pool.release(l, s)
+    assert len(pool.free) == 2 and pool.free[-1][0] == other            # bounded: the oldest idle sets are dropped
