@@ -47,6 +47,8 @@ WORKLOADS = {
     # name: (weights fixture, env kind, obs, A, K, sims)
     "cartpole_mlp_4096x50": dict(weights="weights_ckpt421.npz", env="cartpole", obs=4, A=2, K=2, sims=50, envs=4096),
     "lunarlander_mlp_4096x50": dict(weights="weights_lunar_L0.npz", env="synthetic", obs=8, A=4, K=2, sims=50, envs=4096),
+    # SURVEY 8d(3)'s stress variant: every expansion keeps all four actions (N = 1 + 4 + 50 x 4 = 205 nodes per tree)
+    "lunarlander_mlp_4096x50_K4": dict(weights="weights_lunar_L0.npz", env="synthetic", obs=8, A=4, K=4, sims=50, envs=4096),
     "cartpole_mlp_4096x100": dict(weights="weights_ckpt421.npz", env="cartpole", obs=4, A=2, K=2, sims=100, envs=4096),
     # the reference's ResNet-v2 vision family (random init, L=1), 98x98x3 frames, hidden 3x7x7; heads =
     # smz_vision_initial / smz_vision_recurrent between the HIP tree kernels, one HIP graph per env step
@@ -127,28 +129,10 @@ def algorithmic_bytes(stats, A, K, S, launches):
 
 
 def host_cores():
-    """Cores this process can actually USE: its affinity mask, capped by the container's CPU quota (cgroup v2 cpu.max / v1
-    cfs_quota_us) -- the bench box shows 256 hardware threads and grants 16 CPUs' worth of time; threads beyond the quota only
-    get the others throttled."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    quota = None
-    try:
-        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            quota = int(q) / int(period)
-    except (OSError, ValueError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            if q > 0:
-                quota = q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-        except (OSError, ValueError):
-            pass
-    if quota:
-        n = max(1, min(n, int(quota + 0.5)))
-    return n
+    """Cores this process can actually USE (affinity mask capped by the cgroup CPU quota): host_envs.usable_cores."""
+    from importlib import import_module
+    import stochastic_muzero_amd  # noqa: F401
+    return import_module("stochastic-muzero_amd.host_envs").usable_cores()
 
 
 def cpu_baseline_mlp(wl, weights_path, seconds_target=15.0):
@@ -264,7 +248,17 @@ def self_launch(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0 and args.gather_mode == "overlapped":
+        # The overlapped exchange's failure modes under RCCL are mostly not Python exceptions (an abort, or a hang that the
+        # process-group timeout turns into one): nothing inside a rank can fall back then, but this launcher can -- one more
+        # run with the plain, synchronous gather, and the line it prints says so (timing.gather_overlap.mode.kind = "plain").
+        print(f"bench.py: the {args.gpus}-rank run exited with status {rc}; running again with --gather-mode plain", file=sys.stderr)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            cmd[cmd.index("--master-port") + 1] = str(s.getsockname()[1])
+        rc = subprocess.call(cmd + ["--gather-mode", "plain"], env=env)
+    return rc
 
 
 def main():
@@ -283,7 +277,7 @@ def main():
     ap.add_argument("--stepwise", action="store_true", help="never use the single-launch search kernel")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SMZ_STREAM_GROUPS", "0")),
                     help="independent env groups per GPU, each on its own HIP stream (0 = 2 groups from 262 144 envs on -- "
-                         "one group's tree kernel overlaps the other's network kernel: +6..14 % measured -- else 1)")
+                         "one group's tree kernel overlaps the other's network kernel: +6..14 %% measured -- else 1)")
     ap.add_argument("--min-timed-seconds", type=float, default=10.0,
                     help="repeat the K-step block until this much is timed (default 10 s: ~1400 blocks of the headline workload, so "
                          "that the timed region is the larger part of the command's run time)")
@@ -308,6 +302,15 @@ def main():
                          "0 = step the envs serially in this process)")
     ap.add_argument("--gather-slices", type=int, default=4,
                     help="N > 1: parts a K-step block's trajectory gather is cut into (each part's transfer overlaps the next part's search)")
+    ap.add_argument("--gather-mode", default=os.environ.get("SMZ_GATHER_MODE", "overlapped"), choices=["overlapped", "plain"],
+                    help="N > 1: overlapped = sliced side-stream exchange (gather.TrajectoryGather); plain = one synchronous grouped "
+                         "send / receive per chunk.  `python bench.py --gpus N` re-runs the ranks with plain if the overlapped run dies")
+    ap.add_argument("--rccl-loopback", action="store_true",
+                    help="ONE rank, but through everything the N > 1 line uses: an nccl (RCCL) process group of world size 1, the "
+                         "sliced trajectory gather with the rank sending to and receiving from itself, barrier / all_reduce / "
+                         "all_gather_object -- the multi-GPU code path on a single-GPU box (its own labelled line)")
+    ap.add_argument("--dist-timeout-seconds", type=float, default=300.0,
+                    help="process-group timeout: a collective that hangs ends as an error instead of stalling the run")
     ap.add_argument("--frame-upload", default="taps", choices=["taps", "frames"],
                     help="--host-env on the vision workload: upload only the pixels the 98x98 resize reads (taps) or whole frames")
     args = ap.parse_args()
@@ -333,16 +336,26 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    from datetime import timedelta
     backend = None
-    if world > 1:
+    multi = world > 1 or args.rccl_loopback          # the code path of the N > 1 line (a loopback run takes it with one rank)
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as s_:
+                    s_.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # "nccl" is RCCL on ROCm; it cannot place two ranks on one device, so a run with more ranks than GPUs (the
         # 1-GPU functional test of the N > 1 path) exchanges through gloo and says so in its JSON line
         backend = os.environ.get("SMZ_DIST_BACKEND", "gloo" if shared_gpu else "nccl")
+        tmo = timedelta(seconds=args.dist_timeout_seconds)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     import stochastic_muzero_amd as smz  # noqa: F401
     from importlib import import_module
@@ -363,7 +376,7 @@ def main():
     lo = rank * B
     # the CPU leg runs FIRST (rank 0, N = 1 only, bounded wall time): the GPU part then fills the rest of the command's run time
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rccl_loopback:
         cpu_baseline = (cpu_baseline_vision(wl, model, args.cpu_baseline_seconds) if wl["env"] == "image"
                         else cpu_baseline_mlp(wl, wpath, args.cpu_baseline_seconds))
     T = max(args.steps, args.warmup, 1)
@@ -410,12 +423,12 @@ def main():
     env, heads, mcts = groups[0].env, groups[0].heads, groups[0].mcts
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     def max_over_ranks(x):
-        if world == 1:
+        if not multi:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -423,33 +436,29 @@ def main():
 
     # N > 1: the chunk is played in `--gather-slices` slices; every finished slice's rows go to rank 0 on a side stream (compact
     # wire format) while the next slice is searched (gather.TrajectoryGather) -- only the last slice's transfer is exposed
-    tg = gather_mod.TrajectoryGather(groups[0].chunk.rec_obs_dim, wl["A"], slices=args.gather_slices) if world > 1 else None
+    tg = gather_mod.TrajectoryGather(groups[0].chunk.rec_obs_dim, wl["A"], slices=args.gather_slices, total_envs=total,
+                                     loopback=args.rccl_loopback) if multi else None
     exposed = []
 
     def rows(chunks, name, t0, t1):
-        parts = [getattr(c, name)[t0:t1] for c in chunks]
+        parts = [getattr(c, name) for c in chunks]
+        if parts[0] is None:
+            return None
+        parts = [p[t0:t1] for p in parts]
         return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
-    gather_mode = {"kind": "overlapped"}
+    # (gather.ChunkExchange: slices + overlapped exchange, or -- mode "plain" -- the whole chunk with one synchronous grouped
+    #  send / receive; its warm_up() falls back to plain when the first overlapped exchange raises)
+    xch = gather_mod.ChunkExchange(tg, lambda n, t0: sp.play_games_grouped(groups, args.temperature, n, t0=t0), rows,
+                                   mode=args.gather_mode, total_envs=total,
+                                   log=lambda m: print("bench.py: " + m, file=sys.stderr)) if multi else None
+    gather_mode = xch.mode if xch is not None else {"kind": None}
 
     def play_and_gather(n):
         """n env steps of every group; with N > 1 in slices, each slice's rows handed to the overlapped gather."""
-        if tg is None:
+        if xch is None:
             return sp.play_games_grouped(groups, args.temperature, n)
-        if gather_mode["kind"] == "plain":         # (fallback, see the warm-up below) whole chunk, one synchronous grouped send / recv
-            chunks = sp.play_games_grouped(groups, args.temperature, n)
-            gather_mod.gather_to_learner(rows(chunks, "data", 0, n))
-            if chunks[0].obs is not None:
-                gather_mod.gather_to_learner(rows(chunks, "obs", 0, n))
-            return chunks
-        k = max(1, min(tg.slices, n))
-        cuts = [n * i // k for i in range(k + 1)]
-        for i in range(k):
-            chunks = sp.play_games_grouped(groups, args.temperature, cuts[i + 1] - cuts[i], t0=cuts[i])
-            tg.start(rows(chunks, "data", cuts[i], cuts[i + 1]),
-                     rows(chunks, "obs", cuts[i], cuts[i + 1]) if chunks[0].obs is not None else None)
-        tg.finish()
-        return chunks
+        return xch.run(n)[0]
 
     def timed_block():
         """EXACTLY K steps (+ the trajectory gather when N > 1) between two barrier + synchronize pairs; max over ranks."""
@@ -476,11 +485,11 @@ def main():
             if args.pipeline > 1:
                 n_games = 0
                 for games, _ in sp.self_play_iterations(env, model, mcts, args.temperature, args.steps, args.pipeline, replay_buffer=sink,
-                                                        gather=tg if world > 1 else None, ignore_termination=True):
+                                                        gather=tg if multi else None, ignore_termination=True):
                     n_games += len(games or ())
             else:
                 games, _ = sp.self_play_iteration(env, model, mcts, args.temperature, args.steps, replay_buffer=sink,
-                                                  gather=tg if world > 1 else None, ignore_termination=True)
+                                                  gather=tg if multi else None, ignore_termination=True)
                 n_games = len(games or ())
             barrier()
             dt_block = max_over_ranks(time.perf_counter() - t0)
@@ -499,23 +508,19 @@ def main():
     gc.collect()
     gc.freeze()
     gc.disable()
-    # W untimed warm-up steps (with N > 1 the first grouped send / recv builds the RCCL communicators here, outside the timed region)
-    try:
-        chunks = play_and_gather(max(1, args.warmup) if world > 1 else args.warmup)
-        torch.cuda.synchronize(dev)
-    except Exception as e:                         # the overlapped exchange has never met real RCCL (no multi-GPU box to build on):
-        if tg is None:                             # if its first use fails HERE, outside the timed region, fall back to the plain gather
-            raise
-        print(f"bench.py: overlapped trajectory gather failed at warm-up ({type(e).__name__}: {e}); using the plain gather", file=sys.stderr)
-        gather_mode.update(kind="plain", error=f"{type(e).__name__}: {e}")
-        tg._pending = []
-        chunks = play_and_gather(max(1, args.warmup))
+    # W untimed warm-up steps (with N > 1 the first grouped send / recv builds the RCCL communicators here, outside the timed
+    # region; if that first overlapped exchange RAISES, ChunkExchange.warm_up falls back to the plain gather)
+    if xch is not None:
+        chunks = xch.warm_up(max(1, args.warmup))[0]
+    else:
+        chunks = play_and_gather(args.warmup)
+    torch.cuda.synchronize(dev)
     first = timed_block()                                      # block 1 (timed like the others; also sizes R)
     R = int(min(args.max_blocks, max(1, np.ceil(args.min_timed_seconds / max(first, 1e-6)))))
     blocks = [first] + [timed_block() for _ in range(R - 1)]
     dt = float(np.median(blocks))
     per_rank_rate, ranks_seen, gather_ms = None, None, None
-    if world > 1:                                              # every rank's own rate of its last block, for the record
+    if multi:                                                  # every rank's own rate of its last block, for the record
         barrier()
         t0 = time.perf_counter()
         chunks = sp.play_games_grouped(groups, args.temperature, args.steps)
@@ -534,9 +539,9 @@ def main():
             barrier()
             t0 = time.perf_counter()
             if gather_mode["kind"] == "plain":
-                gather_mod.gather_to_learner(rows(chunks, "data", 0, args.steps))
+                gather_mod.gather_to_learner(rows(chunks, "data", 0, args.steps), total_envs=total)
             else:
-                tg.start(rows(chunks, "data", 0, args.steps), rows(chunks, "obs", 0, args.steps) if chunks[0].obs is not None else None)
+                tg.start(rows(chunks, "data", 0, args.steps), rows(chunks, "obs", 0, args.steps))
                 tg.finish()
             barrier()
             gts.append(max_over_ranks(time.perf_counter() - t0))
@@ -544,7 +549,7 @@ def main():
     block_steps = args.steps * (args.pipeline if args.end_to_end else 1)      # env steps inside one timed block
     sims_total = total * wl["sims"] * block_steps
     headline = (args.workload == "cartpole_mlp_4096x50" and B == 4096 and not args.host_env and args.rng == "mt19937"
-                and not args.end_to_end)
+                and not args.end_to_end and not args.rccl_loopback)
     single = getattr(mcts, "_single", None) is True
     data_note = {"cartpole": "synthetic (CartPole-shaped Euler env, fixed-length episodes; checkpoint-421 weights)",
                  "synthetic": "synthetic (N(0,1) observations of LunarLander width generated on the device; random-init weights, reference init rule)",
@@ -564,9 +569,11 @@ def main():
                       else f"host, Python envs (envs.HostVecEnv: {host_workers} worker processes for each of {G} env group(s) (sleeping on a futex while idle) writing into a page-locked shared block; action download + observation upload per step; "
                            "one group's search overlaps the other's host step)" if args.host_env else "device"),
               "host_workers": host_workers if args.host_env == "python" else None,
-              "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else "single GPU"}
-    if world > 1:
-        config["collective_backend"] = "nccl (RCCL)" if backend == "nccl" else f"{backend} ({world} ranks share {n_dev} GPU(s))"
+              "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else
+                              ("single GPU, trajectory gather to itself over RCCL (loopback)" if args.rccl_loopback else "single GPU")}
+    if multi:
+        config["collective_backend"] = ("nccl (RCCL)" if backend == "nccl" else f"{backend} ({world} ranks share {n_dev} GPU(s))") + \
+            (" -- LOOPBACK: one rank, every send received by the sender itself" if args.rccl_loopback else "")
         config["ranks"] = world
         config["ranks_seen_by_collective"] = ranks_seen
         config["gpus_visible"] = n_dev
@@ -812,7 +819,7 @@ def main():
             g.env.close()                                  # host envs: the worker processes exit
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

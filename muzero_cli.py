@@ -72,9 +72,14 @@ def make_env(name, num_envs, device, seed, limit=0, on_end="continue"):
     probe = gym.make(name)                                 # the spaces; the envs themselves are built inside the worker processes
     obs_dim, n_actions = int(np_prod(probe.observation_space.shape)), int(probe.action_space.n)
     probe.close()
-    workers = int(os.environ.get("SMZ_HOST_WORKERS", min(64, 3 * len(os.sched_getaffinity(0))))) if num_envs >= 64 else 0
+    workers = int(os.environ.get("SMZ_HOST_WORKERS", min(64, 3 * _host_envs().usable_cores()))) if num_envs >= 64 else 0
     return envs.HostVecEnv([functools.partial(gym.make, name) for _ in range(num_envs)], obs_dim, n_actions, device, env_seed=seed,
                            limit=limit, on_end="reset" if on_end == "continue" else on_end, workers=workers)
+
+
+def _host_envs():
+    from importlib import import_module
+    return import_module("stochastic-muzero_amd.host_envs")
 
 
 def np_prod(shape):

@@ -214,12 +214,65 @@ class TrajectoryGather:
         return gather_to_learner(slab, self.dst, self.group, self.total_envs)
 
 
-def broadcast_model(model, src=0, group=None, device=None):
+class ChunkExchange:
+    """A K-step block on N > 1 ranks the way bench.py runs it: played in slices, every finished slice handed to the overlapped
+    exchange (TrajectoryGather) -- or, in mode "plain", played whole and sent with one synchronous grouped send / receive per
+    message (gather_to_learner).  Both modes deliver the same tensors to the learner.
+
+        play(n_steps, t0) -> chunks            plays rows [t0, t0 + n_steps) of every env group's chunk
+        rows(chunks, name, t0, t1) -> tensor   the groups' `name` rows ("data" | "obs") side by side (dim 1), or None
+
+    warm_up(n) is the first use of the exchange: an exception raised there (outside any timed region) switches to "plain" and
+    plays again -- what `gather_mode` in bench.py's JSON line reports.  (An RCCL failure that hangs or aborts instead of raising
+    is not caught in-process: bench.py's launcher re-runs the ranks with --gather-mode plain, and the process group carries a
+    timeout so that a hang ends as an error.)"""
+
+    def __init__(self, tg, play, rows, mode="overlapped", total_envs=None, log=None):
+        assert mode in ("overlapped", "plain")
+        self.tg, self.play, self.rows, self.total_envs, self.log = tg, play, rows, total_envs, log
+        self.mode = {"kind": mode}
+
+    def run(self, n):
+        """n env steps + the exchange.  Returns (chunks, gathered): gathered = (records, frames | None) on the learner, None on
+        the other ranks."""
+        tg = self.tg
+        if self.mode["kind"] == "plain":
+            chunks = self.play(n, 0)
+            parts = gather_to_learner(self.rows(chunks, "data", 0, n), tg.dst, tg.group, self.total_envs)
+            obs = self.rows(chunks, "obs", 0, n)
+            fparts = gather_to_learner(obs, tg.dst, tg.group, self.total_envs) if obs is not None else None
+            if parts is None:
+                return chunks, None
+            return chunks, (torch.cat(list(parts), 1), torch.cat(list(fparts), 1) if fparts is not None else None)
+        k = max(1, min(tg.slices, n))
+        cuts = [n * i // k for i in range(k + 1)]
+        chunks = None
+        for i in range(k):
+            chunks = self.play(cuts[i + 1] - cuts[i], cuts[i])
+            tg.start(self.rows(chunks, "data", cuts[i], cuts[i + 1]), self.rows(chunks, "obs", cuts[i], cuts[i + 1]))
+        return chunks, tg.finish()
+
+    def warm_up(self, n):
+        try:
+            return self.run(n)
+        except Exception as e:                      # noqa: BLE001  (whatever the first contact with the collective library raises)
+            if self.mode["kind"] == "plain":
+                raise
+            if self.log is not None:
+                self.log(f"overlapped trajectory gather failed at warm-up ({type(e).__name__}: {e}); using the plain gather")
+            self.mode.update(kind="plain", error=f"{type(e).__name__}: {e}")
+            self.tg._pending, self.tg._sizes = [], None
+            return self.run(n)
+
+
+def broadcast_model(model, src=0, group=None, device=None, loopback=False):
     """Learner -> actors weight hand-off after a training step (replaces Ray re-pickling the whole model into every
     task, self_play.py:249-256): every parameter/buffer of the six head modules is broadcast from rank `src` in one
     flattened message per module (checkpoint 421: 115 KB in total), then the cached batched evaluators are dropped so
-    the next search packs the new weights.  "nccl" (= RCCL) broadcasts from device memory; "gloo" from the host."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    the next search packs the new weights.  "nccl" (= RCCL) broadcasts from device memory; "gloo" from the host.
+    `loopback`: a world of one rank still flattens, broadcasts (RCCL executes the collective with a single participant) and
+    copies back -- the single-GPU test of this path."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not loopback):
         return model
     use_cuda = dist.get_backend(group) == "nccl"
     # (gloo = the functional runs without RCCL: the message goes through the host whatever `device` says)

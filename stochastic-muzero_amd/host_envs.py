@@ -25,6 +25,32 @@ import time
 import numpy as np
 
 
+def usable_cores():
+    """Cores this process can actually USE: its affinity mask, capped by the container's CPU quota (cgroup v2 cpu.max / v1
+    cfs_quota_us) -- the bench box shows 256 hardware threads and grants 16 CPUs' worth of time; threads beyond the quota only
+    get the others throttled."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                quota = q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # built-in stand-ins (gymnasium is not part of this build)
 # ---------------------------------------------------------------------------------------------------------------------------

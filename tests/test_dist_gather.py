@@ -217,6 +217,85 @@ def test_loopback_exchange_in_a_world_of_one(tmp_path):
     assert os.path.exists(os.path.join(tmp_path, "ok.pt"))
 
 
+class _FakeChunk:
+    def __init__(self, data, obs):
+        self.data, self.obs = data, obs
+
+
+def _fallback_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import stochastic_muzero_amd  # noqa: F401
+    g = import_module("stochastic-muzero_amd.gather")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from datetime import timedelta
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=60))
+    T, total, o, A = 8, 11, 4, 3
+    full = _record(T, total, o, A, 5)
+    frames = torch.arange(T * total * 6, dtype=torch.float32).reshape(T, total, 6)
+    lo, hi = g.shard_range(total, rank, world)
+    mid = (lo + hi) // 2                                        # two env groups per rank, as bench.py's --groups
+    for with_frames in (False, True):
+        played = []
+
+        def play(n, t0):                                        # "plays" rows [t0, t0 + n) of this rank's two groups
+            played.append((n, t0))
+            return [_FakeChunk(full[:, a:b], frames[:, a:b] if with_frames else None) for a, b in ((lo, mid), (mid, hi))]
+
+        def rows(chunks, name, t0, t1):
+            parts = [getattr(c, name) for c in chunks]
+            return None if parts[0] is None else torch.cat([p[t0:t1] for p in parts], 1)
+
+        want = (full, frames if with_frames else None)
+        # the overlapped mode, undisturbed
+        x = g.ChunkExchange(g.TrajectoryGather(o, A, slices=4, total_envs=total), play, rows, total_envs=total)
+        _, got = x.warm_up(T)
+        assert x.mode == {"kind": "overlapped"} and played == [(2, 0), (2, 2), (2, 4), (2, 6)]
+        if rank == 0:
+            assert torch.equal(got[0], want[0]) and (want[1] is None or torch.equal(got[1], want[1]))
+        else:
+            assert got is None
+        # the first exchange raises at its second slice (on every rank, as a collective that cannot be built does): the warm-up
+        # switches to the plain gather, replays the block whole, and every later block stays plain -- same tensors on the learner
+        del played[:]
+        tg = g.TrajectoryGather(o, A, slices=4, total_envs=total)
+        real_start, calls, said = tg.start, [], []
+
+        def broken_start(data, fr=None):
+            calls.append(1)
+            if len(calls) == 2:
+                raise RuntimeError("injected: ncclCommInitRank failed")
+            return real_start(data, fr)
+        tg.start = broken_start
+        x = g.ChunkExchange(tg, play, rows, total_envs=total, log=said.append)
+        _, got = x.warm_up(T)
+        assert x.mode["kind"] == "plain" and "injected" in x.mode["error"] and len(said) == 1
+        assert played == [(2, 0), (2, 2), (T, 0)]
+        for _ in range(2):
+            if rank == 0:
+                assert torch.equal(got[0], want[0]) and (want[1] is None or torch.equal(got[1], want[1])), with_frames
+            else:
+                assert got is None
+            _, got = x.run(T)
+        assert len(calls) == 2                                   # the overlapped exchange was not tried again
+    # a failure in plain mode is not swallowed
+    x = g.ChunkExchange(g.TrajectoryGather(o, A), lambda n, t0: (_ for _ in ()).throw(ValueError("play failed")), None, mode="plain")
+    with pytest.raises(ValueError):
+        x.warm_up(2)
+    if rank == 0:
+        torch.save(torch.ones(1), os.path.join(out_dir, "ok.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_plain_gather_fallback_delivers_the_same_chunk(tmp_path):
+    """bench.py's fallback from the overlapped to the plain trajectory gather (gather.ChunkExchange.warm_up) is
+    driven by an injected exception, 2 gloo ranks x 2 env groups, with and without image records."""
+    port = 21500 + (os.getpid() % 2000)
+    mp.spawn(_fallback_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "ok.pt"))
+
+
 def test_compact_wire_format_is_lossless_and_smaller():
     sys.path.insert(0, ROOT)
     import stochastic_muzero_amd  # noqa: F401

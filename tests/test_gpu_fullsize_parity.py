@@ -131,7 +131,8 @@ def assert_engine_equals_oracle(eng, trees, sims, prior_rtol):
 @pytest.mark.parametrize("wname,B,sims,K,T", [("weights_ckpt421", 4096, 50, 2, 1.0),       # BASELINE configs[1]
                                               ("weights_lunar_L0", 4096, 50, 2, 0.5),      # configs[2], A = 4 (AEX, MAXA 4)
                                               ("weights_ckpt421", 4096, 100, 2, 0.0),      # configs[4]'s per-GPU shard
-                                              ("weights_lunar_L0", 1000, 20, 4, 0.2)])     # K = A = 4, ragged batch
+                                              ("weights_lunar_L0", 1000, 20, 4, 0.2),      # K = A = 4, ragged batch
+                                              ("weights_lunar_L0", 4096, 50, 4, 1.0)])     # SURVEY 8d(3)'s K = 4 stress at full size (N 205)
 def test_production_search_kernel_equals_oracle_on_every_tree(wname, B, sims, K, T):
     import orc
     mcts_mod, model_mod = _mods()
@@ -162,6 +163,22 @@ def test_production_search_kernel_equals_oracle_on_every_tree(wname, B, sims, K,
     assert np.array_equal(root_value.cpu().numpy(), np.array([a[3] for a in oa], np.float32))
     print(f"[{wname} {B}x{sims} K={K}] single-launch == oracle on all {B} trees; f64 root priors bit-identical with "
           f"device-drawn noise: {n_exact}/{B}")
+    _keep_count(dict(test="production_search_kernel_equals_oracle_on_every_tree", weights=wname, trees=B, sims=sims, K=K,
+                     kernel=e.last_kernel() if hasattr(e, "last_kernel") else None,
+                     priors_bit_identical_with_device_noise=n_exact, priors_within_1e_13=B, visits_actions_stream_identical=B))
+
+
+def _keep_count(rec):
+    """how often the device-drawn Dirichlet noise gives bit-identical float64 root priors is evidence, not a
+    print: appended to gpurun_out/prior_exactness.jsonl (copied to profiles/ by the round's profile script)."""
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "prior_exactness.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
 
 
 def assert_engine_equals_oracle_after_act(eng, trees, sims):
