@@ -297,6 +297,13 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="--end-to-end: iterations per timed block through selfplay.self_play_iterations (the search of iteration k + 1 is "
                          "enqueued before the host builds and stores iteration k's games); 1 = one synchronous self_play_iteration per block")
+    ap.add_argument("--learning-cycle", action="store_true",
+                    help="--end-to-end through selfplay.learning_cycle itself (the reference's loop, self_play.py:168-306): "
+                         "--pipeline iterations per timed block with number_of_training_before_self_play = 0 and a model whose "
+                         "save_model is a no-op; --pipeline 1 = the synchronous loop")
+    ap.add_argument("--per-env-step", action="store_true",
+                    help="--host-env python: step every env with its own Python call (HostSlice's per-env loop, the checker of the "
+                         "batched-slice path) instead of one array step per worker slice (host_envs.CartPoleBatch)")
     ap.add_argument("--host-workers", type=int, default=None,
                     help="--host-env python: env worker processes per env group (default min(64, 3 x usable host cores); "
                          "0 = step the envs serially in this process)")
@@ -322,6 +329,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # The job's stdout carries the JSON line and nothing else: RCCL writes a version banner to stdout through C stdio (seen on the
+    # loopback run, flushed at process exit BEHIND the line).  Every rank points fd 1 at stderr now; rank 0 keeps a private
+    # duplicate of the real stdout for the line.
+    sys.stdout.flush()
+    json_fd = os.dup(1) if rank == 0 else None
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}.  Run `python bench.py --gpus N` on its own "
                          f"(it starts the N ranks itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`.")
@@ -381,9 +394,14 @@ def main():
                         else cpu_baseline_mlp(wl, wpath, args.cpu_baseline_seconds))
     T = max(args.steps, args.warmup, 1)
     # host envs behind Python (--host-env python): two env groups, so that one group's search runs while the other's envs step
-    G = args.groups if args.groups > 0 else (2 if ((B >= 262144 or args.host_env == "python") and B % 2 == 0) else 1)
+    # (CartPole envs stepped slice-wise: a worker's step is ~40 numpy operations, the hand-off dominates -- one group, few workers:
+    #  measured on the 16-CPU-quota box 8 / 16 workers x 1 group 308 / 312 M, x 2 groups 224 M, in-process 212 M simulations/s)
+    batched_slices = args.host_env == "python" and wl["env"] == "cartpole" and not args.per_env_step
+    G = args.groups if args.groups > 0 else (2 if ((B >= 262144 or (args.host_env == "python" and not batched_slices)) and B % 2 == 0) else 1)
     host_workers = 0
-    if args.host_env == "python":
+    if batched_slices:
+        host_workers = args.host_workers if args.host_workers is not None else min(16, max(1, host_cores()))
+    elif args.host_env == "python":
         # worker processes PER ENV GROUP: idle workers sleep in the kernel (futex), so while one group's envs step, the other
         # group's workers cost nothing and every group may use all usable cores; 3 x the cores hides the wake-up latencies
         # (measured on the 16-CPU-quota bench box: 14 workers 76 M, 16 113 M, 24 135 M simulations/s with one group)
@@ -400,7 +418,7 @@ def main():
             env = envs_mod.HostCartPoleVec(Bg, dev, seed=0, first_env=glo)
         elif wl["env"] == "cartpole" and args.host_env:
             env = envs_mod.HostVecEnv([envs_mod.HostCartPole for _ in range(Bg)], 4, 2, dev, env_seed=0, limit=0,
-                                      on_end="reset", first_env=glo, workers=host_workers)
+                                      on_end="reset", first_env=glo, workers=host_workers, batch_step=not args.per_env_step)
         elif wl["env"] == "cartpole":
             env = envs_mod.CartPoleVec(Bg, dev, seed=0, first_env=glo, total_envs=total)
         elif wl["env"] == "image" and args.host_env:
@@ -473,6 +491,12 @@ def main():
 
     sink = ReplaySink(td_steps=50)                            # config/experiment_421_config.json: td_steps 50
     e2e_parts = []
+    lc_model = None
+    if args.learning_cycle:
+        assert args.end_to_end, "--learning-cycle is a variant of --end-to-end"
+        import copy
+        lc_model = copy.copy(model)
+        lc_model.save_model = lambda **k: None                # (no checkpoint file per iteration inside the timed region)
     if args.end_to_end:
         assert G == 1, "--end-to-end times self_play_iteration: one env group"
 
@@ -482,7 +506,15 @@ def main():
             sink.clear()
             barrier()
             t0 = time.perf_counter()
-            if args.pipeline > 1:
+            if args.learning_cycle:
+                before = len(sink.buffer)
+                sp.learning_cycle(number_of_iteration=args.pipeline, number_of_self_play_before_training=1,
+                                  number_of_training_before_self_play=0, model_tag_number=1, number_of_worker_selfplay="gpu",
+                                  temperature_type="static_one_temperature", verbose=False, muzero_model=lc_model, gameplay=env,
+                                  monte_carlo_tree_search=mcts, replay_buffer=sink, steps_per_iteration=args.steps,
+                                  gather=tg if multi else None, pipeline=None if args.pipeline > 1 else False)
+                n_games = len(sink.buffer) - before
+            elif args.pipeline > 1:
                 n_games = 0
                 for games, _ in sp.self_play_iterations(env, model, mcts, args.temperature, args.steps, args.pipeline, replay_buffer=sink,
                                                         gather=tg if multi else None, ignore_termination=True):
@@ -567,7 +599,8 @@ def main():
                       else f"host, Python envs rendering 400x600x3 uint8 frames (envs.HostImageVecEnv: {host_workers} worker processes for each of {G} env group(s), page-locked shared block, "
                            f"upload = {args.frame_upload}: " + ("115 KB of resize taps per frame + smz_frames_resize_taps_u8" if args.frame_upload == "taps" else "720 KB frames + smz_frames_resize_u8") + " per step)" if (args.host_env and wl["env"] == "image")
                       else f"host, Python envs (envs.HostVecEnv: {host_workers} worker processes for each of {G} env group(s) (sleeping on a futex while idle) writing into a page-locked shared block; action download + observation upload per step; "
-                           "one group's search overlaps the other's host step)" if args.host_env else "device"),
+                           + ("every worker steps its slice of the envs with ONE array step (host_envs.CartPoleBatch, the batched-slice protocol; identical env by env to the per-env loop))" if batched_slices else
+                              "one Python env.step call per env; one group's search overlaps the other's host step)") if args.host_env else "device"),
               "host_workers": host_workers if args.host_env == "python" else None,
               "parallelism": f"envs sharded x{world}, trajectory gather to rank 0" if world > 1 else
                               ("single GPU, trajectory gather to itself over RCCL (loopback)" if args.rccl_loopback else "single GPU")}
@@ -579,9 +612,11 @@ def main():
         config["gpus_visible"] = n_dev
     out = {"metric": "MCTS simulations/sec (whole node), CartPole MLP 4096 envs \u00d7 50 sims" if headline else
                      f"MCTS simulations/sec (whole node), {args.workload} at {B} envs/GPU" + (" (host-resident envs)" if args.host_env else "")
+                     + (" (RCCL LOOPBACK: the N > 1 code path -- process group, sliced trajectory gather to itself -- with one rank)" if args.rccl_loopback else "")
                      + (" (Philox throughput-mode random streams)" if args.rng == "philox" else "")
                      + (" (END TO END: self_play_iteration = search + transfer + Game records + save_game)" if args.end_to_end else "")
-                     + (f" (pipelined: {args.pipeline} iterations per block, the next search enqueued before a chunk's host half)" if args.end_to_end and args.pipeline > 1 else ""),
+                     + (f" (pipelined: {args.pipeline} iterations per block, the next search enqueued before a chunk's host half)" if args.end_to_end and args.pipeline > 1 else "")
+                     + (" (through selfplay.learning_cycle, no training between iterations, save_model a no-op)" if args.learning_cycle else ""),
            "value": sims_total / dt, "unit": "simulations/s", "n_gpus": world, "steps": block_steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * dt / block_steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32 (tree values, heads) + f64 (pUCT scores, root priors) + i32 (counts)",
@@ -818,7 +853,8 @@ def main():
         if hasattr(g.env, "close"):
             g.env.close()                                  # host envs: the worker processes exit
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.close(json_fd)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -638,6 +638,11 @@ extern __shared__ float4 smz_search_lds4[];
 #endif
 // -DSMZ_BPS_PROBE (variant builds, tools/bps_probe.sh): s_memtime stamps inside the production LDS-resident kernel, summed
 // over waves into smz_read_stats' slots 8.. (expand + backup | select: prepare, evaluate, chase, records | networks | staging)
+// SMZ_EARLY_ROWS (round 5): in the block-parallel selection the wave's two parent rows are requested from global memory as soon
+// as the pointer chase has named them (-DSMZ_EARLY_ROWS=0 builds keep the loads where the network inputs are assembled)
+#ifndef SMZ_EARLY_ROWS
+#define SMZ_EARLY_ROWS 1
+#endif
 #ifdef SMZ_BPS_PROBE
 #define SMZ_PROBE_DECL unsigned long long pb_t0 = 0, pb_acc[7] = {0, 0, 0, 0, 0, 0, 0};
 #define SMZ_PROBE_START pb_t0 = __builtin_amdgcn_s_memtime();
@@ -851,6 +856,8 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         constexpr bool BPS = SMZ_SELECT_BLOCKS && AEX && KS == 2 && TLDS && !INSTR && MAXA == 2;   // (four actions: the root is a
         // code path of its own beside the blocks' -- measured 409 against 458 M, profiles/r04_bps_ab.txt)
         bool bps_done = false;
+        bool bps_all = false;                 // every tree of the wave went through the block-parallel selection this round
+        float early_row[kFastTpw] = {0.f, 0.f};
         if constexpr (BPS) {
             uint16_t *selw = reinterpret_cast<uint16_t *>(scratch + ml.sel_off);          // [tpw][sel_n]
             const int SELN = ml.sel_n;
@@ -883,6 +890,27 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             smz_mlp::lds_sync();
             SMZ_PROBE(3)
             const int blen = pick_lane01(len, src);
+#if SMZ_EARLY_ROWS
+            // Round 5: the leaf's PARENT is the path's last-but-one entry -- known here, before the path records, the leaf's
+            // action and the stream position are worked out.  The loads of the wave's two parent rows (global memory: an L2 round
+            // trip of ~1.5 k cycles that used to start only after all of that) are issued now and land in registers while the
+            // LDS-only rest of the selection runs; the network inputs are written from the registers.  The tree phases of this
+            // instantiation touch no global memory, so no later wait of the selection sits behind these loads (gfx950 returns
+            // vector-memory loads in order: profiles/r03_ceiling.md 6b).  A tree that falls back to the sequential descent
+            // (bps_all false) takes the old path.
+            bps_all = __ballot(valid && len == 0) == 0ull && __ballot(valid) != 0ull;
+            if (bps_all) {
+                int par = 0;
+                if (valid && len > 1) { const int loc = pathw[lane * SELN + len - 2], pb = loc >> 8; par = pb == 0 ? 1 + (loc & 3) : 1 + A + (pb - 1) * 2 + (loc & 3); }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // (rows stored in earlier rounds may be this round's parents)
+#pragma unroll
+                for (int t = 0; t < kFastTpw; t++) {
+                    const int parent = __builtin_amdgcn_readlane(par, t);
+                    const float *srow = P.hidden + ((size_t)(tree0 + t) * P.N + parent) * P.hs;
+                    early_row[t] = (lane < S && tree0 + t < P.B) ? srow[lane] : 0.f;
+                }
+            }
+#endif
             for (int d = lane >> 1; d < blen; d += kWave / 2) select_record(P, stb, pathw + src * SELN, d, pvals + src * P.P);
             if (valid && len > 0) {
                 L = select_leaf(P, stb, pathw + lane * SELN, len);
@@ -936,10 +964,18 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         SMZ_PROBE(4)
         __builtin_amdgcn_s_setprio(SMZ_PRIO_HEADS);
         // hidden rows written in earlier rounds (by any lane of this wave) may be this round's parent rows
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (!(BPS && SMZ_EARLY_ROWS && bps_all)) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         StagePre<SU> pre;       // (after the fence: it drains the vector-memory counter)
         if (split && !(dbg & 8)) stage_issue<SU, PHC>(P, tree, valid, packed, pre);
         // all rows' network inputs first (independent global loads, one latency), then the rows one after another
+        if (BPS && SMZ_EARLY_ROWS && bps_all) {                 // (the parent rows are in registers already: see the selection)
+#pragma unroll
+            for (int t = 0; t < kFastTpw; t++) {
+                if (tree0 + t >= P.B) break;
+                const int act = __builtin_amdgcn_readlane(L.action, t);
+                if (lane < K4in) xall[t * K4in + lane] = (lane < S) ? early_row[t] : ((lane < S + A && (lane - S) == act) ? 1.f : 0.f);
+            }
+        } else
         for (int t = 0; t < tpw; t++) {
             const int row = tree0 + t;
             if (row >= P.B) break;                               // wave-uniform

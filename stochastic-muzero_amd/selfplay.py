@@ -812,7 +812,7 @@ def _reward_sums(games):
 def learning_cycle(number_of_iteration=10000, number_of_self_play_before_training=1, number_of_training_before_self_play=1,
                    model_tag_number=124, number_of_worker_selfplay=1, temperature_type="static_temperature", verbose=True,
                    muzero_model=None, gameplay=None, monte_carlo_tree_search=None, replay_buffer=None,
-                   steps_per_iteration=None, gather=None, model_directory="model_checkpoint", broadcast=None):
+                   steps_per_iteration=None, gather=None, model_directory="model_checkpoint", broadcast=None, pipeline=None):
     """The reference's learning_cycle (self_play.py:168-306), same keyword arguments, assertions and return value
     (epoch_pr, loss, reward, configuration).  What plays the games is chosen the way the reference chooses its backend
     (self_play.py:237-243), by `number_of_worker_selfplay` and by what `gameplay` is:
@@ -833,7 +833,18 @@ def learning_cycle(number_of_iteration=10000, number_of_self_play_before_trainin
 
     The training half (self_play.py:285-288) calls muzero_model.train(replay_buffer.sample_batch()) exactly as the
     reference does; this package's Muzero raises NotImplementedError there (training is the reference's), any model
-    object with the reference's train() works."""
+    object with the reference's train() works.
+
+    `pipeline` (batched engine only): None = pipelined when it cannot change a result, i.e. when
+    number_of_training_before_self_play == 0 -- the loop is then driven by self_play_iterations: the search of iteration
+    k + 1 is enqueued before the host turns iteration k's chunk into games, stores them and saves the model, so the host half
+    hides behind the search (the games, rewards and buffer contents are those of the synchronous loop; the weights never
+    change, so the per-iteration broadcast is skipped too).  True forces it for a caller whose train() leaves the searching
+    weights alone until the loop ends (iteration k + 1 is already running with the weights of the moment it was enqueued when
+    iteration k trains); False keeps the synchronous self_play_iteration per iteration.  With training between the
+    iterations the loop stays synchronous: iteration k + 1 must search with the weights iteration k's training produced
+    (self_play.py:285-288 -> :249-256), so neither the learner nor an actor rank may start it earlier without playing it
+    with stale weights."""
     assert isinstance(number_of_iteration, int) and number_of_iteration >= 1, "number_of_iterationt ∈ int | {1 < number_of_iteration < +inf)"
     assert isinstance(number_of_self_play_before_training, int) and number_of_self_play_before_training >= 0, "number_of_self_play_before_training ∈ int | {0 < number_of_self_play_before_training < +inf)"
     assert isinstance(number_of_training_before_self_play, int) and number_of_training_before_self_play >= 0, "number_of_training_before_self_play ∈ int | {0 < number_of_training_before_self_play < +inf)"
@@ -848,12 +859,24 @@ def learning_cycle(number_of_iteration=10000, number_of_self_play_before_trainin
     reward, epoch_pr, loss = [-float("inf")], [], []
     if broadcast is not None:
         broadcast(muzero_model)               # every rank starts from the learner's weights (Ray pickles the learner's model)
+
+    def temperature_of(ep):
+        t = temperature_scheduler(number_of_iteration + 1, ep, mode=temperature_type)
+        return float(t.reshape(-1)[0]) if isinstance(t, np.ndarray) else t
+    pipelined = batched and (number_of_training_before_self_play == 0 if pipeline is None else bool(pipeline))
+    piped = None
+    if pipelined:
+        steps = steps_per_iteration or getattr(gameplay, "limit", 0) or 500
+        piped = self_play_iterations(gameplay, muzero_model, monte_carlo_tree_search, lambda it: temperature_of(it + 1), steps,
+                                     number_of_iteration, replay_buffer=replay_buffer, gather=gather)
     for ep in range(1, number_of_iteration + 1):
-        temperature = temperature_scheduler(number_of_iteration + 1, ep, mode=temperature_type)
-        if isinstance(temperature, np.ndarray):
-            temperature = float(temperature.reshape(-1)[0])
+        temperature = temperature_of(ep)
         learner = True
-        if batched:
+        if pipelined:
+            game, batched_reward = next(piped)                # (iteration ep + 1's search is already enqueued)
+            learner = game is not None
+            game = game or []
+        elif batched:
             steps = steps_per_iteration or getattr(gameplay, "limit", 0) or 500
             # (the games are stored by self_play_iteration itself -- replay_buffer.save_game per game, self_play.py:266-268 --
             #  and their mean reward comes back with them)
@@ -887,7 +910,7 @@ def learning_cycle(number_of_iteration=10000, number_of_self_play_before_trainin
                 cache_loss.append(muzero_model.store_loss[-1][0])
         else:
             reward.append(float("nan"))       # an actor rank neither stores games, nor saves, nor trains
-        if broadcast is not None:
+        if broadcast is not None and not (pipelined and number_of_training_before_self_play == 0):
             broadcast(muzero_model)           # the new weights reach the actors (self_play.py:285-288 -> next :249-256)
         loss.append(sum(cache_loss) / len(cache_loss) if cache_loss else float("nan"))   # (the reference divides by 0 here)
         epoch_pr.append(f"EPOCH {ep} || selfplay reward: {reward[-1]} || training loss: {loss[-1]}||")
@@ -898,4 +921,6 @@ def learning_cycle(number_of_iteration=10000, number_of_self_play_before_trainin
                      "number_of_training_before_self_play": number_of_training_before_self_play,
                      "model_tag_number": model_tag_number, "number_of_worker_selfplay": number_of_worker_selfplay,
                      "temperature_type": temperature_type, "verbose": verbose}
+    if piped is not None:
+        piped.close()
     return epoch_pr, loss, reward, configuration

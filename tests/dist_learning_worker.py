@@ -30,6 +30,10 @@ def main():
     ap.add_argument("--sims", type=int, default=8)
     ap.add_argument("--limit", type=int, default=6)
     ap.add_argument("--iterations", type=int, default=3)
+    ap.add_argument("--training", type=int, default=1, help="number_of_training_before_self_play")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "off", "on"], help="learning_cycle(pipeline=None | False | True)")
+    ap.add_argument("--sliced", type=int, default=0, help="slices of a gather.TrajectoryGather (0: gather_to_learner)")
+    ap.add_argument("--tag", default="")
     a = ap.parse_args()
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
     n_dev = torch.cuda.device_count()
@@ -61,23 +65,23 @@ def main():
         model.store_loss = getattr(model, "store_loss", []) + [[1.0 / calls["train"]]]
         return "prio", "pos"
     model.train = train
-    model.save_model = lambda **k: calls["save"].append(k.get("model_update_or_backtrack"))
+    per_iteration = []
+    # (save_model closes an iteration's games: learning_cycle stores them, saves, then trains -- self_play.py:266-288)
+    model.save_model = lambda **k: (calls["save"].append(k.get("model_update_or_backtrack")), per_iteration.append([]))
     lo, hi = g.shard_range(a.total, rank, world)
     env = envs_mod.CartPoleVec(hi - lo, dev, seed=0, first_env=lo, total_envs=a.total, on_end="reset", limit=a.limit)
     m = mcts_mod.BatchedMCTS(hi - lo, num_simulations=a.sims, discount=0.999, root_exploration_fraction=0.1, device=dev.index)
     m.seed(np.arange(lo, hi, dtype=np.uint64))
     buf = sh.FakeBuffer()
-    per_iteration = []
     save_game = buf.save_game
     buf.save_game = lambda gm: (save_game(gm), per_iteration[-1].append(game_arrays(gm)))
-    sample = buf.sample_batch
-    buf.sample_batch = lambda: (per_iteration.append([]), sample())[1]       # the training phase closes an iteration's games
     per_iteration.append([])
     epoch_pr, loss, reward, conf = sp.learning_cycle(
-        number_of_iteration=a.iterations, number_of_self_play_before_training=1, number_of_training_before_self_play=1,
+        number_of_iteration=a.iterations, number_of_self_play_before_training=1, number_of_training_before_self_play=a.training,
         model_tag_number=1, number_of_worker_selfplay="gpu", temperature_type="static_one_temperature", verbose=False,
         muzero_model=model, gameplay=env, monte_carlo_tree_search=m, replay_buffer=buf, steps_per_iteration=a.steps,
-        gather=g.gather_to_learner if world > 1 else None)
+        gather=(g.TrajectoryGather(env.obs_dim, env.num_actions, slices=a.sliced, total_envs=a.total) if a.sliced else g.gather_to_learner) if world > 1 else None,
+        pipeline={"auto": None, "off": False, "on": True}[a.pipeline])
     torch.cuda.synchronize(dev)
     final = model.heads(dev).weights.cpu()
     if world > 1:
@@ -89,7 +93,7 @@ def main():
                       reward=[float(r) for r in reward], weights=final)]
     if rank == 0:
         torch.save(dict(world=world, backend=backend if world > 1 else None, ranks=every, loss=loss,
-                        games=[it for it in per_iteration if it]), os.path.join(a.out, f"learning_w{world}.pt"))
+                        games=[it for it in per_iteration if it]), os.path.join(a.out, f"learning_w{world}{a.tag}.pt"))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -271,3 +271,37 @@ def test_learning_cycle_on_two_ranks_trains_on_the_learner_and_broadcasts_inside
             for k in x:
                 assert np.array_equal(x[k], y[k]), (it, k)
     print("learning_cycle on 2 ranks over", two["backend"])
+
+
+def test_pipelined_learning_cycle_equals_the_synchronous_loop_on_one_and_two_ranks(tmp_path):
+    """with number_of_training_before_self_play = 0 learning_cycle drives self_play_iterations (the search
+    of iteration k + 1 enqueued before iteration k's games are built, stored and the model saved); the games of EVERY
+    iteration, the rewards and the model saves equal the synchronous loop's (pipeline=False) -- on one rank and on two ranks
+    (sliced exchange), and the two-rank run equals the one-rank run."""
+    worker = os.path.join(ROOT, "tests", "dist_learning_worker.py")
+    base = ["--out", str(tmp_path), "--total", "64", "--steps", "10", "--sims", "8", "--limit", "6", "--iterations", "4", "--training", "0"]
+    runs = {}
+    for world in (1, 2):
+        for pipe in ("off", "auto"):
+            tag = f"_{pipe}"
+            args = base + ["--pipeline", pipe, "--tag", tag] + (["--sliced", "2"] if world == 2 else [])
+            cmd = [sys.executable, worker] + args if world == 1 else \
+                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                 "--master-port", str(_port()), worker] + args
+            r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+            runs[(world, pipe)] = torch.load(os.path.join(tmp_path, f"learning_w{world}{tag}.pt"), weights_only=False)
+    ref = runs[(1, "off")]
+    assert len(ref["games"]) == 4 and ref["ranks"][0]["save"] == 4 and ref["ranks"][0]["train"] == 0
+    for key, got in runs.items():
+        lead = got["ranks"][0]
+        assert lead["reward"] == ref["ranks"][0]["reward"] and lead["save"] == 4 and lead["games"] == ref["ranks"][0]["games"], key
+        assert len(got["games"]) == 4, key
+        for it, (ga, gb) in enumerate(zip(got["games"], ref["games"])):
+            assert len(ga) == len(gb) and len(ga) >= 64, (key, it)
+            for x, y in zip(ga, gb):
+                for k in x:
+                    assert np.array_equal(x[k], y[k]), (key, it, k)
+        if key[0] == 2:
+            actor = got["ranks"][1]
+            assert (actor["train"], actor["save"], actor["games"]) == (0, 0, 0)

@@ -58,7 +58,9 @@ def test_bench_rccl_loopback_line():
            "--min-timed-seconds", "0.2", "--no-roofline"]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-5000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    # stdout is the JSON line and nothing else (RCCL's version banner, written through C stdio, must not trail it)
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-1500:]
+    out = json.loads(r.stdout)
     assert out["n_gpus"] == 1 and "LOOPBACK" in out["config"]["collective_backend"] and out["config"]["ranks_seen_by_collective"] == 1
     go = out["timing"]["gather_overlap"]
     assert go["mode"]["kind"] == "overlapped" and go["slices"] == 4 and go["exposed_ms_median"] is not None
