@@ -99,7 +99,7 @@ def test_c5_shape_eight_ranks_of_4096_envs_x_100_simulations_equal_one_32768_env
 
 def test_bench_starts_its_own_ranks():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs", "256",
-           "--no-cpu-baseline", "--min-timed-seconds", "0.05"]
+           "--no-cpu-baseline", "--min-timed-seconds", "0.05", "--gather-mode", "overlapped"]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -108,6 +108,8 @@ def test_bench_starts_its_own_ranks():
     assert out["value"] > 0 and out["scaling"] == "weak" and out["timing"]["blocks"] >= 1
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
     assert out["timing"]["gather_overlap"]["slices"] == 4 and out["timing"]["gather_ms_median"] > 0
+    assert out["timing"]["gather_overlap"]["mode"]["kind"] == "overlapped"
+    assert len(r.stdout.strip().splitlines()) == 1                      # stdout is the JSON line and nothing else
     # a launcher / flag mismatch is an error, not a silent single-GPU run
     bad = dict(_env(), WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=bad, capture_output=True, text=True,

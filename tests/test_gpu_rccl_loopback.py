@@ -56,6 +56,13 @@ def test_bench_rccl_loopback_line():
     rank over RCCL."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rccl-loopback", "--steps", "4", "--warmup", "1", "--envs", "512",
            "--min-timed-seconds", "0.2", "--no-roofline"]
+    # the default exchange is the plain gather (one grouped send / receive per block) ...
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-5000:]
+    plain = json.loads(r.stdout)
+    assert plain["timing"]["gather_overlap"]["mode"]["kind"] == "plain" and plain["timing"]["gather_ms_median"] > 0
+    # ... and the overlapped, sliced one is a switch away
+    cmd += ["--gather-mode", "overlapped"]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-5000:]
     # stdout is the JSON line and nothing else (RCCL's version banner, written through C stdio, must not trail it)
