@@ -113,9 +113,19 @@ __device__ inline float elu(float x) { return x > 0.f ? x : smz_exp(x) - 1.0f; }
 // to 5 instructions per step (identity mov + hazard nop + v_mov_dpp + NaN canonicalisation + op), hence the asm;
 // `s_nop 1` covers the 2 wait states a DPP read needs after the VALU write of the same register.  All 64 lanes must be
 // active (the callers are wave-uniform).
+// SMZ_DPP_VOLATILE: `volatile` keeps the reduction chains of a pass in program order (two rows' tails one after the other);
+// without it (-DSMZ_DPP_VOLATILE= builds) the scheduler may interleave independent chains.  (A/B: profiles/r05_d_*.)
+#ifndef SMZ_DPP_VOLATILE
+#define SMZ_DPP_VOLATILE volatile
+#endif
+// SMZ_PAIR_TAILS (round 5): the tails of a two-row pass are evaluated for both rows at once (softmax_decode_pair and friends
+// below: bit-identical to the per-row tails).  -DSMZ_PAIR_TAILS=0 builds keep the per-row tails.
+#ifndef SMZ_PAIR_TAILS
+#define SMZ_PAIR_TAILS 1
+#endif
 #define SMZ_DPP_REDUCE(NAME, INSN)                                                               \
     __device__ inline float NAME(float v) {                                                      \
-        asm volatile("s_nop 1\n\t"                                                               \
+        asm SMZ_DPP_VOLATILE("s_nop 1\n\t"                                                               \
                      INSN " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"      \
                      INSN " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"      \
                      INSN " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"      \
@@ -133,7 +143,7 @@ __device__ inline float op_max(float a, float b) { return fmaxf(a, b); }
 __device__ inline float op_min(float a, float b) { return fminf(a, b); }
 // two independent sums in one chain: each instruction fills one of the other's DPP wait states
 __device__ inline void wave_sum2(float &a, float &b) {
-    asm volatile("s_nop 1\n\t"
+    asm SMZ_DPP_VOLATILE("s_nop 1\n\t"
                  "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
                  "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
                  "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
@@ -145,7 +155,7 @@ __device__ inline void wave_sum2(float &a, float &b) {
     b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
 }
 __device__ inline void wave_minmax(float &mn, float &mx) {
-    asm volatile("s_nop 1\n\t"
+    asm SMZ_DPP_VOLATILE("s_nop 1\n\t"
                  "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
                  "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
                  "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
@@ -162,7 +172,7 @@ __device__ inline void wave_minmax(float &mn, float &mx) {
     I0 " %0, %0, %0 " CTRL "\n\t" I1 " %1, %1, %1 " CTRL "\n\t" I2 " %2, %2, %2 " CTRL "\n\t"
 #define SMZ_DPP3_REDUCE(NAME, I0, I1, I2)                                                          \
     __device__ inline void NAME(float &a, float &b, float &c) {                                    \
-        asm volatile("s_nop 1\n\t"                                                                 \
+        asm SMZ_DPP_VOLATILE("s_nop 1\n\t"                                                                 \
                      SMZ_DPP3_STEP(I0, I1, I2, "row_shr:1 row_mask:0xf bank_mask:0xf")             \
                      SMZ_DPP3_STEP(I0, I1, I2, "row_shr:2 row_mask:0xf bank_mask:0xf")             \
                      SMZ_DPP3_STEP(I0, I1, I2, "row_shr:4 row_mask:0xf bank_mask:0xf")             \
@@ -180,7 +190,7 @@ SMZ_DPP3_REDUCE(wave_max_min_max, "v_max_f32_dpp", "v_min_f32_dpp", "v_max_f32_d
 #undef SMZ_DPP3_REDUCE
 #undef SMZ_DPP3_STEP
 __device__ inline void wave_max2(float &a, float &b) {
-    asm volatile("s_nop 1\n\t"
+    asm SMZ_DPP_VOLATILE("s_nop 1\n\t"
                  "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
                  "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
                  "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
@@ -325,6 +335,130 @@ __device__ inline float decode_scale_lanes(const float (&v)[U], int S, int lane,
     return support_to_scalar(num, den);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the tails of a TWO-row pass evaluated for both rows at once.  v_permlane32_swap packs the rows' accumulators so
+// that row h lives in lanes [32 h, 32 h + 32): P = outputs 0..31, Q = outputs 32..63 of both rows.  Every reduction then
+// runs ONCE over 32-lane halves (row_shr 1 / 2 / 4 / 8 + row_bcast:15: five steps instead of six, results in lanes 31 and
+// 63), the exponentials, quotients and the support decode run once for both rows, and the decode itself is computed in the
+// lanes that hold the sums.  Bit-identical to the per-row functions above:
+//   * max / min do not depend on the order;
+//   * a wave_sum over 64 lanes is the balanced tree ((R0 + R1) + (R2 + R3)) of its 16-lane rows; the half-wide chain yields
+//     R0 + R1 of the P part and, run on the Q part, R2 + R3 (a part whose lanes are all zero contributes an exact zero) --
+//     their sum is the original total, term by term in the original association;
+//   * every element-wise operation is the same instruction on the same operands.
+// Requires U == 1, S <= 32 and all 64 lanes active.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ inline void swap32(float &a, float &b) {      // a = [a.lo | b.lo], b = [a.hi | b.hi]  (lo / hi: lanes 0..31 / 32..63)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+// the value lane 31 holds for lanes 0..31, the value lane 63 holds for lanes 32..63
+__device__ inline float half_bcast(float v, bool hi) {
+    const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return hi ? s1 : s0;
+}
+#define SMZ_HSTEP1(I0, CTRL) I0 " %0, %0, %0 " CTRL "\n\t"
+#define SMZ_HSTEP2(I0, I1, CTRL) I0 " %0, %0, %0 " CTRL "\n\t" I1 " %1, %1, %1 " CTRL "\n\t"
+#define SMZ_HSTEP3(I0, I1, I2, CTRL) I0 " %0, %0, %0 " CTRL "\n\t" I1 " %1, %1, %1 " CTRL "\n\t" I2 " %2, %2, %2 " CTRL "\n\t"
+#define SMZ_HSTEP5(I, CTRL) I " %0, %0, %0 " CTRL "\n\t" I " %1, %1, %1 " CTRL "\n\t" I " %2, %2, %2 " CTRL "\n\t" I " %3, %3, %3 " CTRL "\n\t" I " %4, %4, %4 " CTRL "\n\t"
+#define SMZ_HALF_CHAIN(STEP, ...)                                                          \
+    "s_nop 1\n\t" STEP(__VA_ARGS__, "row_shr:1 row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"  \
+    STEP(__VA_ARGS__, "row_shr:2 row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"                \
+    STEP(__VA_ARGS__, "row_shr:4 row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"                \
+    STEP(__VA_ARGS__, "row_shr:8 row_mask:0xf bank_mask:0xf") "s_nop 0\n\t"                \
+    STEP(__VA_ARGS__, "row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 1"
+// (results: lane 31 for the lower half, lane 63 for the upper)
+__device__ inline void half_max2(float &a, float &b) {
+    asm SMZ_DPP_VOLATILE(SMZ_HALF_CHAIN(SMZ_HSTEP2, "v_max_f32_dpp", "v_max_f32_dpp") : "+v"(a), "+v"(b));
+}
+__device__ inline void half_minmax(float &mn, float &mx) {
+    asm SMZ_DPP_VOLATILE(SMZ_HALF_CHAIN(SMZ_HSTEP2, "v_min_f32_dpp", "v_max_f32_dpp") : "+v"(mn), "+v"(mx));
+}
+__device__ inline void half_max_min_max(float &a, float &b, float &c) {
+    asm SMZ_DPP_VOLATILE(SMZ_HALF_CHAIN(SMZ_HSTEP3, "v_max_f32_dpp", "v_min_f32_dpp", "v_max_f32_dpp") : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ inline void half_sum2(float &a, float &b) {
+    asm SMZ_DPP_VOLATILE(SMZ_HALF_CHAIN(SMZ_HSTEP2, "v_add_f32_dpp", "v_add_f32_dpp") : "+v"(a), "+v"(b));
+}
+__device__ inline void half_sum5(float &a, float &b, float &c, float &d, float &e) {
+    asm SMZ_DPP_VOLATILE(SMZ_HALF_CHAIN(SMZ_HSTEP5, "v_add_f32_dpp") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+}
+
+// softmax_decode_lanes for two rows: policies to dst0 / dst1 (non-null), values returned
+__device__ inline void softmax_decode_pair(float a0, float a1, int A, int S, int lane, float *dst0, float *dst1, float &val0,
+                                           float &val1) {
+    float P = a0, Q = a1;
+    swap32(P, Q);
+    const bool hi = lane >= 32;
+    const int j = lane & 31, oq = 32 + j, half = S / 2;
+    const bool ppol = j < A, pval = !ppol && j < A + S, qval = oq >= A && oq < A + S;      // (A <= 32: the policy lies in P)
+    float mp = ppol ? P : -__builtin_inff();
+    float mv = op_max(pval ? P : -__builtin_inff(), qval ? Q : -__builtin_inff());
+    half_max2(mp, mv);
+    mp = half_bcast(mp, hi); mv = half_bcast(mv, hi);
+    const float eP = (ppol || pval) ? smz_exp(P - (ppol ? mp : mv)) : 0.f;
+    const float eQ = qval ? smz_exp(Q - mv) : 0.f;
+    float dp = ppol ? eP : 0.f, dvP = pval ? eP : 0.f, nvP = pval ? (float)(j - A - half) * eP : 0.f;
+    float dvQ = eQ, nvQ = qval ? (float)(oq - A - half) * eQ : 0.f;
+    half_sum5(dp, dvP, nvP, dvQ, nvQ);
+    // lanes 31 / 63: the rows' totals in wave_sum3's association; the decode runs there, once for both rows
+    const float dv = dvP + dvQ, nv = nvP + nvQ;
+    const float v = support_to_scalar(nv, dv);
+    val0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    val1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    const float dpb = half_bcast(dp, hi);
+    float *dst = hi ? dst1 : dst0;
+    if (ppol && dst) dst[j] = __fdividef(eP, dpb);
+}
+
+// The dynamics-layer tails of two rows, each row on its own branch (d0 / d1: dynamics = decode_scale_lanes -- reward logits
+// [0, S) | next state [S, 2 S) --, afterstate = scale_lanes over [0, S)): which lanes are logits and which are state is a lane
+// predicate per half.  Rewards returned (0 for an afterstate row); next states to act0 / act1 (LDS) and dst0 / dst1.
+__device__ inline void dynamics_tail_pair(float a0, float a1, bool d0, bool d1, int S, int lane, float *act0, float *act1,
+                                          float *dst0, float *dst1, float &rew0, float &rew1) {
+    float P = a0, Q = a1;
+    swap32(P, Q);
+    const bool hi = lane >= 32, dyn = hi ? d1 : d0;
+    const int j = lane & 31, oq = 32 + j, half = S / 2;
+    const bool plog = dyn && j < S;                                                         // (S <= 32: the reward logits lie in P)
+    const bool pst = dyn ? j >= S : j < S, qst = dyn && oq < 2 * S;
+    float mr = plog ? P : -__builtin_inff();
+    float mn = op_min(pst ? P : __builtin_inff(), qst ? Q : __builtin_inff());
+    float mx = op_max(pst ? P : -__builtin_inff(), qst ? Q : -__builtin_inff());
+    half_max_min_max(mr, mn, mx);
+    mr = half_bcast(mr, hi); mn = half_bcast(mn, hi); mx = half_bcast(mx, hi);
+    const float e = plog ? smz_exp(P - mr) : 0.f;
+    float den = e, num = plog ? (float)(j - half) * e : 0.f;
+    half_sum2(den, num);
+    const float r = support_to_scalar(num, den);
+    rew0 = d0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 31)) : 0.f;
+    rew1 = d1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 63)) : 0.f;
+    float sc = mx - mn;
+    if (sc < 1e-5f) sc += 1e-5f;
+    float *act = hi ? act1 : act0, *dst = hi ? dst1 : dst0;
+    const int ip = dyn ? j - S : j;
+    if (pst) { const float h = __fdividef(P - mn, sc); act[ip] = h; if (dst) dst[ip] = h; }
+    if (qst) { const float h = __fdividef(Q - mn, sc); act[oq - S] = h; if (dst) dst[oq - S] = h; }
+}
+
+// scale_lanes (outputs [0, S)) for two rows of the afterstate branch
+__device__ inline void scale_pair(float a0, float a1, int S, int lane, float *act0, float *act1, float *dst0, float *dst1) {
+    float P = a0, Q = a1;
+    swap32(P, Q);
+    const bool hi = lane >= 32;
+    const int j = lane & 31;
+    const bool in = j < S;                                                                  // (S <= 32)
+    float mn = in ? P : __builtin_inff(), mx = in ? P : -__builtin_inff();
+    half_minmax(mn, mx);
+    mn = half_bcast(mn, hi); mx = half_bcast(mx, hi);
+    float sc = mx - mn;
+    if (sc < 1e-5f) sc += 1e-5f;
+    float *act = hi ? act1 : act0, *dst = hi ? dst1 : dst0;
+    if (in) { const float h = __fdividef(P - mn, sc); act[j] = h; if (dst) dst[j] = h; }
+}
+
 // Float offsets of one matrix and its bias.  A descriptor's off[] must only ever be indexed with compile-time
 // constants: a run-time index (`off[dyn ? M_DYN_IN : M_ADY_IN]`) makes the compiler keep the whole table in scratch
 // memory and turns every layer's set-up into a global-memory round trip (measured: the dominant stall of a leaf
@@ -462,6 +596,23 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         }
         dense<U, R, SAME>(W, Bv, Ac, K4h, op, lane, acc);
     }
+    constexpr bool PAIRED = SMZ_PAIR_TAILS && U == 1 && R == 2;        // both rows' tails at once (see softmax_decode_pair)
+    if constexpr (PAIRED) {
+        if (S <= 32) {
+            reward[0] = reward[1] = 0.f;
+            if (!dyn[0] && !dyn[1]) scale_pair(acc[0][0], acc[1][0], S, lane, hbuf[0], hbuf[1], live[0] ? dst_hidden[0] : nullptr,
+                                               live[1] ? dst_hidden[1] : nullptr);
+            else dynamics_tail_pair(acc[0][0], acc[1][0], dyn[0], dyn[1], S, lane, hbuf[0], hbuf[1], live[0] ? dst_hidden[0] : nullptr,
+                                    live[1] ? dst_hidden[1] : nullptr, reward[0], reward[1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                reward[r] = 0.f;
+                if (dyn[r]) reward[r] = decode_scale_lanes<U>(acc[r], S, lane, hbuf[r], live[r] ? dst_hidden[r] : nullptr);
+                else scale_lanes<U>(acc[r], 0, S, lane, hbuf[r], live[r] ? dst_hidden[r] : nullptr);
+            }
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < R; r++) {
         reward[r] = 0.f;
@@ -470,6 +621,7 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         } else {
             scale_lanes<U>(acc[r], 0, S, lane, hbuf[r], live[r] ? dst_hidden[r] : nullptr);
         }
+    }
     }
     lds_sync();
     {
@@ -486,9 +638,19 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         }
         dense<U, R, SAME>(W, Bv, Ac, K4h, op, lane, acc);
     }
+    if constexpr (PAIRED) {
+        if (S <= 32 && A <= 32) {
+            softmax_decode_pair(acc[0][0], acc[1][0], A, S, lane, live[0] ? dst_policy[0] : nullptr, live[1] ? dst_policy[1] : nullptr,
+                                value[0], value[1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) value[r] = softmax_decode_lanes<U>(acc[r], A, S, lane, live[r] ? dst_policy[r] : nullptr);
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < R; r++) {
         value[r] = softmax_decode_lanes<U>(acc[r], A, S, lane, live[r] ? dst_policy[r] : nullptr);
+    }
     }
     lds_sync();
 }

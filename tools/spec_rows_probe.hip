@@ -78,6 +78,43 @@ __global__ void __launch_bounds__(512) probe(smz_mlp_desc d, const float *weight
     if (lane == 0) { atomicAdd(&out[0], t1 - t0); if (sink == 12345.f) out[1] = 1; }
 }
 
+// One pass of the two-row variants on per-wave pseudo-random inputs; everything the pass produces goes to `dump`
+// ([workgroup][wave][variant 0 / 1][row][40 floats]: 32 hidden | 4 policy | reward | value): two builds of this probe (e.g.
+// -DSMZ_PAIR_TAILS=0 / 1) must write identical files.
+__global__ void __launch_bounds__(512) dump_kernel(smz_mlp_desc d, const float *weights, float *dump, int waves) {
+    d.A = 2; d.S = 31; d.H = 64; d.L = 0; d.OP = kWave; d.obs = 4;
+    float *lds = reinterpret_cast<float *>(lds4);
+    const smz_mlp_desc dl = lds_desc_compact(d);
+    stage_weights_compact(lds, weights, d);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x / 64;
+    if (wave >= waves) return;
+    const int K4in = up4(d.S + d.A), rs = row_scratch_floats(d);
+    float *scratch = lds + ((dl.total_floats + 3) & ~3) + wave * (4 * rs + 4 * K4in + 16);
+    float *xall = scratch + 4 * rs, *outs = xall + 4 * K4in;
+    const unsigned id = blockIdx.x * waves + wave;
+    for (int k = lane; k < 2 * K4in; k += 64) {
+        unsigned h = (id * 2654435761u) ^ (k * 40503u + 12345u); h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+        const int kk = k % K4in;
+        xall[k] = kk < d.S ? (float)(h & 0xffff) / 65536.f : (kk == d.S + (int)((h >> 16) & 1) ? 1.f : 0.f);
+    }
+    lds_sync();
+    for (int var = 0; var < 2; var++) {
+        for (int b = 0; b < 2; b++) {
+            float *o = dump + (((size_t)id * 2 + var) * 2 + b) * 2 * 40;
+            const float *xin[2] = {xall, xall + K4in};
+            const bool b0 = b != 0;
+            const bool dyn[2] = {b0, var ? !b0 : b0}, live[2] = {true, true};
+            float *dh[2] = {o, o + 40}, *dp[2] = {outs, outs + 4};
+            float rw[2], vl[2];
+            if (var == 0) recurrent_rows<1, 2, true, true>(lds, dl, scratch, xin, dyn, live, dh, dp, rw, vl);
+            else recurrent_rows<1, 2, false, true>(lds, dl, scratch, xin, dyn, live, dh, dp, rw, vl);
+            lds_sync();
+            if (lane < 2) { o[32 + lane] = outs[lane]; o[40 + 32 + lane] = outs[4 + lane]; }
+            if (lane == 0) { o[36] = rw[0]; o[37] = vl[0]; o[40 + 36] = rw[1]; o[40 + 37] = vl[1]; }
+        }
+    }
+}
+
 template <int VAR>
 static double run(const smz_mlp_desc &d, const float *dw, float *dh, unsigned long long *dout, int waves, size_t lds, int reps) {
     CK(hipFuncSetAttribute((const void *)probe<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -97,7 +134,7 @@ static double run(const smz_mlp_desc &d, const float *dw, float *dh, unsigned lo
     return ticks;
 }
 
-int main() {
+int main(int argc, char **argv) {
     smz_mlp_desc d = {}; d.obs = 4; d.A = 2; d.S = 31; d.H = 64; d.L = 0;
     if (smz_mlp_layout(&d) != 0) { printf("layout failed\n"); return 1; }
     std::vector<float> w(d.total_floats);
@@ -110,6 +147,18 @@ int main() {
     const char *names[5] = {"2 rows, one branch (today, same-branch pair)", "2 rows, two branches (today, mixed pair)",
                             "2 x (2 rows, one branch) back to back (four rows with today's pass)",
                             "4 rows, one branch (weights read once)", "4 rows, per-row matrices (weights read four times)"};
+    if (argc > 1) {     // dump mode: the outputs of the two-row passes on 2048 distinct inputs -> file
+        const size_t n = (size_t)256 * 8 * 2 * 2 * 2 * 40;
+        float *dd; CK(hipMalloc(&dd, n * 4)); CK(hipMemset(dd, 0, n * 4));
+        CK(hipFuncSetAttribute((const void *)dump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(dump_kernel, dim3(256), dim3(512), lds, 0, d, dw, dd, 8);
+        CK(hipDeviceSynchronize());
+        std::vector<float> h(n); CK(hipMemcpy(h.data(), dd, n * 4, hipMemcpyDeviceToHost));
+        FILE *f = fopen(argv[1], "wb"); fwrite(h.data(), 4, n, f); fclose(f);
+        double sum = 0; int nan = 0; for (float v : h) { if (v != v) nan++; else sum += v; }
+        printf("dumped %zu floats to %s (sum %.6f, %d NaN)\n", n, argv[1], sum, nan);
+        return 0;
+    }
     for (int waves : {4, 8}) {
         printf("== %d wavefronts per CU (%d per SIMD), 256 workgroups\n", waves, waves / 4);
         const int reps = 400;

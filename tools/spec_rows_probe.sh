@@ -2,7 +2,7 @@
 # Builds tools/spec_rows_probe (stage 1 of the speculative-evaluation study) against the built libsmz.so and prints the static
 # instruction mix of every variant; run the binary on the GPU box:  tools/spec_rows_probe | tee gpurun_out/r05_spec_rows_probe.txt
 R=$(cd "$(dirname "$0")/.." && pwd); T=$(mktemp -d)
-cd $T && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -save-temps=obj -o $T/spec_rows_probe $R/tools/spec_rows_probe.hip \
+cd $T && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 $EXTRA -save-temps=obj -o $T/spec_rows_probe $R/tools/spec_rows_probe.hip \
     -L$R/stochastic-muzero_amd -l:libsmz.so -Wl,-rpath,'$ORIGIN/../stochastic-muzero_amd' 2>/dev/null || exit 1
 cp $T/spec_rows_probe $R/tools/spec_rows_probe
 python3 - $T/spec_rows_probe-hip-amdgcn-amd-amdhsa-gfx950.s <<'PY'
