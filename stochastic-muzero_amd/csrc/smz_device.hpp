@@ -823,23 +823,16 @@ __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int
 // leaf from the path's last two entries.
 // the leaf the path ends in, read back from the path (tracking it inside the chase loop instead costs the kernel its gain: the
 // register allocation of the whole kernel changes -- 453 against 462 M on one box, profiles/r04_bps_ab.txt)
-// node id of a path entry (block << 8 | pick)
-__device__ inline int select_node(const Params &P, int loc) {
-    const int b = loc >> 8, pk = loc & 3;
-    return b == 0 ? 1 + pk : 1 + P.A + (b - 1) * 2 + pk;
-}
-// ... from the path's last two entries themselves (the scalar chase keeps them in registers)
-__device__ inline Leaf select_leaf_locs(const Params &P, const uint32_t *tb, int last, int prev, int depth) {
-    const int lb = last >> 8, lp = last & 3;
+__device__ inline Leaf select_leaf(const Params &P, const uint32_t *tb, const uint16_t *path, int depth) {
+    const int A = P.A;
+    auto node = [&](int loc) { const int b = loc >> 8, pk = loc & 3; return b == 0 ? 1 + pk : 1 + A + (b - 1) * 2 + pk; };
+    const int last = path[depth - 1], lb = last >> 8, lp = last & 3;
     Leaf L;
-    L.leaf_id = select_node(P, last);
-    L.parent_id = depth > 1 ? select_node(P, prev) : 0;
+    L.leaf_id = node(last);
+    L.parent_id = depth > 1 ? node(path[depth - 2]) : 0;
     L.action = lb == 0 ? lp : (int)tb[P.rb_words + (size_t)(lb - 1) * P.eb_words + 5 * 2 + lp];
     L.branch = depth_flag(depth - 1);
     return L;
-}
-__device__ inline Leaf select_leaf(const Params &P, const uint32_t *tb, const uint16_t *path, int depth) {
-    return select_leaf_locs(P, tb, path[depth - 1], depth > 1 ? path[depth - 2] : 0, depth);
 }
 __device__ inline int select_chase(const uint16_t *sel, uint16_t *path) {
     int b = 0, depth = 0;
@@ -852,15 +845,11 @@ __device__ inline int select_chase(const uint16_t *sel, uint16_t *path) {
     }
 }
 template <class REC>
-__device__ inline void select_record_loc(const Params &P, const uint32_t *tb, int loc, int d, REC rec) {
-    const int b = loc >> 8, pick = loc & 3;
+__device__ inline void select_record(const Params &P, const uint32_t *tb, const uint16_t *path, int d, REC rec) {
+    const int loc = path[d], b = loc >> 8, pick = loc & 3;
     const uint32_t *bp = b == 0 ? tb : tb + P.rb_words + (size_t)(b - 1) * P.eb_words;
     const uint2 vv = *reinterpret_cast<const uint2 *>(bp + 2 * pick);                     // (visit, value_sum) of the picked child
     rec[d] = make_uint4((uint32_t)loc, vv.x, vv.y, bp[2 * (b == 0 ? P.A : 2) + pick]);
-}
-template <class REC>
-__device__ inline void select_record(const Params &P, const uint32_t *tb, const uint16_t *path, int d, REC rec) {
-    select_record_loc(P, tb, path[d], d, rec);
 }
 // YV kernels: the value term of the child in slot `sl` of block `b`, chosen at path level `level` (= the depth of the block's
 // node), goes beside the block -- unless that node samples its children (the two words hold its threshold then, and a value

@@ -643,11 +643,6 @@ extern __shared__ float4 smz_search_lds4[];
 #ifndef SMZ_EARLY_ROWS
 #define SMZ_EARLY_ROWS 1
 #endif
-// SMZ_SCALAR_CHASE (round 5): the block-parallel selection's descent on the scalar unit (v_readlane chase over the picks the
-// lanes keep in registers) instead of a pointer chase through LDS; -DSMZ_SCALAR_CHASE=0 builds keep the LDS chase
-#ifndef SMZ_SCALAR_CHASE
-#define SMZ_SCALAR_CHASE 1
-#endif
 #ifdef SMZ_BPS_PROBE
 #define SMZ_PROBE_DECL unsigned long long pb_t0 = 0, pb_acc[7] = {0, 0, 0, 0, 0, 0, 0};
 #define SMZ_PROBE_START pb_t0 = __builtin_amdgcn_s_memtime();
@@ -876,7 +871,6 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             const int nmax = max(__builtin_amdgcn_readlane(valid ? h.n_exp : -1, 0), __builtin_amdgcn_readlane(valid ? h.n_exp : -1, 1));
             const uint32_t *stb = tree_base(P, tree0 + src);
             SMZ_PROBE(1)
-            uint32_t rv0 = 0u, rv1 = 0u;           // the picks of blocks 0..31 / 32..63 of tree `src`, in the lane that computed them
             for (int base = 0; base <= nmax; base += kWave / 2) {
                 const int b = base + (lane >> 1);
                 if (b <= nexp) {
@@ -884,59 +878,23 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
                     const uint32_t r = select_block<MAXA, YV, RngT<PHC>>(P, stb, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged,
                                                                         pbc_lds);
                     selw[src * SELN + b] = (uint16_t)((depth << 9) | r);
-                    if (base == 0) rv0 = r;
-                    else if (base == kWave / 2) rv1 = r;
                 }
             }
+            smz_mlp::lds_sync();
             SMZ_PROBE(2)
-            int len = 0, blen = 0;
+            // the descent: the tree's lane follows the picks (one dependent LDS read per level) and leaves the path in the upper half
+            // of the tree's sel words (sel_n covers both); then one lane per level writes that level's path record.
+            // (The same chase on the scalar unit -- picks kept in the lanes that computed them, a v_readlane per level, path entries
+            // dropped into lanes by compare + select, no LDS traffic -- was built twice: round 4 at the 256-register limit (-8 %,
+            // scratch) and round 5 with 58 registers to spare (-4 %: 106 scalar registers are the limit too, and a taken scalar
+            // branch per level costs what the LDS round trip does); profiles/r05_f_pair_chase_ab.txt, commit "experiment: scalar
+            // chase".)
             uint16_t *pathw = selw + tpw * SELN;                                        // [tpw][sel_n]
-            bool scalar_chase = false;
-#if SMZ_SCALAR_CHASE
-            // Round 5: the descent over the picks as a chain of v_readlane + scalar arithmetic (~20 cycles a level) instead of one
-            // dependent LDS round trip a level (~250): the picks stay in the lanes that computed them (blocks 0..63: two registers),
-            // the chase runs on the scalar unit for both trees, every level's path entry is dropped into lane 2 d + t by a compare
-            // + select, and the last two entries -- leaf and parent -- stay in scalar registers.  No LDS traffic, no wave
-            // synchronisation between evaluation and chase.  (Round 4 measured this form 8 % SLOWER: the kernel then sat at the
-            // 256-register limit and the extra live registers went to scratch; with the paired network tails it needs 198.)
-            scalar_chase = nmax < kWave;                                                // (wave-uniform)
-            uint32_t pathv = 0u;
-            int lens[kFastTpw] = {0, 0};
-            uint32_t lasts[kFastTpw] = {0u, 0u}, prevs[kFastTpw] = {0u, 0u};
-            if (scalar_chase) {
-#pragma unroll
-                for (int t = 0; t < kFastTpw; t++) {
-                    if (!SMZ_SLOT_VALID(t)) continue;                                   // wave-uniform
-                    int b = 0, d = 0;
-                    uint32_t e_last = 0u, e_prev = 0u;
-                    for (;;) {
-                        const int ln = ((b & 31) << 1) | t;
-                        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)rv0, ln), s1 = (uint32_t)__builtin_amdgcn_readlane((int)rv1, ln);
-                        const uint32_t sw = b < kWave / 2 ? s0 : s1;
-                        if (!(sw & 0x100u)) { d = 0; break; }                           // a block on the way was not evaluated
-                        const uint32_t e = ((uint32_t)b << 8) | ((sw >> 7) & 1u);
-                        if (lane == 2 * d + t) pathv = e;
-                        e_prev = e_last; e_last = e;
-                        d++;
-                        b = (int)(sw & 127u);
-                        if (b == 0) break;
-                        if (d >= kWave / 2) { d = 0; break; }                           // deeper than the lanes a tree has: sequential descent
-                    }
-                    lens[t] = d; lasts[t] = e_last; prevs[t] = e_prev;
-                }
-                len = valid ? (lane ? lens[1] : lens[0]) : 0;
-                blen = src ? lens[1] : lens[0];
-            } else
-#endif
-            {
-                smz_mlp::lds_sync();
-                // the descent: the tree's lane follows the picks (one dependent LDS read per level) and leaves the path in the upper half
-                // of the tree's sel words (sel_n covers both); then one lane per level writes that level's path record
-                if (valid) len = select_chase(selw + lane * SELN, pathw + lane * SELN);
-                smz_mlp::lds_sync();
-                blen = pick_lane01(len, src);
-            }
+            int len = 0;
+            if (valid) len = select_chase(selw + lane * SELN, pathw + lane * SELN);
+            smz_mlp::lds_sync();
             SMZ_PROBE(3)
+            const int blen = pick_lane01(len, src);
 #if SMZ_EARLY_ROWS
             // Round 5: the leaf's PARENT is the path's last-but-one entry -- known here, before the path records, the leaf's
             // action and the stream position are worked out.  The loads of the wave's two parent rows (global memory: an L2 round
@@ -948,10 +906,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             bps_all = __ballot(valid && len == 0) == 0ull && __ballot(valid) != 0ull;
             if (bps_all) {
                 int par = 0;
-#if SMZ_SCALAR_CHASE
-                if (scalar_chase) { if (valid && len > 1) par = select_node(P, (int)(lane ? prevs[1] : prevs[0])); } else
-#endif
-                if (valid && len > 1) par = select_node(P, pathw[lane * SELN + len - 2]);
+                if (valid && len > 1) { const int loc = pathw[lane * SELN + len - 2], pb = loc >> 8; par = pb == 0 ? 1 + (loc & 3) : 1 + A + (pb - 1) * 2 + (loc & 3); }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // (rows stored in earlier rounds may be this round's parents)
 #pragma unroll
                 for (int t = 0; t < kFastTpw; t++) {
@@ -961,17 +916,8 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
                 }
             }
 #endif
-#if SMZ_SCALAR_CHASE
-            if (scalar_chase) {
-                if ((lane >> 1) < blen) select_record_loc(P, stb, (int)pathv, lane >> 1, pvals + src * P.P);
-            } else
-#endif
             for (int d = lane >> 1; d < blen; d += kWave / 2) select_record(P, stb, pathw + src * SELN, d, pvals + src * P.P);
             if (valid && len > 0) {
-#if SMZ_SCALAR_CHASE
-                if (scalar_chase) L = select_leaf_locs(P, stb, (int)(lane ? lasts[1] : lasts[0]), (int)(lane ? prevs[1] : prevs[0]), len);
-                else
-#endif
                 L = select_leaf(P, stb, pathw + lane * SELN, len);
                 const int nw = select_words(len, A);                    // the words the descent's levels drew (all inside the staged window)
                 rng.used += nw; rng.ready -= nw; rng.idx += nw;
