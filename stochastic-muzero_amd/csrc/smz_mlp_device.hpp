@@ -123,6 +123,10 @@ __device__ inline float elu(float x) { return x > 0.f ? x : smz_exp(x) - 1.0f; }
 #ifndef SMZ_PAIR_TAILS
 #define SMZ_PAIR_TAILS 1
 #endif
+// SMZ_ONE_DECODE (round 5): the reward's and the value's support decodes of a paired pass run as ONE instruction sequence
+#ifndef SMZ_ONE_DECODE
+#define SMZ_ONE_DECODE 1
+#endif
 #define SMZ_DPP_REDUCE(NAME, INSN)                                                               \
     __device__ inline float NAME(float v) {                                                      \
         asm SMZ_DPP_VOLATILE("s_nop 1\n\t"                                                               \
@@ -387,8 +391,12 @@ __device__ inline void half_sum5(float &a, float &b, float &c, float &d, float &
 }
 
 // softmax_decode_lanes for two rows: policies to dst0 / dst1 (non-null), values returned
+// WITH_REWARD: rnum / rden hold the dynamics tail's reward sums in lanes 31 / 63 (dynamics_tail_pair<true>); they move one
+// lane down (DPP row_shl:1: lanes 30 / 62) into the registers whose lanes 31 / 63 hold the value's sums, and ONE
+// support_to_scalar decodes all four (the same instruction sequence on the same operands: bit-identical).
+template <bool WITH_REWARD = false>
 __device__ inline void softmax_decode_pair(float a0, float a1, int A, int S, int lane, float *dst0, float *dst1, float &val0,
-                                           float &val1) {
+                                           float &val1, float rnum = 0.f, float rden = 0.f, float *rew0 = nullptr, float *rew1 = nullptr) {
     float P = a0, Q = a1;
     swap32(P, Q);
     const bool hi = lane >= 32;
@@ -404,10 +412,21 @@ __device__ inline void softmax_decode_pair(float a0, float a1, int A, int S, int
     float dvQ = eQ, nvQ = qval ? (float)(oq - A - half) * eQ : 0.f;
     half_sum5(dp, dvP, nvP, dvQ, nvQ);
     // lanes 31 / 63: the rows' totals in wave_sum3's association; the decode runs there, once for both rows
-    const float dv = dvP + dvQ, nv = nvP + nvQ;
+    float dv = dvP + dvQ, nv = nvP + nvQ;
+    if constexpr (WITH_REWARD) {
+        const float sn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rnum), 0x101, 0xf, 0xf, false));   // row_shl:1
+        const float sd = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rden), 0x101, 0xf, 0xf, false));
+        const bool rl = (lane & 31) == 30;
+        nv = rl ? sn : nv;
+        dv = rl ? sd : dv;
+    }
     const float v = support_to_scalar(nv, dv);
     val0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
     val1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    if constexpr (WITH_REWARD) {
+        *rew0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 30));
+        *rew1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 62));
+    }
     const float dpb = half_bcast(dp, hi);
     float *dst = hi ? dst1 : dst0;
     if (ppol && dst) dst[j] = __fdividef(eP, dpb);
@@ -416,8 +435,11 @@ __device__ inline void softmax_decode_pair(float a0, float a1, int A, int S, int
 // The dynamics-layer tails of two rows, each row on its own branch (d0 / d1: dynamics = decode_scale_lanes -- reward logits
 // [0, S) | next state [S, 2 S) --, afterstate = scale_lanes over [0, S)): which lanes are logits and which are state is a lane
 // predicate per half.  Rewards returned (0 for an afterstate row); next states to act0 / act1 (LDS) and dst0 / dst1.
+// With `defer` the reward's (num, den) -- lanes 31 / 63 of rnum / rden -- are handed on instead of being decoded: the
+// prediction tail decodes them together with the value's (softmax_decode_pair: ONE support decode per pass).
+template <bool DEFER = false>
 __device__ inline void dynamics_tail_pair(float a0, float a1, bool d0, bool d1, int S, int lane, float *act0, float *act1,
-                                          float *dst0, float *dst1, float &rew0, float &rew1) {
+                                          float *dst0, float *dst1, float &rew0, float &rew1, float *rnum = nullptr, float *rden = nullptr) {
     float P = a0, Q = a1;
     swap32(P, Q);
     const bool hi = lane >= 32, dyn = hi ? d1 : d0;
@@ -432,9 +454,14 @@ __device__ inline void dynamics_tail_pair(float a0, float a1, bool d0, bool d1, 
     const float e = plog ? smz_exp(P - mr) : 0.f;
     float den = e, num = plog ? (float)(j - half) * e : 0.f;
     half_sum2(den, num);
-    const float r = support_to_scalar(num, den);
-    rew0 = d0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 31)) : 0.f;
-    rew1 = d1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 63)) : 0.f;
+    if constexpr (DEFER) {
+        *rnum = num; *rden = den;
+        rew0 = rew1 = 0.f;
+    } else {
+        const float r = support_to_scalar(num, den);
+        rew0 = d0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 31)) : 0.f;
+        rew1 = d1 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 63)) : 0.f;
+    }
     float sc = mx - mn;
     if (sc < 1e-5f) sc += 1e-5f;
     float *act = hi ? act1 : act0, *dst = hi ? dst1 : dst0;
@@ -597,13 +624,19 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         dense<U, R, SAME>(W, Bv, Ac, K4h, op, lane, acc);
     }
     constexpr bool PAIRED = SMZ_PAIR_TAILS && U == 1 && R == 2;        // both rows' tails at once (see softmax_decode_pair)
+    float pair_rnum = 0.f, pair_rden = 0.f;                            // (the reward's sums of a dynamics row, decoded with the value's)
+    bool pair_reward = false;
     if constexpr (PAIRED) {
         if (S <= 32) {
             reward[0] = reward[1] = 0.f;
             if (!dyn[0] && !dyn[1]) scale_pair(acc[0][0], acc[1][0], S, lane, hbuf[0], hbuf[1], live[0] ? dst_hidden[0] : nullptr,
                                                live[1] ? dst_hidden[1] : nullptr);
-            else dynamics_tail_pair(acc[0][0], acc[1][0], dyn[0], dyn[1], S, lane, hbuf[0], hbuf[1], live[0] ? dst_hidden[0] : nullptr,
-                                    live[1] ? dst_hidden[1] : nullptr, reward[0], reward[1]);
+            else if (SMZ_ONE_DECODE) {
+                dynamics_tail_pair<true>(acc[0][0], acc[1][0], dyn[0], dyn[1], S, lane, hbuf[0], hbuf[1], live[0] ? dst_hidden[0] : nullptr,
+                                         live[1] ? dst_hidden[1] : nullptr, reward[0], reward[1], &pair_rnum, &pair_rden);
+                pair_reward = true;
+            } else dynamics_tail_pair(acc[0][0], acc[1][0], dyn[0], dyn[1], S, lane, hbuf[0], hbuf[1], live[0] ? dst_hidden[0] : nullptr,
+                                      live[1] ? dst_hidden[1] : nullptr, reward[0], reward[1]);
         } else {
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -639,7 +672,13 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         dense<U, R, SAME>(W, Bv, Ac, K4h, op, lane, acc);
     }
     if constexpr (PAIRED) {
-        if (S <= 32 && A <= 32) {
+        if (S <= 32 && A <= 32 && pair_reward) {                       // (wave-uniform)
+            float r0, r1;
+            softmax_decode_pair<true>(acc[0][0], acc[1][0], A, S, lane, live[0] ? dst_policy[0] : nullptr,
+                                      live[1] ? dst_policy[1] : nullptr, value[0], value[1], pair_rnum, pair_rden, &r0, &r1);
+            reward[0] = dyn[0] ? r0 : 0.f;
+            reward[1] = dyn[1] ? r1 : 0.f;
+        } else if (S <= 32 && A <= 32) {
             softmax_decode_pair(acc[0][0], acc[1][0], A, S, lane, live[0] ? dst_policy[0] : nullptr, live[1] ? dst_policy[1] : nullptr,
                                 value[0], value[1]);
         } else {
