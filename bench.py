@@ -171,16 +171,18 @@ def cpu_baseline_mlp(wl, weights_path, seconds_target=15.0):
                        f"(os.cpu_count() = {os.cpu_count()}; cores = affinity mask capped by the cgroup CPU quota)")
 
 
-def cpu_baseline_vision(wl, model, seconds_target=12.0):
-    """Vision family: the oracle's tree arithmetic (C) driven by the model's batch-1 torch-CPU inference functions -- the
-    call shape of the reference's own search (muzero_model.py:802-909), one process, one torch thread."""
+def _vision_cpu_worker(weights_path, A, K, sims, seconds, seed):
+    """One process of the vision cpu_baseline: the oracle's tree arithmetic (C) driven by the model's batch-1 torch-CPU inference
+    functions -- the call shape of the reference's own search (muzero_model.py:802-909) -- for `seconds`; returns simulations done."""
     import numpy as np
     import torch
     import orc
+    from importlib import import_module
+    import stochastic_muzero_amd  # noqa: F401
     torch.set_num_threads(1)
-    A, K, sims = wl["A"], wl["K"], wl["sims"]
+    model = import_module("stochastic-muzero_amd.model").Muzero.from_state_dicts(weights_path)
     cfg = orc.make_cfg(A, K, 147, sims, discount=0.999, alpha=0.25, frac=0.1)
-    rs = np.random.RandomState(0)
+    rs = np.random.RandomState(seed)
 
     def search(tree, frame):
         h = model.representation_function_inference(frame)
@@ -196,18 +198,42 @@ def cpu_baseline_vision(wl, model, seconds_target=12.0):
                 reward, h2 = 0.0, model.afterstate_dynamics_function_inference(ph, act)
                 pol, val = model.afterstate_prediction_function_inference(h2)
             tree.expand_backup(np.asarray(pol, np.float32).reshape(-1), float(val), reward=float(reward), hidden=h2.numpy().reshape(-1))
+    tree = orc.Tree(cfg)
+    tree.seed(seed)
+    search(tree, torch.from_numpy(rs.rand(1, 3, 98, 98).astype(np.float32)))          # (warm-up: lazy initialisation is not work)
     t0 = time.perf_counter()
     done = 0
-    tree = orc.Tree(cfg)
-    tree.seed(0)
-    while time.perf_counter() - t0 < seconds_target:
+    while time.perf_counter() - t0 < seconds:
         search(tree, torch.from_numpy(rs.rand(1, 3, 98, 98).astype(np.float32)))
         done += sims
-    dt = time.perf_counter() - t0
-    return dict(value=done / dt, unit="simulations/s", cores=1, kind="port",
-                sample=f"PER CORE: {done // sims} searches x {sims} sims on 98x98x3 frames, oracle tree (oracle/smz_oracle.c) driven by "
-                       f"batch-1 torch-CPU heads of the same ResNet-v2 weights, 1 process / 1 torch thread of {host_cores()} host "
-                       f"cores, {dt:.1f} s (the reference's Ray fan-out would run one such process per core)")
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline_vision(wl, weights_path, seconds_target=12.0):
+    """Vision family on ALL usable host cores (SURVEY 8d's shape: one game per worker process, the reference's Ray fan-out
+    without Ray): `cores` child processes -- started before this process touches the GPU, torch-CPU only (the GPU is hidden from
+    them) -- each running _vision_cpu_worker for the same wall-clock window; the figure is the sum."""
+    cores = host_cores()
+    code = ("import sys, json; sys.path[:0] = [%r, %r]; import bench; "
+            "print(json.dumps(bench._vision_cpu_worker(%r, %d, %d, %d, %f, int(sys.argv[1]))))"
+            % (ROOT, os.path.join(ROOT, "oracle"), weights_path, wl["A"], wl["K"], wl["sims"], seconds_target))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(i)], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for i in range(cores)]
+    outs = []
+    for p_ in procs:
+        o, _ = p_.communicate(timeout=seconds_target * 6 + 300)
+        lines = [ln for ln in o.splitlines() if ln.startswith("[")]
+        if p_.returncode == 0 and lines:
+            outs.append(json.loads(lines[-1]))
+    done = sum(o[0] for o in outs)
+    dt = max((o[1] for o in outs), default=float("nan"))
+    one = max((o[0] / o[1] for o in outs), default=float("nan"))
+    return dict(value=done / dt if outs else float("nan"), unit="simulations/s", cores=len(outs), kind="port",
+                sample=f"{done // wl['sims']} searches x {wl['sims']} sims on 98x98x3 frames in {dt:.1f} s: oracle tree (oracle/smz_oracle.c) driven by "
+                       f"batch-1 torch-CPU heads of the same ResNet-v2 weights, {len(outs)} worker processes x 1 torch thread (the shape of the "
+                       f"reference's Ray fan-out: one game per worker) on the {cores} cores the cgroup quota grants; fastest single "
+                       f"process {one:.0f} simulations/s")
 
 
 class ReplaySink:
@@ -394,7 +420,7 @@ def main():
     # the CPU leg runs FIRST (rank 0, N = 1 only, bounded wall time): the GPU part then fills the rest of the command's run time
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rccl_loopback:
-        cpu_baseline = (cpu_baseline_vision(wl, model, args.cpu_baseline_seconds) if wl["env"] == "image"
+        cpu_baseline = (cpu_baseline_vision(wl, wpath, args.cpu_baseline_seconds) if wl["env"] == "image"
                         else cpu_baseline_mlp(wl, wpath, args.cpu_baseline_seconds))
     T = max(args.steps, args.warmup, 1)
     # host envs behind Python (--host-env python): two env groups, so that one group's search runs while the other's envs step

@@ -633,6 +633,12 @@ __device__ inline void cartpole_env_step(const EnvStep &E, int e, int B, const i
 // ---------------------------------------------------------------------------------------------------------------
 extern __shared__ float4 smz_search_lds4[];
 
+// SMZ_BPS_HBM (round 5): the block-parallel selection also in the specialised kernels whose trees stay in global memory (more
+// simulations than LDS holds: BASELINE configs[4]'s per-rank shape) -- every block of a tree is then ONE load from L2 issued by
+// its own lane, instead of one dependent L2 round trip per level of the descent
+#ifndef SMZ_BPS_HBM
+#define SMZ_BPS_HBM 1
+#endif
 #ifndef SMZ_SELECT_BLOCKS
 #define SMZ_SELECT_BLOCKS 1       // block-parallel selection in the kernels that keep their trees in LDS (A/B builds: 0)
 #endif
@@ -659,7 +665,8 @@ extern __shared__ float4 smz_search_lds4[];
 //   mlp scratch | network inputs [tpw][K4in] | path records [tpw][P] uint4 | rng tile | head outputs
 struct MegaLds {
     int pbc_off, wave_off, per_wave;                       // float offsets from the LDS base
-    int x_off, pv_off, rng_off, out_off, sel_off, sel_n;   // float offsets inside a wave's region (sel: TLDS, block-parallel select)
+    int x_off, pv_off, rng_off, out_off, sel_off, sel_n;   // float offsets inside a wave's region (sel: block-parallel select)
+    int sel_on;                                            // the selection words are there
     int trees_off, tree_words;                             // TLDS: the workgroup's trees (words per tree, blocks packed at 6 K words)
 };
 __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
@@ -674,7 +681,16 @@ __host__ __device__ inline MegaLds mega_lds(const smz_mlp_desc &d, const Params 
     m.out_off = m.rng_off + r4(tpw * kRngStride);
     m.sel_off = m.out_off + r4(tpw * (P.A + 2));
     m.sel_n = (P.sims + 2 + 1) & ~1;                       // 16-bit words per tree: one per block (select_block / select_chase)
-    m.per_wave = m.sel_off + (tlds ? r4(tpw * m.sel_n) : 0);      // (picks per block + the path of the descent: 2 x tpw x sel_n 16-bit words)
+    // (picks per block + the path of the descent: 2 x tpw x sel_n 16-bit words.)  Round 5: the kernels whose trees stay in
+    // global memory run the block-parallel selection too (SMZ_BPS_HBM) -- two actions, two children, up to 126 simulations,
+    // and only when the words fit beside everything else (host and device evaluate this same function)
+    bool sel = tlds;
+    if (!tlds && SMZ_BPS_HBM && P.A == 2 && P.K == 2 && tpw == 2 && P.sims <= 126) {
+        const int per = m.sel_off + r4(tpw * m.sel_n);
+        sel = ((size_t)m.wave_off + (size_t)waves * per) * sizeof(float) <= (size_t)160 * 1024;
+    }
+    m.sel_on = sel ? 1 : 0;
+    m.per_wave = m.sel_off + (sel ? r4(tpw * m.sel_n) : 0);
     m.tree_words = r4(P.rb_words + P.sims * 6 * P.K + (P.K == 2 ? 2 * P.sims : 0));   // (+ the chance thresholds, one double per block;
                                                                                       //  trees stay 16-byte aligned)
     m.trees_off = m.wave_off + waves * m.per_wave;
@@ -853,12 +869,12 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         // Trees in LDS: block-parallel selection (smz_device.hpp, select_block / select_chase) -- every block of the wave's two
         // trees gets a lane that computes the block's pick from the words its level will read, then the tree's lane follows the
         // picks.  SMZ_SELECT_BLOCKS=0 (-DSMZ_SELECT_BLOCKS=0 builds) keeps the level-by-level descent.
-        constexpr bool BPS = SMZ_SELECT_BLOCKS && AEX && KS == 2 && TLDS && !INSTR && MAXA == 2;   // (four actions: the root is a
+        constexpr bool BPS = SMZ_SELECT_BLOCKS && AEX && KS == 2 && (TLDS || SMZ_BPS_HBM) && !INSTR && MAXA == 2;   // (four actions: the root is a
         // code path of its own beside the blocks' -- measured 409 against 458 M, profiles/r04_bps_ab.txt)
         bool bps_done = false;
         bool bps_all = false;                 // every tree of the wave went through the block-parallel selection this round
         float early_row[kFastTpw] = {0.f, 0.f};
-        if constexpr (BPS) {
+        if constexpr (BPS) if (TLDS || ml.sel_on) {
             uint16_t *selw = reinterpret_cast<uint16_t *>(scratch + ml.sel_off);          // [tpw][sel_n]
             const int SELN = ml.sel_n;
             if (valid && s > 0) selw[lane * SELN + h.n_exp] = (uint16_t)(h.path_len << 9);   // depth of the node the expansion created
@@ -1905,7 +1921,7 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
     while (tpw < kFastTpw && (size_t)256 * kWaves * tpw < (size_t)P.B) tpw <<= 1;
     if (const char *e = getenv("SMZ_SEARCH_TPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) tpw = v; }
     P.tpw = tpw;
-    const MegaLds ml = mega_lds(*desc, P, tpw);
+    const MegaLds ml = mega_lds(*desc, P, tpw, false, kWaves);
     const size_t lds = ((size_t)ml.wave_off + (size_t)kWaves * ml.per_wave) * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_TOO_LARGE, "smz_search_mlp: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kWaves * tpw - 1) / (kWaves * tpw);
