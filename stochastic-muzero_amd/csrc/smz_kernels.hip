@@ -506,7 +506,8 @@ __global__ void __launch_bounds__(kWave, 4) k_select(Params Pin, float *parent_h
 #endif
 
 #if SMZ_PART != 2 && SMZ_PART != 4 && SMZ_PART != 5 && SMZ_PART != 6
-template <int MAXA, int KS, bool FUSE_SELECT, bool AEX>
+// PHX (round 5, with AEX): the specialised kernel for Philox handles -- counter streams, no MT19937 state to load, twist or store
+template <int MAXA, int KS, bool FUSE_SELECT, bool AEX, bool PHX = false>
 __global__ void __launch_bounds__(kWave, MAXA > 16 ? 1 : SMZ_EB_WAVES) k_expand_backup(Params Pin, const float *hidden, const float *reward,
                                                          const float *policy, const float *value,
                                                          float *parent_hidden, int32_t *last_action, uint8_t *branch,
@@ -514,6 +515,7 @@ __global__ void __launch_bounds__(kWave, MAXA > 16 ? 1 : SMZ_EB_WAVES) k_expand_
     Params P = Pin;
     P.tree0 = 0;
     if (AEX) P.A = MAXA;
+    if (AEX) P.philox = PHX ? 1 : 0;          // (a constant in everything inlined below)
     if (KS > 0) P.K = KS;
     fix_layout(P, AEX, KS > 0);
     uint32_t *rng_tile = rng_tile_ptr(P);
@@ -522,8 +524,8 @@ __global__ void __launch_bounds__(kWave, MAXA > 16 ? 1 : SMZ_EB_WAVES) k_expand_
     const int tree = blockIdx.x * P.tpw + threadIdx.x;
     const bool valid = (int)threadIdx.x < P.tpw && tree < P.B && tree_active(P, tree);
     const double *pbc_lds = stage_pbc(P);
-    const int packed = narrow ? wave_stage_rng_narrow(P, tree, valid, rng_tile) : wave_stage_rng<!AEX>(P, tree, valid, rng_tile);
-    RngT<!AEX> rng;
+    const int packed = narrow ? wave_stage_rng_narrow(P, tree, valid, rng_tile) : wave_stage_rng<!AEX || PHX>(P, tree, valid, rng_tile);
+    RngT<!AEX || PHX> rng;
     rng.bind(P, tree, valid);
     TreeHdr h = {0, 0, 0.f, 0.f, 0, 0.f, 0, 0};
     int leaf = 0;
@@ -1804,6 +1806,16 @@ int smz_expand_backup_select(smz_handle *h, const float *hidden_dev, const float
     if (!h || !policy_dev || !value_dev) return fail(SMZ_ERR_INVALID, "smz_expand_backup_select: null argument%s");
     if (!h->selected) return fail(SMZ_ERR_STATE, "smz_expand_backup_select without a preceding smz_select%s");
     DeviceGuard guard(h->cfg.device);
+    if (h->P.philox && h->P.A == h->maxa && h->maxa <= 4) {       // Philox handles, exact action count: the specialised kernel too
+#define SMZ_EBS_PHX(MA, KS)                                                                                                  \
+        hipLaunchKernelGGL((k_expand_backup<MA, KS, true, true, true>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),   \
+                           (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev, parent_hidden_dev,     \
+                           last_action_dev, branch_dev, mlp_input_dev)
+        if (h->maxa == 2) { if (h->K == 2) SMZ_EBS_PHX(2, 2); else SMZ_EBS_PHX(2, 0); }
+        else { if (h->K == 2) SMZ_EBS_PHX(4, 2); else SMZ_EBS_PHX(4, 0); }
+#undef SMZ_EBS_PHX
+        return launch_check();
+    }
     SMZ_DISPATCH2_AEX(h->maxa, h->K, h->P.A == h->maxa && !h->P.philox, hipLaunchKernelGGL((k_expand_backup<MA, KS, true, AEX>), wave_grid(h->P), dim3(kWave), tree_lds_bytes(h->P),
                                              (hipStream_t)stream, h->P, hidden_dev, reward_dev, policy_dev, value_dev,
                                              parent_hidden_dev, last_action_dev, branch_dev, mlp_input_dev));
