@@ -83,7 +83,7 @@ class _Sub:
                                              # more simulations than LDS holds: the kernels whose trees stay in global memory, with
                                              # the per-tree mask and with restarts (round 5: block-parallel selection there too,
                                              # three passes of blocks at 70 simulations)
-                                             ("mask", 4096, 70, 4), ("reset", 4096, 70, 3)])
+                                             ("mask", 4096, 70, 4), ("reset", 4096, 70, 6)])
 def test_every_tree_of_every_step_of_the_timed_loop_equals_the_oracle(on_end, B, sims, T):
     import orc
     import stochastic_muzero_amd as smz
