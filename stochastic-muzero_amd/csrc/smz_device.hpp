@@ -790,7 +790,7 @@ __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int
     {
         // two actions: the root block has the expansion blocks' field offsets (A == K == 2), so the root is ONE code path with
         // the decision-flagged blocks -- its float64 priors, its value terms and its visit count come from their own places
-        const bool root = MAXA == 2 && b == 0;                 // (four actions: the root has its own lanes, select_root_quad)
+        const bool root = b == 0;
         const uint32_t *bp = root ? tb : tb + P.rb_words + (size_t)(b - 1) * P.eb_words;
         const uint32_t *aux = root ? tb + (RY ? P.ry_off : 0) : tb + P.thr_off + (size_t)(b - 1) * P.thr_stride;
         Kids<2> k;
@@ -813,51 +813,8 @@ __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int
         }
         c = pick ? k.chd[1] : k.chd[0];
     }
-    static_assert(MAXA == 2 || MAXA == 4, "block-parallel selection: two actions, or four with the root on a quad (select_root_quad)");
+    static_assert(MAXA == 2, "one bit for the pick: the block-parallel selection is built for two actions");
     return 0x100u | ((uint32_t)pick << 7) | (uint32_t)c;
-}
-// Round 5, four actions: the root's four children on the four lanes of a quad (lane = 4 tree slot + child).  Every lane scores
-// its child with the arithmetic of pick_decision's scan (puct_score on the words level 0 draws for that child: words 2 c and
-// 2 c + 1 behind the stream position), then the quad agrees on the argmax with two quad-perm exchanges: the larger score wins,
-// an exact tie goes to the larger action -- what the sequential `score >= best` scan ends with.  Returns the root's selection
-// word in the lane of the picked child (pick << 9 | ok << 8 | next block; the root's depth bits are free) and ~0u elsewhere.
-__device__ inline double quad_xor1(double v) {             // value held by lane ^ 1
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-template <bool YV, class RNG>
-__device__ inline uint32_t select_root_quad(const Params &P, const uint32_t *tb, int c, int root_visit, float mn, float mx,
-                                            const uint32_t *stage, int used, int staged, const double *pbc_sqrt) {
-    constexpr int A = 4;
-    const bool ok = used + 2 * A <= staged;
-    const uint32_t *w = stage + used;
-    Kids<1> k;
-    k.vis[0] = (int32_t)tb[2 * c];
-    k.vsum[0] = __uint_as_float(tb[2 * c + 1]);
-    k.rew[0] = __uint_as_float(tb[2 * A + c]);
-    k.pri[0] = 0.f;
-    k.chd[0] = (int32_t)tb[4 * A + c];
-    k.act[0] = c;
-    k.pri64[0] = reinterpret_cast<const double *>(tb + P.rp_off)[c];
-    k.yv[0] = YV ? __uint_as_float(tb[P.ry_off + c]) : 0.f;
-    const bool norm = mx > mn;
-    const float span = mx - mn;
-    const double u = ok ? RNG::to_double(w[2 * c], w[2 * c + 1]) : 0.0;
-    double best = puct_score<1, YV>(k, 0, pbc_sqrt[root_visit], norm, mn, span, P.disc32, u, pbc_sqrt + P.sims + 2);
-    int pick = c;
-    {
-        const double ob = quad_xor1(best);
-        const int op = __builtin_amdgcn_update_dpp(0, pick, 0xB1, 0xf, 0xf, false);
-        if (ob > best || (ob == best && op > pick)) { best = ob; pick = op; }
-    }
-    {
-        const double ob = quad_partner(best);              // lane ^ 2
-        const int op = __builtin_amdgcn_update_dpp(0, pick, 0x4E, 0xf, 0xf, false);
-        if (ob > best || (ob == best && op > pick)) { best = ob; pick = op; }
-    }
-    pick = __builtin_amdgcn_update_dpp(0, pick, 0x00, 0xf, 0xf, false);     // (the quad's first lane has the last word)
-    return c == pick ? (((uint32_t)pick << 9) | (ok ? 0x100u : 0u) | (uint32_t)k.chd[0]) : ~0u;
 }
 // The descent over the evaluated blocks, in two steps.  (1) select_chase, by the tree's lane: follow sel[] from the root --
 // ONE dependent LDS read per level -- and leave (block << 8 | pick) of every level in `path`; returns the depth (0: a block on
@@ -877,13 +834,12 @@ __device__ inline Leaf select_leaf(const Params &P, const uint32_t *tb, const ui
     L.branch = depth_flag(depth - 1);
     return L;
 }
-template <bool ROOT4 = false>        // ROOT4: the root's pick has two bits, kept where a block's depth sits (select_root_quad)
 __device__ inline int select_chase(const uint16_t *sel, uint16_t *path) {
     int b = 0, depth = 0;
     for (;;) {
         const uint32_t s = sel[b];
         if (!(s & 0x100u)) return 0;
-        path[depth++] = (uint16_t)((b << 8) | ((ROOT4 && b == 0) ? ((s >> 9) & 3u) : ((s >> 7) & 1u)));
+        path[depth++] = (uint16_t)((b << 8) | ((s >> 7) & 1u));
         b = (int)(s & 127u);
         if (b == 0) return depth;
     }

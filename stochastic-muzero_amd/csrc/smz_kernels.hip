@@ -641,11 +641,6 @@ extern __shared__ float4 smz_search_lds4[];
 #ifndef SMZ_BPS_HBM
 #define SMZ_BPS_HBM 1
 #endif
-// SMZ_BPS_A4 (round 5): the block-parallel selection for four actions (LDS-resident trees): the root's four children are scored
-// on the four lanes of a quad (select_root_quad), the two-child blocks below it by a lane each as for two actions
-#ifndef SMZ_BPS_A4
-#define SMZ_BPS_A4 1
-#endif
 #ifndef SMZ_SELECT_BLOCKS
 #define SMZ_SELECT_BLOCKS 1       // block-parallel selection in the kernels that keep their trees in LDS (A/B builds: 0)
 #endif
@@ -876,8 +871,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         // Trees in LDS: block-parallel selection (smz_device.hpp, select_block / select_chase) -- every block of the wave's two
         // trees gets a lane that computes the block's pick from the words its level will read, then the tree's lane follows the
         // picks.  SMZ_SELECT_BLOCKS=0 (-DSMZ_SELECT_BLOCKS=0 builds) keeps the level-by-level descent.
-        constexpr bool BPS = SMZ_SELECT_BLOCKS && AEX && KS == 2 && !INSTR &&
-                             ((MAXA == 2 && (TLDS || SMZ_BPS_HBM)) || (MAXA == 4 && TLDS && SMZ_BPS_A4));   // (four actions: the root is a
+        constexpr bool BPS = SMZ_SELECT_BLOCKS && AEX && KS == 2 && (TLDS || SMZ_BPS_HBM) && !INSTR && MAXA == 2;   // (four actions: the root is a
         // code path of its own beside the blocks' -- measured 409 against 458 M, profiles/r04_bps_ab.txt)
         bool bps_done = false;
         bool bps_all = false;                 // every tree of the wave went through the block-parallel selection this round
@@ -895,22 +889,9 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             const int nmax = max(__builtin_amdgcn_readlane(valid ? h.n_exp : -1, 0), __builtin_amdgcn_readlane(valid ? h.n_exp : -1, 1));
             const uint32_t *stb = tree_base(P, tree0 + src);
             SMZ_PROBE(1)
-            if constexpr (MAXA == 4) {
-                // four actions: the root's four children on a quad per tree (lanes 0..3 | 4..7), then the blocks as below
-                const int qt = (lane >> 2) & 1;
-                auto of = [&](int v) { const int a0 = __builtin_amdgcn_readlane(v, 0), a1 = __builtin_amdgcn_readlane(v, 1); return qt ? a1 : a0; };
-                const int qn = of(valid ? h.n_exp : -1), qrv = of(h.root_visit), qus = of(valid ? rng.used : 0), qsg = of(valid ? rng.staged : 0);
-                const int qst = of(valid ? (int)(rng.stage - rng_tile) : 0);
-                const float qmn = __int_as_float(of(__float_as_int(h.mn))), qmx = __int_as_float(of(__float_as_int(h.mx)));
-                if (lane < 8 && qn >= 0) {
-                    const uint32_t r = select_root_quad<YV, RngT<PHC>>(P, tree_base(P, tree0 + qt), lane & 3, qrv, qmn, qmx, rng_tile + qst, qus, qsg,
-                                                                     pbc_lds);
-                    if (r != ~0u) selw[qt * SELN] = (uint16_t)r;
-                }
-            }
             for (int base = 0; base <= nmax; base += kWave / 2) {
                 const int b = base + (lane >> 1);
-                if (b <= nexp && (MAXA == 2 || b > 0)) {
+                if (b <= nexp) {
                     const int depth = b == 0 ? 0 : (int)(selw[src * SELN + b] >> 9);
                     const uint32_t r = select_block<MAXA, YV, RngT<PHC>>(P, stb, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged,
                                                                         pbc_lds);
@@ -928,7 +909,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             // chase".)
             uint16_t *pathw = selw + tpw * SELN;                                        // [tpw][sel_n]
             int len = 0;
-            if (valid) len = select_chase<MAXA == 4>(selw + lane * SELN, pathw + lane * SELN);
+            if (valid) len = select_chase(selw + lane * SELN, pathw + lane * SELN);
             smz_mlp::lds_sync();
             SMZ_PROBE(3)
             const int blen = pick_lane01(len, src);
