@@ -100,6 +100,34 @@ __device__ inline void dense(const float *const (&W)[R], const float *const (&bi
     dense<U, R, SAME>(W, bias, act, K4, op, lane, acc);
 }
 
+// A layer with at most 32 outputs for TWO rows at once on lane halves: lane l computes output l & 31 of row l >> 5 (row 0 reads
+// act0, row 1 act1; both use matrix W).  The chain of every output is dense()'s (even / odd inputs in the halves of a packed
+// register, four 4-wide steps per iteration, added at the end): bit-identical, in half the multiply-add instructions.
+__device__ inline float dense_halves(const float *W, const float *bias, const float *act0, const float *act1, int K4, int OP, int lane) {
+    const int o = lane & 31;
+    const float4 *a4 = reinterpret_cast<const float4 *>(lane < 32 ? act0 : act1);
+    const float4 *w4 = reinterpret_cast<const float4 *>(W) + o;
+    v2f acc2 = {bias[o], 0.f};
+    const int n = K4 >> 2;
+    int q = 0;
+    for (; q + 4 <= n; q += 4) {
+        float4 a[4], w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { a[j] = a4[q + j]; w[j] = w4[(size_t)(q + j) * OP]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            acc2 = pk_fma(w[j].x, w[j].y, a[j].x, a[j].y, acc2);
+            acc2 = pk_fma(w[j].z, w[j].w, a[j].z, a[j].w, acc2);
+        }
+    }
+    for (; q < n; q++) {
+        const float4 av = a4[q], wv = w4[(size_t)q * OP];
+        acc2 = pk_fma(wv.x, wv.y, av.x, av.y, acc2);
+        acc2 = pk_fma(wv.z, wv.w, av.z, av.w, acc2);
+    }
+    return acc2.x + acc2.y;
+}
+
 // exp for the heads: the hardware exponential (v_exp_f32 on x log2 e, ~1 ulp) -- the network outputs are held to the
 // 1e-5 class against the reference's torch-CPU numbers, not to bit parity, and the library expf costs a dozen more
 // instructions per call on the leaf-evaluation path (ELU of every hidden unit, three softmaxes per leaf)
@@ -126,6 +154,10 @@ __device__ inline float elu(float x) { return x > 0.f ? x : smz_exp(x) - 1.0f; }
 // SMZ_ONE_DECODE (round 5): the reward's and the value's support decodes of a paired pass run as ONE instruction sequence
 #ifndef SMZ_ONE_DECODE
 #define SMZ_ONE_DECODE 1
+#endif
+// SMZ_DENSE_HALVES (round 5): a pair of afterstate rows runs its narrow dynamics layer on lane halves (dense_halves)
+#ifndef SMZ_DENSE_HALVES
+#define SMZ_DENSE_HALVES 1
 #endif
 #define SMZ_DPP_REDUCE(NAME, INSN)                                                               \
     __device__ inline float NAME(float v) {                                                      \
@@ -386,6 +418,9 @@ __device__ inline void half_max_min_max(float &a, float &b, float &c) {
 __device__ inline void half_sum2(float &a, float &b) {
     asm SMZ_DPP_VOLATILE(SMZ_HALF_CHAIN(SMZ_HSTEP2, "v_add_f32_dpp", "v_add_f32_dpp") : "+v"(a), "+v"(b));
 }
+__device__ inline void half_sum3(float &a, float &b, float &c) {
+    asm SMZ_DPP_VOLATILE(SMZ_HALF_CHAIN(SMZ_HSTEP3, "v_add_f32_dpp", "v_add_f32_dpp", "v_add_f32_dpp") : "+v"(a), "+v"(b), "+v"(c));
+}
 __device__ inline void half_sum5(float &a, float &b, float &c, float &d, float &e) {
     asm SMZ_DPP_VOLATILE(SMZ_HALF_CHAIN(SMZ_HSTEP5, "v_add_f32_dpp") : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
 }
@@ -409,10 +444,23 @@ __device__ inline void softmax_decode_pair(float a0, float a1, int A, int S, int
     const float eP = (ppol || pval) ? smz_exp(P - (ppol ? mp : mv)) : 0.f;
     const float eQ = qval ? smz_exp(Q - mv) : 0.f;
     float dp = ppol ? eP : 0.f, dvP = pval ? eP : 0.f, nvP = pval ? (float)(j - A - half) * eP : 0.f;
-    float dvQ = eQ, nvQ = qval ? (float)(oq - A - half) * eQ : 0.f;
-    half_sum5(dp, dvP, nvP, dvQ, nvQ);
-    // lanes 31 / 63: the rows' totals in wave_sum3's association; the decode runs there, once for both rows
-    float dv = dvP + dvQ, nv = nvP + nvQ;
+    float dv, nv;
+    if (A + S == 33) {
+        // the Q part is ONE output (o = 32, local lane 0): a tree sum over it and zeros is the element itself -- no chains for
+        // it; it travels to the lanes that hold the P totals (row_mirror: lane 15 <- lane 0 of a 16-lane row; row_bcast:15:
+        // the next row <- lane 15) and the same products / sums as below are formed there
+        half_sum3(dp, dvP, nvP);
+        int q = __builtin_amdgcn_update_dpp(0, __float_as_int(eQ), 0x140, 0xf, 0xf, false);
+        q = __builtin_amdgcn_update_dpp(q, q, 0x142, 0xa, 0xf, false);
+        const float e32 = __int_as_float(q);
+        dv = dvP + e32;
+        nv = nvP + (float)(32 - A - half) * e32;
+    } else {
+        float dvQ = eQ, nvQ = qval ? (float)(oq - A - half) * eQ : 0.f;
+        half_sum5(dp, dvP, nvP, dvQ, nvQ);
+        // lanes 31 / 63: the rows' totals in wave_sum3's association; the decode runs there, once for both rows
+        dv = dvP + dvQ; nv = nvP + nvQ;
+    }
     if constexpr (WITH_REWARD) {
         const float sn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rnum), 0x101, 0xf, 0xf, false));   // row_shl:1
         const float sd = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rden), 0x101, 0xf, 0xf, false));
@@ -471,9 +519,11 @@ __device__ inline void dynamics_tail_pair(float a0, float a1, bool d0, bool d1, 
 }
 
 // scale_lanes (outputs [0, S)) for two rows of the afterstate branch
+// PACKED: a0 already holds both rows' outputs on lane halves (dense_halves)
+template <bool PACKED = false>
 __device__ inline void scale_pair(float a0, float a1, int S, int lane, float *act0, float *act1, float *dst0, float *dst1) {
     float P = a0, Q = a1;
-    swap32(P, Q);
+    if (!PACKED) swap32(P, Q);
     const bool hi = lane >= 32;
     const int j = lane & 31;
     const bool in = j < S;                                                                  // (S <= 32)
@@ -613,7 +663,16 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
     }
     trunk<U, R, SAME>(lds, d, m1, m1m, xin, K4in, tA, lane);
     float acc[R][U];
-    {
+    constexpr bool PAIRED = SMZ_PAIR_TAILS && U == 1 && R == 2;        // both rows' tails at once (see softmax_decode_pair)
+    // both rows on the afterstate branch: its dynamics layer has S <= 32 outputs -- both rows at once on lane halves (dense_halves)
+    const bool halves = PAIRED && SAME && SMZ_DENSE_HALVES && S <= 32 && !dyn[0] && !dyn[1];       // (wave-uniform)
+    if (halves) {
+        if constexpr (PAIRED && SAME) {
+            const MatOff m = pick<CP>(d, false, M_DYN_OUT, M_ADY_OUT);
+            acc[0][0] = dense_halves(lds + m.w, lds + m.b, tA[0], tA[1], K4h, m.op, lane);
+            acc[1][0] = 0.f;
+        }
+    } else {
         const float *W[R], *Bv[R], *Ac[R];
         int op[R];
 #pragma unroll
@@ -623,13 +682,14 @@ __device__ inline void recurrent_rows(const float *lds, const smz_mlp_desc &d, f
         }
         dense<U, R, SAME>(W, Bv, Ac, K4h, op, lane, acc);
     }
-    constexpr bool PAIRED = SMZ_PAIR_TAILS && U == 1 && R == 2;        // both rows' tails at once (see softmax_decode_pair)
     float pair_rnum = 0.f, pair_rden = 0.f;                            // (the reward's sums of a dynamics row, decoded with the value's)
     bool pair_reward = false;
     if constexpr (PAIRED) {
         if (S <= 32) {
             reward[0] = reward[1] = 0.f;
-            if (!dyn[0] && !dyn[1]) scale_pair(acc[0][0], acc[1][0], S, lane, hbuf[0], hbuf[1], live[0] ? dst_hidden[0] : nullptr,
+            if (halves) scale_pair<true>(acc[0][0], 0.f, S, lane, hbuf[0], hbuf[1], live[0] ? dst_hidden[0] : nullptr,
+                                         live[1] ? dst_hidden[1] : nullptr);
+            else if (!dyn[0] && !dyn[1]) scale_pair(acc[0][0], acc[1][0], S, lane, hbuf[0], hbuf[1], live[0] ? dst_hidden[0] : nullptr,
                                                live[1] ? dst_hidden[1] : nullptr);
             else if (SMZ_ONE_DECODE) {
                 dynamics_tail_pair<true>(acc[0][0], acc[1][0], dyn[0], dyn[1], S, lane, hbuf[0], hbuf[1], live[0] ? dst_hidden[0] : nullptr,
