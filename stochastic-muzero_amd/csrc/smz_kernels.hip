@@ -654,12 +654,23 @@ extern __shared__ float4 smz_search_lds4[];
 #ifdef SMZ_BPS_PROBE
 #define SMZ_PROBE_DECL unsigned long long pb_t0 = 0, pb_acc[7] = {0, 0, 0, 0, 0, 0, 0};
 #define SMZ_PROBE_START pb_t0 = __builtin_amdgcn_s_memtime();
-#define SMZ_PROBE(i) { const unsigned long long pb_t1 = __builtin_amdgcn_s_memtime(); pb_acc[i] += pb_t1 - pb_t0; pb_t0 = pb_t1; }
+#define SMZ_PROBE_AT(i) { const unsigned long long pb_t1 = __builtin_amdgcn_s_memtime(); pb_acc[i] += pb_t1 - pb_t0; pb_t0 = pb_t1; }
+// -DSMZ_BPS_PROBE (=1): stamp set A (expand + backup | select: prepare, evaluate, chase, records + leaf | networks | staging);
+// -DSMZ_BPS_PROBE=2: set B (expansion | lane-parallel backup | whole select | network inputs (fence, word requests, x rows) |
+//                          the two-row pass | head outputs + hand-off | staging) -- same seven slots
+#if SMZ_BPS_PROBE + 0 == 2
+#define SMZ_PROBE(i)
+#define SMZ_PROBE_B(i) SMZ_PROBE_AT(i)
+#else
+#define SMZ_PROBE(i) SMZ_PROBE_AT(i)
+#define SMZ_PROBE_B(i)
+#endif
 #define SMZ_PROBE_FLUSH(stats) if ((stats) && lane == 0) { for (int pb_i = 0; pb_i < 7; pb_i++) atomicAdd(&(stats)[8 + pb_i], pb_acc[pb_i]); }
 #else
 #define SMZ_PROBE_DECL
 #define SMZ_PROBE_START
 #define SMZ_PROBE(i)
+#define SMZ_PROBE_B(i)
 #define SMZ_PROBE_FLUSH(stats)
 #endif
 
@@ -839,6 +850,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             if (s > 0 && !(dbg & 4)) expand_backup_tree<MAXA, KS, LBKP, THR, YV>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
                                                       outs[lane * slot + A], pvals + lane * P.P, &leaf_rw);
         }
+        SMZ_PROBE_B(0)
         if constexpr (LBKP) {
             if (s > 0) {
                 const int src = lane & (kFastTpw - 1);
@@ -865,6 +877,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         }
         SMZ_STAMP(t_expand)
         SMZ_PROBE(0)
+        SMZ_PROBE_B(1)
         // Specialised two-action kernel: the descent runs on lanes 0..3 -- lane t and its helper t + 2 score one child
         // each (pick_decision_pair).  The helper works on a copy of the tree lane's stream position and MinMax bounds.
         constexpr bool PAIR = AEX && MAXA == 2 && KS == 2 && !INSTR;
@@ -985,6 +998,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         }
         SMZ_STAMP(t_select)
         SMZ_PROBE(4)
+        SMZ_PROBE_B(2)
         __builtin_amdgcn_s_setprio(SMZ_PRIO_HEADS);
         // hidden rows written in earlier rounds (by any lane of this wave) may be this round's parent rows
         if (!(BPS && SMZ_EARLY_ROWS && bps_all)) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1008,6 +1022,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
                 xall[t * K4in + k] = (k < S) ? src[k] : ((k < S + A && (k - S) == act) ? 1.f : 0.f);
         }
         smz_mlp::lds_sync();
+        SMZ_PROBE_B(3)
         bool paired = false;
         if (tpw == 2 && !(dbg & 1)) {
             // the wave's two leaves need the same pair of networks: one pass, weights read from LDS once for both rows
@@ -1023,6 +1038,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
                 const bool live[2] = {MSK ? (vmask & 1) != 0 : true, MSK ? (vmask & 2) != 0 : true};
                 if (b0 == b1) smz_mlp::recurrent_rows<U, 2, true, TLDS>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
                 else smz_mlp::recurrent_rows<U, 2, false, TLDS>(lds, dl, scratch, xin, dyn, live, dh, dp, reward, value);
+                SMZ_PROBE_B(4)
                 if (lane == 0) {
                     outs[A] = value[0]; outs[A + 1] = reward[0];
                     outs[slot + A] = value[1]; outs[slot + A + 1] = reward[1];
@@ -1057,10 +1073,12 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         smz_mlp::lds_sync();
         SMZ_STAMP(t_mlp)
         SMZ_PROBE(5)
+        SMZ_PROBE_B(5)
         if (!(dbg & 8)) packed = split ? stage_finish<SU, PHC>(P, tree, valid, rng_tile, packed, pre, rng.block())
                                        : wave_stage_rng_from<4, PHC>(P, tree, valid, rng_tile, packed, rng.block());
         SMZ_STAMP(t_stage)
         SMZ_PROBE(6)
+        SMZ_PROBE_B(6)
     }
     SMZ_PROBE_FLUSH(Pin.stats)
 #undef SMZ_STAMP
