@@ -355,6 +355,8 @@ def records_from_host_copy(rec, game_end, obs_dim, A, discount, priority_scale=1
     else:
         tops = [None] * len(e)
     games = [ArrayGameRecord(src, *w) for w in zip(e.tolist(), t0.tolist(), t1.tolist(), done.tolist(), tops)]
+    src.windows = (e, t0, t1)                    # (the games' windows as arrays, in list order: _reward_sums)
+    src.fresh = None
     if odd.any():                                                              # the rare envs: the general loop, merged in env order
         merged, k, envs = [], 0, e.tolist()
         for env in np.nonzero(odd)[0].tolist():
@@ -366,6 +368,8 @@ def records_from_host_copy(rec, game_end, obs_dim, A, discount, priority_scale=1
             merged.extend(sub)
         merged.extend(games[k:])
         games = merged
+    else:
+        src.fresh = (games, len(games))          # this very list, unmodified: _reward_sums may sum it from the arrays
     return games
 
 
@@ -711,11 +715,14 @@ def _cut_rules(env, steps, ignore_termination, limit_of_game_play):
 
 
 def _store(games, replay_buffer):
+    """save_game of every game + the games' mean reward (self_play.py:266-271).  The reward sums are taken BEFORE the buffer sees
+    the games: the records are then exactly what records_from_host_copy built, and a list of array records is summed from the
+    windows' arrays without a Python step per game (_reward_sums)."""
+    rewards = _reward_sums(games)
     if replay_buffer is not None:
         save = replay_buffer.save_game
         for g in games:
             save(g)
-    rewards = _reward_sums(games)
     return games, (sum(rewards) / len(rewards) if rewards else float("nan"))
 
 
@@ -777,13 +784,45 @@ def self_play_iterations(env, model, mcts, temperature, steps, iterations, repla
         yield (None, None) if job is None else _store(job.finish(priority_scale, **cut), replay_buffer)
 
 
+def _window_sums(src, e, t0, n):
+    """Left-to-right sums of the reward windows [t0, t0 + n) of envs e in the chunk copy `src` (arrays)."""
+    B_, T = src.rec.shape[:2]
+    col = getattr(src, "_reward_col", None)
+    if col is None:
+        col = src._reward_col = np.ascontiguousarray(src.rec[:, :, src.o])      # [B][T] contiguous, made once per chunk
+    if len(e) == B_ and (n == T).all() and (t0 == 0).all() and (e == np.arange(B_)).all():
+        return np.cumsum(col, axis=1)[:, -1]                       # one game per env over the whole chunk: a row scan each
+    flat = col.reshape(-1)
+    order = np.argsort(-n, kind="stable")                          # games ordered by length: step k touches a prefix
+    lo_s, n_s = (e * T + t0)[order], n[order]
+    L = int(n_s[0]) if len(n_s) else 0
+    alive = len(e) - np.searchsorted(n_s[::-1], np.arange(1, L + 1), side="left")
+    acc = np.zeros(len(e))
+    for k, m in enumerate(alive.tolist()):                         # m games have a step k: one gather + one add each
+        acc[:m] += flat[lo_s[:m] + k]
+    sums = np.empty(len(e))
+    sums[order] = acc
+    return sums
+
+
 def _reward_sums(games):
     """[sum(game.rewards) for game in games] for ArrayGameRecords without touching their lists, bit for bit Python's
     left-to-right sum: the windows of one shared host copy are accumulated together, step k of every game that has one in one
-    vector add (games ordered by length, so step k touches a prefix).  A window is never combined with another game's rows: a
+    vector add (a row scan when every env holds one whole-chunk game).  A window is never combined with another game's rows: a
     non-finite reward (the reference's illegal-move reward is -inf when limit_of_game_play is unlimited) stays in its own game
-    (differences of a per-env cumulative sum turned inf - inf into nan for every later game of the env).  Records
-    whose reward list became a real list are summed the slow way."""
+    (differences of a per-env cumulative sum turned inf - inf into nan for every later game of the env).
+    The list records_from_host_copy has just built is recognised as a whole (its windows are kept as arrays: no Python step per
+    game); any other list is checked record by record, and records whose reward list became a real list are summed the slow way."""
+    if not games:
+        return []
+    g0 = games[0]
+    src = getattr(g0, "_src", None)
+    fresh = getattr(src, "fresh", None)
+    if fresh is not None and fresh[0] is games and fresh[1] == len(games):
+        src.fresh = None                                           # (once: after that the records may have been modified)
+        e, t0, t1 = src.windows
+        e, t0 = np.asarray(e, np.int64), np.asarray(t0, np.int64)
+        return _window_sums(src, e, t0, np.maximum(np.asarray(t1, np.int64) - t0, 0)).tolist()
     out = [None] * len(games)
     by_src = {}
     for i, g in enumerate(games):
@@ -792,20 +831,12 @@ def _reward_sums(games):
         else:
             out[i] = sum(g.rewards)
     for src, idx in by_src.values():
-        T = src.rec.shape[1]
-        col = np.ascontiguousarray(src.rec[:, :, src.o]).reshape(-1)
-        lo = np.array([games[i]._e * T + games[i]._t0 for i in idx], np.int64)
-        n = np.array([max(0, games[i]._t1 - games[i]._t0) for i in idx], np.int64)
-        order = np.argsort(-n, kind="stable")
-        lo_s, n_s = lo[order], n[order]
-        acc = np.zeros(len(idx))
-        alive = len(idx) - np.searchsorted(n_s[::-1], np.arange(1, (int(n_s[0]) if len(n_s) else 0) + 1), side="left")
-        for k, m in enumerate(alive.tolist()):                 # m games have a step k
-            acc[:m] += col[lo_s[:m] + k]
-        sums = np.empty(len(idx))
-        sums[order] = acc
+        e = np.fromiter((games[i]._e for i in idx), np.int64, len(idx))
+        t0 = np.fromiter((games[i]._t0 for i in idx), np.int64, len(idx))
+        t1 = np.fromiter((games[i]._t1 for i in idx), np.int64, len(idx))
+        sums = _window_sums(src, e, t0, np.maximum(t1 - t0, 0)).tolist()
         for j, i in enumerate(idx):
-            out[i] = float(sums[j])
+            out[i] = sums[j]
     return out
 
 

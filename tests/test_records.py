@@ -290,7 +290,9 @@ def test_reward_sums_are_pythons_sums_game_by_game_even_with_non_finite_rewards(
     d[2, 3, 4] = -np.inf                                                # one illegal move in env 3's first game
     d[5, 1, 4] = np.inf
     want, got = build(d, 4, 3, after_end="new_game")
-    sums = sp._reward_sums(got)
+    assert got[0]._src.fresh is not None and got[0]._src.fresh[0] is got
+    sums = sp._reward_sums(got)                                          # the list as built: summed from the windows' arrays
+    assert got[0]._src.fresh is None and sp._reward_sums(got) == sums    # ... once; later calls check record by record
     assert len(sums) == len(want) > 7
     for g, s in zip(want, sums):
         ref = sum(g.rewards)
