@@ -110,6 +110,13 @@ def test_bench_starts_its_own_ranks():
     assert out["timing"]["gather_overlap"]["slices"] == 4 and out["timing"]["gather_ms_median"] > 0
     assert out["timing"]["gather_overlap"]["mode"]["kind"] == "overlapped"
     assert len(r.stdout.strip().splitlines()) == 1                      # stdout is the JSON line and nothing else
+    # the default exchange (one grouped send / receive per block, stream-ordered behind the block's last search)
+    cmd = [c for c in cmd if c not in ("--gather-mode", "overlapped")]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads(r.stdout)
+    assert out["n_gpus"] == 2 and out["timing"]["gather_overlap"]["mode"]["kind"] == "plain" and out["timing"]["gather_ms_median"] > 0
+    assert out["config"]["ranks_seen_by_collective"] == 2 and len(out["per_rank_simulations_per_s"]) == 2
     # a launcher / flag mismatch is an error, not a silent single-GPU run
     bad = dict(_env(), WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=bad, capture_output=True, text=True,
