@@ -212,7 +212,11 @@ def test_single_tree_drop_in_matches_reference_game():
                                             ("weights_ckpt421", 2049, 8, 2), ("weights_ckpt421", 4097, 9, 2),
                                             ("weights_lunar_L0", 4096, 12, 2),
                                             ("weights_lunar_L0", 700, 30, 4), ("weights_lunar_L2", 256, 24, 3),
-                                            ("weights_wide_A11", 130, 20, 9), ("weights_ckpt421", 70, 0, 2), ("weights_lunar_L0", 65, 1, 1)])
+                                            ("weights_wide_A11", 130, 20, 9), ("weights_ckpt421", 70, 0, 2), ("weights_lunar_L0", 65, 1, 1),
+                                            # round 5: trees in global memory with the block-parallel selection -- four passes of
+                                            # blocks, the largest search its 7-bit block indices allow, one beyond (level by level)
+                                            # and one whose selection words no longer fit LDS beside the path records
+                                            ("weights_ckpt421", 4096, 126, 2), ("weights_ckpt421", 2048, 127, 2), ("weights_ckpt421", 4096, 140, 2), ("weights_ckpt421", 1024, 110, 2)])
 def test_single_launch_search_equals_stepwise_search(wname, B, sims, K):
     """smz_search_mlp (whole search in one kernel) against the step-wise kernels driven with the same fused HIP
     heads: same device functions, same draws -> every tree, value and stream position identical."""
