@@ -251,6 +251,10 @@ __device__ inline int wave_stage_rng(const Params &P, int tree, bool valid, uint
                                        (PHC && P.philox && valid) ? P.rng_block[tree] : 0u);
 }
 
+// SMZ_STAGE_STORES_LAST (round 5): stage_finish stores the twisted words after ALL trees' words went to LDS (=0: tree by tree).
+#ifndef SMZ_STAGE_STORES_LAST
+#define SMZ_STAGE_STORES_LAST 1
+#endif
 // The same staging split in two for waves that own at most U trees: stage_issue requests the source words (the loads
 // stay in flight while the caller does unrelated work -- the network evaluation in k_search_mlp), stage_finish twists,
 // stores and fills the LDS tile.  Nothing may draw random words of these trees in between.
@@ -293,6 +297,31 @@ __device__ inline int stage_finish(const Params &P, int tree, bool valid, uint32
             return ((kRngStage) << 16) | (packed & 0xffff);
         }
     }
+#if SMZ_STAGE_STORES_LAST
+    // Every source word is consumed (twisted, tempered, handed to LDS) before the first twisted word is stored: a store between
+    // one tree's words and the next's made the compiler wait for THAT STORE's completion (vmcnt counts stores on gfx9, and with
+    // the twist under a branch its count is conservative: s_waitcnt vmcnt(0) after each global_store -- two serial store round
+    // trips per round, profiles/r05_s_stage_waits.txt).
+    uint32_t tw_w[U];
+    int tw_p[U];
+    bool tw_on[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int pk = __builtin_amdgcn_readlane(packed, u);
+        const bool vt = u < P.tpw && __builtin_amdgcn_readlane((int)valid, u) != 0;
+        const int idx = pk & 0xffff, ready = pk >> 16;
+        int p = idx + lane;
+        if (p >= kMtN) p -= kMtN;
+        tw_on[u] = vt && lane >= ready;
+        tw_p[u] = p;
+        const uint32_t t = mt_twist(pre.w[u], pre.b[u], pre.c[u]);      // (lanes that do not twist hold zeros in b, c: value unused)
+        tw_w[u] = tw_on[u] ? t : pre.w[u];
+        if (vt) lds_tile[u * kRngStride + lane] = mt_temper(tw_w[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        if (tw_on[u]) (P.mt + (size_t)(tree0 + u) * kMtN)[tw_p[u]] = tw_w[u];
+#else
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int pk = __builtin_amdgcn_readlane(packed, u);
@@ -307,6 +336,7 @@ __device__ inline int stage_finish(const Params &P, int tree, bool valid, uint32
         }
         if (vt) lds_tile[u * kRngStride + lane] = mt_temper(w);
     }
+#endif
     const int idx = packed & 0xffff, ready = packed >> 16;
     return ((ready > kRngStage ? ready : kRngStage) << 16) | idx;
 }
@@ -651,6 +681,13 @@ extern __shared__ float4 smz_search_lds4[];
 #ifndef SMZ_EARLY_ROWS
 #define SMZ_EARLY_ROWS 1
 #endif
+// SMZ_EARLY_STAGE (round 5): the next round's MT19937 source words are requested together with the parent rows -- the stream
+// position after the descent follows from the path length alone -- instead of after the selection's last phase.  Before, the
+// wait for the (long landed) parent rows at the network inputs was a vmcnt(0) that also waited for the source words requested
+// a few instructions earlier: one exposed L2 round trip per round (profiles/r05_s_stage_waits.txt).
+#ifndef SMZ_EARLY_STAGE
+#define SMZ_EARLY_STAGE 1
+#endif
 #ifdef SMZ_BPS_PROBE
 #define SMZ_PROBE_DECL unsigned long long pb_t0 = 0, pb_acc[7] = {0, 0, 0, 0, 0, 0, 0};
 #define SMZ_PROBE_START pb_t0 = __builtin_amdgcn_s_memtime();
@@ -889,6 +926,8 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         bool bps_done = false;
         bool bps_all = false;                 // every tree of the wave went through the block-parallel selection this round
         float early_row[kFastTpw] = {0.f, 0.f};
+        StagePre<SU> pre;
+        bool staged_early = false;            // (wave-uniform) the next round's source words were requested with the parent rows
         if constexpr (BPS) if (TLDS || ml.sel_on) {
             uint16_t *selw = reinterpret_cast<uint16_t *>(scratch + ml.sel_off);          // [tpw][sel_n]
             const int SELN = ml.sel_n;
@@ -935,6 +974,14 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             // vector-memory loads in order: profiles/r03_ceiling.md 6b).  A tree that falls back to the sequential descent
             // (bps_all false) takes the old path.
             bps_all = __ballot(valid && len == 0) == 0ull && __ballot(valid) != 0ull;
+#if SMZ_EARLY_STAGE
+            if (valid && len > 0) {                                     // the words the descent's levels drew (all inside the staged window)
+                const int nw = select_words(len, A);
+                rng.used += nw; rng.ready -= nw; rng.idx += nw;
+                if (rng.idx >= kMtN) { rng.idx -= kMtN; rng.wrapped(); }
+                packed = rng.pack();
+            }
+#endif
             if (bps_all) {
                 int par = 0;
                 if (valid && len > 1) { const int loc = pathw[lane * SELN + len - 2], pb = loc >> 8; par = pb == 0 ? 1 + (loc & 3) : 1 + A + (pb - 1) * 2 + (loc & 3); }
@@ -945,16 +992,21 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
                     const float *srow = P.hidden + ((size_t)(tree0 + t) * P.N + parent) * P.hs;
                     early_row[t] = (lane < S && tree0 + t < P.B) ? srow[lane] : 0.f;
                 }
+#if SMZ_EARLY_STAGE
+                if (split && !(dbg & 8)) { stage_issue<SU, PHC>(P, tree, valid, packed, pre); staged_early = true; }
+#endif
             }
 #endif
             for (int d = lane >> 1; d < blen; d += kWave / 2) select_record(P, stb, pathw + src * SELN, d, pvals + src * P.P);
             if (valid && len > 0) {
                 L = select_leaf(P, stb, pathw + lane * SELN, len);
+#if !(SMZ_EARLY_ROWS && SMZ_EARLY_STAGE)
                 const int nw = select_words(len, A);                    // the words the descent's levels drew (all inside the staged window)
                 rng.used += nw; rng.ready -= nw; rng.idx += nw;
                 if (rng.idx >= kMtN) { rng.idx -= kMtN; rng.wrapped(); }
-                h.path_len = len;
                 packed = rng.pack();
+#endif
+                h.path_len = len;
                 bps_done = true;
             }
         }
@@ -1002,8 +1054,8 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         __builtin_amdgcn_s_setprio(SMZ_PRIO_HEADS);
         // hidden rows written in earlier rounds (by any lane of this wave) may be this round's parent rows
         if (!(BPS && SMZ_EARLY_ROWS && bps_all)) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        StagePre<SU> pre;       // (after the fence: it drains the vector-memory counter)
-        if (split && !(dbg & 8)) stage_issue<SU, PHC>(P, tree, valid, packed, pre);
+        // (after the fence: it drains the vector-memory counter)
+        if (split && !(dbg & 8) && !staged_early) stage_issue<SU, PHC>(P, tree, valid, packed, pre);
         // all rows' network inputs first (independent global loads, one latency), then the rows one after another
         if (BPS && SMZ_EARLY_ROWS && bps_all) {                 // (the parent rows are in registers already: see the selection)
 #pragma unroll

@@ -45,6 +45,13 @@ using smz_vision::uniform_ptr;
 namespace {
 
 #ifndef SMZ_VISION_CONV_MFMA
+// SMZ_VISION_BIAS_LDS (round 5): the towers' biases, exactly the four floats every lane starts its accumulators from, are
+// staged in LDS once per launch.  Before, every tower layer of every round began with a scalar load of the bias offset, a
+// global load of the bias and a wait for it (an L2 round trip at one wavefront per SIMD: nothing hides it) -- four to five such
+// trips per round (profiles/r05_s_stage_waits.txt).  =0 builds keep the global loads.
+#ifndef SMZ_VISION_BIAS_LDS
+#define SMZ_VISION_BIAS_LDS 1
+#endif
 #define SMZ_VISION_CONV_MFMA 1                       // 3x3 convolutions as v_mfma_f32_4x4x1 chains (smz_vision_device.hpp conv3x3_m)
 #endif
 constexpr bool kConvMfma = SMZ_VISION_CONV_MFMA != 0;
@@ -54,11 +61,12 @@ constexpr int kTowers = 5;                           // 0 dyn reward | 1 pre val
 constexpr int kP1 = 40;                              // inputs per quarter of the 147-input layer (10 groups of four)
 constexpr int kFS = 164;                             // floats per (input kind, leaf) row of the flat tile: 4 x 40 + bank spread
 constexpr int kHS = 68;                              // floats per (tower, leaf) row of a hidden tile: 64 + bank spread
+constexpr int kBiasUses = 5;                         // layer 1 (own tower | tower 4), hidden layer (own | tower 4), output layer
 constexpr int kYS = 36;                              // floats per (tower, leaf) row of the raw outputs
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct VisLds {                                      // float offsets from the dynamic LDS base
-    int small, pbc, wave, per_wave, plane, pv, rng, outs, prof, F, H1, H2, Y, br, trees, total;
+    int small, pbc, wave, per_wave, plane, pv, rng, outs, prof, F, H1, H2, Y, br, bias, trees, total;
 };
 __host__ __device__ inline VisLds vis_lds(const Params &P, int A) {
     VisLds m;
@@ -76,7 +84,8 @@ __host__ __device__ inline VisLds vis_lds(const Params &P, int A) {
     m.H2 = m.H1 + kTowers * kVW * kHS;
     m.Y = m.H2 + kTowers * kVW * kHS;
     m.br = m.Y + kTowers * kVW * kYS + 64;                        // (+64: the tails read a full wave width of a row)
-    m.trees = (m.br + kVW + 15) & ~15;                                       // the four trees' child blocks (written back at the end)
+    m.bias = (m.br + kVW + 15) & ~15;                                        // [wave][kBiasUses][lane] four floats: tower biases as each lane adds them
+    m.trees = m.bias + (SMZ_VISION_BIAS_LDS ? kVW * kBiasUses * kWave * 4 : 0);   // the four trees' child blocks (written back at the end)
     m.total = m.trees + kVW * (int)P.tree_words;
     return m;
 }
@@ -157,15 +166,20 @@ __device__ inline v4f bias4(const float *b, bool on) { return on ? v4f{b[0], b[1
 // in: per-(tower | input kind, leaf) rows of `stride` floats; out: rows of kHS floats, relu applied.
 template <int NS>
 __device__ inline void tower_layer64(const float (&w)[5][NS], const float *in, int stride, bool by_kind, int pl4, const float *bias_a,
-                                     const float *bias_b, float *out, int wave, int lane, bool need_a, bool need_b) {
+                                     const float *bias_b, const v4f *bias_lds, float *out, int wave, int lane, bool need_a, bool need_b) {
     const int blk = lane >> 2, lf = lane & 3, grp = lane >> 4;
     const int ia = by_kind ? tower_input(wave) : wave, ib = by_kind ? tower_input(4) : 4;
     const float *xa = in + (ia * kVW + lf) * stride, *xb = in + (ib * kVW + lf) * stride + grp * pl4;
     const float *const bx[5] = {xa, xa + pl4, xa + 2 * pl4, xa + 3 * pl4, xb};
     v4f acc[5];
-    acc[0] = bias4(bias_a + 4 * blk, true);
     acc[1] = acc[2] = acc[3] = v4f{0.f, 0.f, 0.f, 0.f};
-    acc[4] = bias4(bias_b + 16 * wave + 4 * (blk & 3), grp == 0);
+    if (SMZ_VISION_BIAS_LDS) {
+        acc[0] = bias_lds[lane];
+        acc[4] = bias_lds[kWave + lane];
+    } else {
+        acc[0] = bias4(bias_a + 4 * blk, true);
+        acc[4] = bias4(bias_b + 16 * wave + 4 * (blk & 3), grp == 0);
+    }
     if (need_a && need_b) rows_mfma<NS, 5, 0>(w, bx, acc);            // (wave-uniform)
     else if (need_a) rows_mfma<NS, 4, 0>(w, bx, acc);
     else if (need_b) rows_mfma<NS, 1, 4>(w, bx, acc);
@@ -229,7 +243,8 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
         pbc_lds[i] = P.pbc_sqrt[i];
         pbc_lds[n_pbc + i] = i > 0 ? 1.0 / (double)i : 0.0;
     }
-    for (int i = threadIdx.x + ml.wave; i < ml.total; i += blockDim.x) lds[i] = 0.f;     // planes' borders, pad inputs of the tiles
+    for (int i = threadIdx.x + ml.wave; i < ml.total; i += blockDim.x)
+        if (i < ml.bias || i >= ml.trees) lds[i] = 0.f;            // planes' borders, pad inputs of the tiles (not the staged biases: no barrier in between)
     // tap-major copies of the 3x3 convolutions: [net 0..1 transition: conv_in, res_a, res_b | net 0..1 prediction: res_a, res_b]
     float *tm = lds + kSmallMax;
     for (int n = 0; n < 2; n++) {
@@ -285,6 +300,16 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
     } else {
         load_row<16>(wo[0], weights + offo[4], lane & 3, (lane >> 2) & 3, plh4, K4h, lane < 32);
         load_row<16>(wo[1], weights + offo[4], 0, 0, plh4, K4h, false);
+    }
+    v4f *const bias_lds = reinterpret_cast<v4f *>(lds + ml.bias) + wave * kBiasUses * kWave;
+    if (SMZ_VISION_BIAS_LDS) {
+        const int grp = lane >> 4;
+        bias_lds[0 * kWave + lane] = bias4(weights + offa[1] + 4 * blk, true);
+        bias_lds[1 * kWave + lane] = bias4(weights + offb[1] + 16 * wave + 4 * (blk & 3), grp == 0);
+        bias_lds[2 * kWave + lane] = bias4(weights + offa[3] + 4 * blk, d.L > 0);
+        bias_lds[3 * kWave + lane] = bias4(weights + offb[3] + 16 * wave + 4 * (blk & 3), d.L > 0 && grp == 0);
+        bias_lds[4 * kWave + lane] = wave < 3 ? bias4(weights + offo[5] + 4 * (blk & 7), lane < 32)
+                                              : bias4(weights + offo[5], (lane & 12) == 0 && lane < 32);
     }
     __syncthreads();
 
@@ -451,12 +476,12 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
         const bool need_dyn = __ballot(mine == 1) != 0ull, need_ady = __ballot(mine == 0) != 0ull;
         const bool need_a = wave < 3 ? need_dyn : need_ady, need_b = need_ady;          // tower `wave` | tower 4
         // ---- towers: 147 -> H, [H -> H] x L (the SAME Linear applied L times), H -> S / A ---------------------------------------
-        tower_layer64<kP1>(w1, F, kFS, true, kP1, weights + offa[1], weights + offb[1], H1, wave, lane, need_a, need_b);
+        tower_layer64<kP1>(w1, F, kFS, true, kP1, weights + offa[1], weights + offb[1], bias_lds, H1, wave, lane, need_a, need_b);
         wg_barrier();
         SMZ_VSTAMP(5)
         float *hin = H1, *hout = H2;
         for (int l = 0; l < d.L; l++) {
-            tower_layer64<16>(wm, hin, kHS, false, plh4, weights + offa[3], weights + offb[3], hout, wave, lane, need_a, need_b);
+            tower_layer64<16>(wm, hin, kHS, false, plh4, weights + offa[3], weights + offb[3], bias_lds + 2 * kWave, hout, wave, lane, need_a, need_b);
             wg_barrier();
             float *tmp = hin; hin = hout; hout = tmp;
         }
@@ -464,7 +489,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
             if (wave < 2 ? need_dyn : need_ady) {
                 const float *x = hin + (t_out * kVW + lf) * kHS + (lane >> 5) * plh4;
                 const float *const bx[2] = {x, x + 2 * plh4};
-                v4f acc[2] = {bias4(weights + offo[5] + 4 * (blk & 7), lane < 32), v4f{0.f, 0.f, 0.f, 0.f}};
+                v4f acc[2] = {SMZ_VISION_BIAS_LDS ? bias_lds[4 * kWave + lane] : bias4(weights + offo[5] + 4 * (blk & 7), lane < 32), v4f{0.f, 0.f, 0.f, 0.f}};
                 rows_mfma<16, 2, 0>(wo, bx, acc);
                 const v4f y = xadd<32>(acc[0]) + xadd<32>(acc[1]);
                 if (lane < 32) *reinterpret_cast<v4f *>(Y + (t_out * kVW + lf) * kYS + 4 * blk) = y;
@@ -473,7 +498,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
             const int t = (lane & 16) ? 4 : 2;
             const float *x = hin + (t * kVW + lf) * kHS + ((lane >> 2) & 3) * plh4;
             const float *const bx[2] = {x, x};
-            v4f acc[2] = {bias4(weights + offo[5], (lane & 12) == 0 && lane < 32), v4f{0.f, 0.f, 0.f, 0.f}};
+            v4f acc[2] = {SMZ_VISION_BIAS_LDS ? bias_lds[4 * kWave + lane] : bias4(weights + offo[5], (lane & 12) == 0 && lane < 32), v4f{0.f, 0.f, 0.f, 0.f}};
             rows_mfma<16, 1, 0>(wo, bx, acc);
             const v4f y = xadd<8>(xadd<4>(acc[0]));
             if ((lane & 12) == 0 && lane < 32) *reinterpret_cast<v4f *>(Y + (t * kVW + lf) * kYS) = y;
