@@ -647,6 +647,40 @@ __device__ inline int pick_decision_pair(const Kids<2> &k, int me, double sp, bo
     return s1 >= s0 ? 1 : 0;      // exact tie -> larger action
 }
 
+// The FOUR-child root level on the same two lanes (round 5; below the root every block has two children and
+// pick_decision_pair above applies): lane `me` scores children 2 me and 2 me + 1, keeps the better (ties to the larger
+// action, as the sequential loop does), the two lanes exchange their best score and pick, and the pair {2, 3} wins ties
+// against {0, 1}: the last maximum in action order, which is what `score >= best` in pick_decision leaves.  Both lanes
+// consume the level's eight words.
+__device__ inline int quad_partner(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); }
+template <bool YV = false, class RNG>
+__device__ inline int pick_decision_pair(const Kids<4> &k, int me, double sp, bool norm, float mn, float span,
+                                         float disc32, RNG &rng, const double *r64) {
+    uint32_t jw[8];
+    rng.template take<8>(jw);
+    Kids<4> mine;                 // slots 0, 1 = this lane's children
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        mine.vis[j] = me ? k.vis[2 + j] : k.vis[j];
+        mine.vsum[j] = me ? k.vsum[2 + j] : k.vsum[j];
+        mine.rew[j] = me ? k.rew[2 + j] : k.rew[j];
+        mine.pri64[j] = me ? k.pri64[2 + j] : k.pri64[j];
+        if (YV) mine.yv[j] = me ? k.yv[2 + j] : k.yv[j];
+    }
+    const double u0 = RNG::to_double(me ? jw[4] : jw[0], me ? jw[5] : jw[1]);
+    const double u1 = RNG::to_double(me ? jw[6] : jw[2], me ? jw[7] : jw[3]);
+    const double sa = puct_score<4, YV>(mine, 0, sp, norm, mn, span, disc32, u0, r64);
+    const double sb = puct_score<4, YV>(mine, 1, sp, norm, mn, span, disc32, u1, r64);
+    const bool second = sb >= sa;
+    const double best = second ? sb : sa;
+    const int lp = second ? 1 : 0;
+    const double obest = quad_partner(best);
+    const int olp = quad_partner(lp);
+    const double b01 = me ? obest : best, b23 = me ? best : obest;
+    const int p01 = me ? olp : lp, p23 = me ? lp : olp;
+    return b23 >= b01 ? 2 + p23 : p01;
+}
+
 // The path records of ONE tree inside the level-major global array: record i of tree t = path[i * B + t].  (The single-launch
 // kernels keep a tree's records in LDS as a plain array and pass a pointer.)
 struct PathCol {

@@ -681,6 +681,11 @@ extern __shared__ float4 smz_search_lds4[];
 #ifndef SMZ_EARLY_ROWS
 #define SMZ_EARLY_ROWS 1
 #endif
+// SMZ_PAIR_A4 (round 5): the paired descent (two lanes per tree, one child each) for FOUR actions too -- only the root has four
+// children, which the two lanes split two and two (pick_decision_pair<Kids<4>>); every level below is the two-action code.
+#ifndef SMZ_PAIR_A4
+#define SMZ_PAIR_A4 1
+#endif
 // SMZ_EARLY_STAGE (round 5): the next round's MT19937 source words are requested together with the parent rows -- the stream
 // position after the descent follows from the path length alone -- instead of after the selection's last phase.  Before, the
 // wait for the (long landed) parent rows at the network inputs was a vmcnt(0) that also waited for the source words requested
@@ -917,7 +922,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         SMZ_PROBE_B(1)
         // Specialised two-action kernel: the descent runs on lanes 0..3 -- lane t and its helper t + 2 score one child
         // each (pick_decision_pair).  The helper works on a copy of the tree lane's stream position and MinMax bounds.
-        constexpr bool PAIR = AEX && MAXA == 2 && KS == 2 && !INSTR;
+        constexpr bool PAIR = AEX && (MAXA == 2 || (SMZ_PAIR_A4 && MAXA == 4)) && KS == 2 && !INSTR;
         // Trees in LDS: block-parallel selection (smz_device.hpp, select_block / select_chase) -- every block of the wave's two
         // trees gets a lane that computes the block's pick from the words its level will read, then the tree's lane follows the
         // picks.  SMZ_SELECT_BLOCKS=0 (-DSMZ_SELECT_BLOCKS=0 builds) keeps the level-by-level descent.
