@@ -36,6 +36,10 @@ import subprocess
 import sys
 import time
 
+# (the host driver of this pool only supports dmabuf IPC: without this RCCL's hipIpcGetMemHandle fails; the launcher exports it,
+#  a rank started by someone else's launcher gets it here, before anything touches the GPU)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
