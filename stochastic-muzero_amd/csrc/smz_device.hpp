@@ -808,7 +808,13 @@ __device__ inline int pick_decision_words(const Kids<N> &k, int cnt, double sp, 
 }
 // the pick of block `b` (0 = root) whose node sits at `depth`; stage[used ..] = the words the descent starts from, `staged` of
 // them valid.  Returns ok << 8 | pick << 7 | next, or 0 when the level's words lie beyond the staged window.
-template <int MAXA, bool YV, class RNG>
+// LF ("loads first", round 5; the kernels whose trees are in GLOBAL memory): every word the block's branches read is requested
+// with the children's fields -- see below.  Trees in LDS: measured slower (-0.3 %: four more registers, and reads every lane
+// issues whether its branch wants them), so those instantiations keep the reads inside the branches.
+#ifndef SMZ_SELECT_LOADS_FIRST
+#define SMZ_SELECT_LOADS_FIRST 1
+#endif
+template <int MAXA, bool YV, class RNG, bool LF = false>
 __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int b, int depth, int root_visit, float mn, float mx,
                                         const uint32_t *stage, int used, int staged, const double *pbc_sqrt) {
     constexpr bool RY = YV && MAXA <= 8;
@@ -829,6 +835,24 @@ __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int
         const uint32_t *aux = root ? tb + (RY ? P.ry_off : 0) : tb + P.thr_off + (size_t)(b - 1) * P.thr_stride;
         Kids<2> k;
         load_kids_static<2>(bp, k);
+        if constexpr (LF && SMZ_SELECT_LOADS_FIRST) {
+        // (round 5) every word the block's branches read is requested HERE, with the children's fields: the block's auxiliary
+        // pair (a chance-flagged block's threshold, a decision-flagged one's value terms -- the same eight bytes) and the root's
+        // float64 priors (every lane reads them: one broadcast address).  Inside the branches each was a dependent round trip
+        // of its own behind the children's -- and the branches of a wavefront run one after the other: up to three serial L2
+        // round trips per pass instead of one (4096 x 100: +0.8 %, profiles/r05_aa_select_loads_ab.txt).
+        const uint2 aux2 = *reinterpret_cast<const uint2 *>(aux);
+        const double *rpp = reinterpret_cast<const double *>(tb + P.rp_off);        // (8-byte aligned: rp_off is even)
+        const double rp2x = rpp[0], rp2y = rpp[1];
+        if (chance) {
+            pick = (__hiloint2double((int)aux2.y, (int)aux2.x) <= RNG::to_double(w[0], w[1])) ? 1 : 0;
+        } else {
+            if constexpr (YV) { k.yv[0] = __uint_as_float(aux2.x); k.yv[1] = __uint_as_float(aux2.y); }
+            if (root) { k.pri64[0] = rp2x; k.pri64[1] = rp2y; }
+            const int np = root ? root_visit : 1 + k.vis[0] + k.vis[1];
+            pick = pick_decision_words<2, YV, RNG>(k, 2, pbc_sqrt[np], norm, mn, span, P.disc32, w, r64);
+        }
+        } else {
         if (chance) {
             pick = (*reinterpret_cast<const double *>(aux) <= RNG::to_double(w[0], w[1])) ? 1 : 0;
         } else {
@@ -844,6 +868,7 @@ __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int
             // one of its children -- what the sequential descent carries along as the picked child's count
             const int np = root ? root_visit : 1 + k.vis[0] + k.vis[1];
             pick = pick_decision_words<2, YV, RNG>(k, 2, pbc_sqrt[np], norm, mn, span, P.disc32, w, r64);
+        }
         }
         c = pick ? k.chd[1] : k.chd[0];
     }

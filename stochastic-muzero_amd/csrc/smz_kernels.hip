@@ -950,7 +950,7 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
                 const int b = base + (lane >> 1);
                 if (b <= nexp) {
                     const int depth = b == 0 ? 0 : (int)(selw[src * SELN + b] >> 9);
-                    const uint32_t r = select_block<MAXA, YV, RngT<PHC>>(P, stb, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged,
+                    const uint32_t r = select_block<MAXA, YV, RngT<PHC>, !TLDS>(P, stb, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged,
                                                                         pbc_lds);
                     selw[src * SELN + b] = (uint16_t)((depth << 9) | r);
                 }
