@@ -809,14 +809,79 @@ __device__ inline int pick_decision_words(const Kids<N> &k, int cnt, double sp, 
 // the pick of block `b` (0 = root) whose node sits at `depth`; stage[used ..] = the words the descent starts from, `staged` of
 // them valid.  Returns ok << 8 | pick << 7 | next, or 0 when the level's words lie beyond the staged window.
 // LF ("loads first", round 5; the kernels whose trees are in GLOBAL memory): every word the block's branches read is requested
-// with the children's fields -- see below.  Trees in LDS: measured slower (-0.3 %: four more registers, and reads every lane
-// issues whether its branch wants them), so those instantiations keep the reads inside the branches.
+// with the children's fields -- see select_block_request.  Trees in LDS: measured slower (-0.3 %: four more registers, and reads
+// every lane issues whether its branch wants them), so those instantiations keep the reads inside the branches.
 #ifndef SMZ_SELECT_LOADS_FIRST
 #define SMZ_SELECT_LOADS_FIRST 1
 #endif
+// What select_block reads of a block, as loaded (nothing is computed on it here: a conversion behind the loads would be a wait
+// between this block's requests and the next one's -- the kernel requests the blocks of TWO passes before it decides the first).
+struct BlockRaw {
+    uint4 q[3];          // the block's twelve words (load_kids_static<2>'s)
+    uint2 aux2;          // a chance-flagged block's threshold / a decision-flagged one's value terms -- the same eight bytes
+    double rp0, rp1;     // the root's float64 priors (every lane reads them: one broadcast address)
+};
+// Inside select_block's branches each of these was a dependent round trip of its own behind the children's fields -- and the
+// branches of a wavefront run one after the other: up to three serial L2 round trips per pass instead of one (4096 x 100:
+// +0.8 %, profiles/r05_aa_select_loads_ab.txt).
+template <int MAXA, bool YV>
+__device__ inline void select_block_request(const Params &P, const uint32_t *tb, int b, BlockRaw &in) {
+    constexpr bool RY = YV && MAXA <= 8;
+    const bool root = b == 0;
+    const uint32_t *bp = root ? tb : tb + P.rb_words + (size_t)(b - 1) * P.eb_words;
+    const uint32_t *aux = root ? tb + (RY ? P.ry_off : 0) : tb + P.thr_off + (size_t)(b - 1) * P.thr_stride;
+#pragma unroll
+    for (int v = 0; v < 3; v++) in.q[v] = reinterpret_cast<const uint4 *>(bp)[v];
+    in.aux2 = *reinterpret_cast<const uint2 *>(aux);
+    const double *rpp = reinterpret_cast<const double *>(tb + P.rp_off);        // (8-byte aligned: rp_off is even)
+    in.rp0 = rpp[0]; in.rp1 = rpp[1];
+}
+template <int MAXA, bool YV, class RNG>
+__device__ inline uint32_t select_block_decide(const Params &P, int b, int depth, int root_visit, float mn, float mx,
+                                               const uint32_t *stage, int used, int staged, const double *pbc_sqrt, const BlockRaw &in) {
+    const int A = P.A;
+    const bool chance = depth_flag(depth) != 0;
+    const int w0 = used + select_words(depth, A), need = chance ? 2 : (b == 0 ? 2 * A : 4);
+    if (w0 + need > staged) return 0u;
+    const uint32_t *w = stage + w0;
+    const bool norm = mx > mn;
+    const float span = mx - mn;
+    const double *r64 = pbc_sqrt + P.sims + 2;
+    const bool root = b == 0;
+    const uint32_t wd[12] = {in.q[0].x, in.q[0].y, in.q[0].z, in.q[0].w, in.q[1].x, in.q[1].y, in.q[1].z, in.q[1].w,
+                             in.q[2].x, in.q[2].y, in.q[2].z, in.q[2].w};
+    Kids<2> k;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {                       // (load_kids_static<2>'s unpacking)
+        k.vis[j] = (int32_t)wd[2 * j];
+        k.vsum[j] = __uint_as_float(wd[2 * j + 1]);
+        k.rew[j] = __uint_as_float(wd[4 + j]);
+        k.pri[j] = __uint_as_float(wd[6 + j]);
+        k.chd[j] = (int32_t)wd[8 + j];
+        k.act[j] = (int32_t)wd[10 + j];
+        k.pri64[j] = (double)k.pri[j];
+    }
+    int pick;
+    if (chance) {
+        pick = (__hiloint2double((int)in.aux2.y, (int)in.aux2.x) <= RNG::to_double(w[0], w[1])) ? 1 : 0;
+    } else {
+        if constexpr (YV) { k.yv[0] = __uint_as_float(in.aux2.x); k.yv[1] = __uint_as_float(in.aux2.y); }
+        if (root) { k.pri64[0] = in.rp0; k.pri64[1] = in.rp1; }
+        const int np = root ? root_visit : 1 + k.vis[0] + k.vis[1];
+        pick = pick_decision_words<2, YV, RNG>(k, 2, pbc_sqrt[np], norm, mn, span, P.disc32, w, r64);
+    }
+    const int c = pick ? k.chd[1] : k.chd[0];
+    return 0x100u | ((uint32_t)pick << 7) | (uint32_t)c;
+}
 template <int MAXA, bool YV, class RNG, bool LF = false>
 __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int b, int depth, int root_visit, float mn, float mx,
                                         const uint32_t *stage, int used, int staged, const double *pbc_sqrt) {
+    static_assert(MAXA == 2, "one bit for the pick: the block-parallel selection is built for two actions");
+    if constexpr (LF && SMZ_SELECT_LOADS_FIRST) {
+        BlockRaw in;
+        select_block_request<MAXA, YV>(P, tb, b, in);
+        return select_block_decide<MAXA, YV, RNG>(P, b, depth, root_visit, mn, mx, stage, used, staged, pbc_sqrt, in);
+    }
     constexpr bool RY = YV && MAXA <= 8;
     const int A = P.A;
     const bool chance = depth_flag(depth) != 0;
@@ -835,24 +900,6 @@ __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int
         const uint32_t *aux = root ? tb + (RY ? P.ry_off : 0) : tb + P.thr_off + (size_t)(b - 1) * P.thr_stride;
         Kids<2> k;
         load_kids_static<2>(bp, k);
-        if constexpr (LF && SMZ_SELECT_LOADS_FIRST) {
-        // (round 5) every word the block's branches read is requested HERE, with the children's fields: the block's auxiliary
-        // pair (a chance-flagged block's threshold, a decision-flagged one's value terms -- the same eight bytes) and the root's
-        // float64 priors (every lane reads them: one broadcast address).  Inside the branches each was a dependent round trip
-        // of its own behind the children's -- and the branches of a wavefront run one after the other: up to three serial L2
-        // round trips per pass instead of one (4096 x 100: +0.8 %, profiles/r05_aa_select_loads_ab.txt).
-        const uint2 aux2 = *reinterpret_cast<const uint2 *>(aux);
-        const double *rpp = reinterpret_cast<const double *>(tb + P.rp_off);        // (8-byte aligned: rp_off is even)
-        const double rp2x = rpp[0], rp2y = rpp[1];
-        if (chance) {
-            pick = (__hiloint2double((int)aux2.y, (int)aux2.x) <= RNG::to_double(w[0], w[1])) ? 1 : 0;
-        } else {
-            if constexpr (YV) { k.yv[0] = __uint_as_float(aux2.x); k.yv[1] = __uint_as_float(aux2.y); }
-            if (root) { k.pri64[0] = rp2x; k.pri64[1] = rp2y; }
-            const int np = root ? root_visit : 1 + k.vis[0] + k.vis[1];
-            pick = pick_decision_words<2, YV, RNG>(k, 2, pbc_sqrt[np], norm, mn, span, P.disc32, w, r64);
-        }
-        } else {
         if (chance) {
             pick = (*reinterpret_cast<const double *>(aux) <= RNG::to_double(w[0], w[1])) ? 1 : 0;
         } else {
@@ -869,10 +916,8 @@ __device__ inline uint32_t select_block(const Params &P, const uint32_t *tb, int
             const int np = root ? root_visit : 1 + k.vis[0] + k.vis[1];
             pick = pick_decision_words<2, YV, RNG>(k, 2, pbc_sqrt[np], norm, mn, span, P.disc32, w, r64);
         }
-        }
         c = pick ? k.chd[1] : k.chd[0];
     }
-    static_assert(MAXA == 2, "one bit for the pick: the block-parallel selection is built for two actions");
     return 0x100u | ((uint32_t)pick << 7) | (uint32_t)c;
 }
 // The descent over the evaluated blocks, in two steps.  (1) select_chase, by the tree's lane: follow sel[] from the root --

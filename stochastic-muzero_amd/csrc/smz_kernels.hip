@@ -686,6 +686,11 @@ extern __shared__ float4 smz_search_lds4[];
 #ifndef SMZ_PAIR_A4
 #define SMZ_PAIR_A4 1
 #endif
+// SMZ_SELECT_TWO_PASSES (round 5): the block-parallel selection on trees in global memory requests the blocks of two passes
+// (64 per tree) before it decides the first pass' picks (-DSMZ_SELECT_TWO_PASSES=0: pass by pass).
+#ifndef SMZ_SELECT_TWO_PASSES
+#define SMZ_SELECT_TWO_PASSES 1
+#endif
 // SMZ_EARLY_STAGE (round 5): the next round's MT19937 source words are requested together with the parent rows -- the stream
 // position after the descent follows from the path length alone -- instead of after the selection's last phase.  Before, the
 // wait for the (long landed) parent rows at the network inputs was a vmcnt(0) that also waited for the source words requested
@@ -946,6 +951,28 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             const int nmax = max(__builtin_amdgcn_readlane(valid ? h.n_exp : -1, 0), __builtin_amdgcn_readlane(valid ? h.n_exp : -1, 1));
             const uint32_t *stb = tree_base(P, tree0 + src);
             SMZ_PROBE(1)
+            if constexpr (!TLDS && SMZ_SELECT_LOADS_FIRST && SMZ_SELECT_TWO_PASSES) {
+                // Trees in global memory: a pass of 32 blocks per tree is one L2 round trip, and a search of 100 simulations takes
+                // up to four of them one after the other.  The blocks of TWO passes are requested before the first is decided.
+                for (int base = 0; base <= nmax; base += kWave) {
+                    const int b0 = base + (lane >> 1), b1 = b0 + kWave / 2;
+                    BlockRaw raw0, raw1;
+                    if (b0 <= nexp) select_block_request<MAXA, YV>(P, stb, b0, raw0);
+                    if (b1 <= nexp) select_block_request<MAXA, YV>(P, stb, b1, raw1);
+                    if (b0 <= nexp) {
+                        const int depth = b0 == 0 ? 0 : (int)(selw[src * SELN + b0] >> 9);
+                        const uint32_t r = select_block_decide<MAXA, YV, RngT<PHC>>(P, b0, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged,
+                                                                                     pbc_lds, raw0);
+                        selw[src * SELN + b0] = (uint16_t)((depth << 9) | r);
+                    }
+                    if (b1 <= nexp) {
+                        const int depth = (int)(selw[src * SELN + b1] >> 9);
+                        const uint32_t r = select_block_decide<MAXA, YV, RngT<PHC>>(P, b1, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged,
+                                                                                     pbc_lds, raw1);
+                        selw[src * SELN + b1] = (uint16_t)((depth << 9) | r);
+                    }
+                }
+            } else
             for (int base = 0; base <= nmax; base += kWave / 2) {
                 const int b = base + (lane >> 1);
                 if (b <= nexp) {
