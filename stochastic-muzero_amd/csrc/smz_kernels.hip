@@ -687,9 +687,12 @@ extern __shared__ float4 smz_search_lds4[];
 #define SMZ_PAIR_A4 1
 #endif
 // SMZ_SELECT_TWO_PASSES (round 5): the block-parallel selection on trees in global memory requests the blocks of two passes
-// (64 per tree) before it decides the first pass' picks (-DSMZ_SELECT_TWO_PASSES=0: pass by pass).
+// (64 per tree) before it decides the first pass' picks (-DSMZ_SELECT_TWO_PASSES=0: pass by pass; =3: three passes in flight).
 #ifndef SMZ_SELECT_TWO_PASSES
 #define SMZ_SELECT_TWO_PASSES 1
+#endif
+#ifndef SMZ_LEAF_FIRST
+#define SMZ_LEAF_FIRST 1
 #endif
 // SMZ_EARLY_STAGE (round 5): the next round's MT19937 source words are requested together with the parent rows -- the stream
 // position after the descent follows from the path length alone -- instead of after the selection's last phase.  Before, the
@@ -954,22 +957,23 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
             if constexpr (!TLDS && SMZ_SELECT_LOADS_FIRST && SMZ_SELECT_TWO_PASSES) {
                 // Trees in global memory: a pass of 32 blocks per tree is one L2 round trip, and a search of 100 simulations takes
                 // up to four of them one after the other.  The blocks of TWO passes are requested before the first is decided.
-                for (int base = 0; base <= nmax; base += kWave) {
-                    const int b0 = base + (lane >> 1), b1 = b0 + kWave / 2;
-                    BlockRaw raw0, raw1;
-                    if (b0 <= nexp) select_block_request<MAXA, YV>(P, stb, b0, raw0);
-                    if (b1 <= nexp) select_block_request<MAXA, YV>(P, stb, b1, raw1);
-                    if (b0 <= nexp) {
-                        const int depth = b0 == 0 ? 0 : (int)(selw[src * SELN + b0] >> 9);
-                        const uint32_t r = select_block_decide<MAXA, YV, RngT<PHC>>(P, b0, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged,
-                                                                                     pbc_lds, raw0);
-                        selw[src * SELN + b0] = (uint16_t)((depth << 9) | r);
+                constexpr int NP = SMZ_SELECT_TWO_PASSES > 1 ? SMZ_SELECT_TWO_PASSES : 2;          // passes in flight
+                for (int base = 0; base <= nmax; base += NP * (kWave / 2)) {
+                    BlockRaw raw[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; p++) {
+                        const int b = base + p * (kWave / 2) + (lane >> 1);
+                        if (b <= nexp) select_block_request<MAXA, YV>(P, stb, b, raw[p]);
                     }
-                    if (b1 <= nexp) {
-                        const int depth = (int)(selw[src * SELN + b1] >> 9);
-                        const uint32_t r = select_block_decide<MAXA, YV, RngT<PHC>>(P, b1, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged,
-                                                                                     pbc_lds, raw1);
-                        selw[src * SELN + b1] = (uint16_t)((depth << 9) | r);
+#pragma unroll
+                    for (int p = 0; p < NP; p++) {
+                        const int b = base + p * (kWave / 2) + (lane >> 1);
+                        if (b <= nexp) {
+                            const int depth = b == 0 ? 0 : (int)(selw[src * SELN + b] >> 9);
+                            const uint32_t r = select_block_decide<MAXA, YV, RngT<PHC>>(P, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged,
+                                                                                         pbc_lds, raw[p]);
+                            selw[src * SELN + b] = (uint16_t)((depth << 9) | r);
+                        }
                     }
                 }
             } else
@@ -1029,9 +1033,12 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
 #endif
             }
 #endif
+            // (trees in global memory: the leaf's action word is requested BEFORE the path records' words, so the two L2 round trips
+            //  overlap -- the records' loop waits for its own loads, and the leaf's used to start only behind that wait)
+            if constexpr (!TLDS && SMZ_LEAF_FIRST) { if (valid && len > 0) L = select_leaf(P, stb, pathw + lane * SELN, len); }
             for (int d = lane >> 1; d < blen; d += kWave / 2) select_record(P, stb, pathw + src * SELN, d, pvals + src * P.P);
             if (valid && len > 0) {
-                L = select_leaf(P, stb, pathw + lane * SELN, len);
+                if constexpr (TLDS || !SMZ_LEAF_FIRST) L = select_leaf(P, stb, pathw + lane * SELN, len);
 #if !(SMZ_EARLY_ROWS && SMZ_EARLY_STAGE)
                 const int nw = select_words(len, A);                    // the words the descent's levels drew (all inside the staged window)
                 rng.used += nw; rng.ready -= nw; rng.idx += nw;
