@@ -14,9 +14,9 @@ for case in range(n_cases):
     w = list(nets)[rs.randint(len(nets))]
     model = nets[w]; heads = model.heads("cuda:0", backend="hip")
     A = model.action_dimension
-    B = int(rs.choice([1, 2, 3, 63, 64, 65, 511, 2047, 2049, 4096, 4097, 6001]))
-    sims = int(rs.choice([0, 1, 2, 5, 13, 31, 50]))
-    K = int(rs.randint(1, A + 2))
+    B = int(rs.choice([1, 2, 3, 63, 64, 65, 511, 2047, 2049, 4096, 4096, 4096, 4097, 6001]))
+    sims = int(rs.choice([0, 1, 2, 5, 13, 31, 50, 53, 54, 70, 100, 126, 127]))     # (> 53: trees in global memory; <= 126: block-parallel selection there)
+    K = 2 if rs.randint(3) == 0 else int(rs.randint(1, A + 2))      # (K = 2: the specialised instantiations)
     T = float(rs.choice([0.0, 0.2, 0.5, 1.0]))
     train = bool(rs.randint(2))
     obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(case)).mul(0.3).cuda()
