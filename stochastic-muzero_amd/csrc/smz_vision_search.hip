@@ -49,6 +49,14 @@ namespace {
 // staged in LDS once per launch.  Before, every tower layer of every round began with a scalar load of the bias offset, a
 // global load of the bias and a wait for it (an L2 round trip at one wavefront per SIMD: nothing hides it) -- four to five such
 // trips per round (profiles/r05_s_stage_waits.txt).  =0 builds keep the global loads.
+// SMZ_VISION_BPS (round 5): the two-action instantiation selects with k_search_mlp's block-parallel selection -- one tree per
+// wavefront = at most 63 blocks for 62 simulations: the whole tree's picks in ONE pass of select_block (a lane per block), a
+// pointer chase, a lane per level for the path records -- and requests the leaf's parent planes (an L2 round trip) and the next
+// round's source words right behind the chase.  Needs the chance thresholds beside the blocks (expand_backup_tree<THR>: in the
+// padding of the 64-byte blocks).  A level whose words lie beyond the staged window falls back to the paired descent.
+#ifndef SMZ_VISION_BPS
+#define SMZ_VISION_BPS 1
+#endif
 #ifndef SMZ_VISION_BIAS_LDS
 #define SMZ_VISION_BIAS_LDS 1
 #endif
@@ -66,7 +74,7 @@ constexpr int kYS = 36;                              // floats per (tower, leaf)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct VisLds {                                      // float offsets from the dynamic LDS base
-    int small, pbc, wave, per_wave, plane, pv, rng, outs, prof, F, H1, H2, Y, br, bias, trees, total;
+    int small, pbc, wave, per_wave, plane, pv, rng, outs, prof, sel, sel_n, F, H1, H2, Y, br, bias, trees, total;
 };
 __host__ __device__ inline VisLds vis_lds(const Params &P, int A) {
     VisLds m;
@@ -78,7 +86,9 @@ __host__ __device__ inline VisLds vis_lds(const Params &P, int A) {
     m.rng = m.pv + P.P * 4;
     m.outs = m.rng + r4(kRngStride);
     m.prof = m.outs + r4(A + 2);                                  // eight 64-bit phase counters (SMZ_DEBUG_SKIP=16)
-    m.per_wave = m.prof + 16;
+    m.sel = m.prof + 16;                                          // [2][sel_n] 16-bit words: picks per block | the path (select_block / select_chase)
+    m.sel_n = (P.sims + 2 + 1) & ~1;
+    m.per_wave = m.sel + (SMZ_VISION_BPS ? r4(m.sel_n) : 0);
     m.F = m.wave + kVW * m.per_wave;
     m.H1 = m.F + 3 * kVW * kFS;
     m.H2 = m.H1 + kTowers * kVW * kHS;
@@ -229,6 +239,13 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
     P.K = KS; P.tpw = VT;
     if (AEQ) P.A = MAXA;            // (not d.A: a modified copy of the descriptor, indexed at run time, would live in scratch)
     fix_layout(P, AEQ, true);
+    // block-parallel selection (two actions, two children, at most 126 simulations: 7-bit block indices): chance thresholds
+    // in the padding of the 64-byte blocks, as the global-memory-tree instantiations of k_search_mlp keep them
+    constexpr bool VBPS = SMZ_VISION_BPS && MAXA == 2 && AEQ;
+    const bool vbps = VBPS && P.sims <= 126 && P.eb_words >= 14;           // (wave-uniform)
+    // (the children's stored value terms -- YV, as the LDS-resident k_search_mlp keeps them -- measured equal here: 80.1 against
+    //  80.4 M, profiles/r05_ah_vision_bps_ab.txt)
+    if (VBPS) { P.thr_off = P.rb_words + 12; P.thr_stride = P.eb_words; P.ry_off = -1; }
     float *lds = reinterpret_cast<float *>(smz_vsearch_lds4);
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int A = P.A, S = d.S, K4h = up4(d.H);
@@ -357,8 +374,8 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
         float leaf_rw = 0.f;
         if (valid) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            if (s > 0) expand_backup_tree<MAXA, KS, true>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
-                                                          outs[lane * slot + A], pvals + lane * P.P, &leaf_rw);
+            if (s > 0) expand_backup_tree<MAXA, KS, true, VBPS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1],
+                                                                outs[lane * slot + A], pvals + lane * P.P, &leaf_rw);
         }
         if (s > 0 && live0) {
             const int len = __builtin_amdgcn_readlane(h.path_len, 0);
@@ -379,7 +396,53 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
                 }
             }
         }
-        if constexpr (MAXA == 2) {
+        bool bps_done = false;                 // (wave-uniform) this round's leaf came out of the block-parallel selection
+        float early_x[3] = {0.f, 0.f, 0.f};    // ... and its parent planes were requested there
+        StagePre<VT> pre;
+        if constexpr (VBPS) if (vbps && live0) {
+            uint16_t *selw = reinterpret_cast<uint16_t *>(wl + ml.sel), *pathw = selw + ml.sel_n;
+            if (valid && s > 0) selw[h.n_exp] = (uint16_t)(h.path_len << 9);          // depth of the node the expansion created
+            lds_sync();
+            const int nexp = __builtin_amdgcn_readlane(h.n_exp, 0), rvis = __builtin_amdgcn_readlane(h.root_visit, 0);
+            const float bmn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.mn), 0));
+            const float bmx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.mx), 0));
+            const int bused = __builtin_amdgcn_readlane(valid ? rng.used : 0, 0), bstaged = __builtin_amdgcn_readlane(valid ? rng.staged : 0, 0);
+            const int bstage = __builtin_amdgcn_readlane(valid ? (int)(rng.stage - rng_tile) : 0, 0);
+            const uint32_t *stb = tree_base(P, tree0);
+            for (int base = 0; base <= nexp; base += kWave) {
+                const int b = base + lane;
+                if (b <= nexp) {
+                    const int depth = b == 0 ? 0 : (int)(selw[b] >> 9);
+                    const uint32_t r = select_block<MAXA, false, RngMt>(P, stb, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged, pbc_lds);
+                    selw[b] = (uint16_t)((depth << 9) | r);
+                }
+            }
+            lds_sync();
+            int len = 0;
+            if (valid) len = select_chase(selw, pathw);
+            lds_sync();
+            const int blen = __builtin_amdgcn_readlane(len, 0);
+            if (blen > 0) {                                                   // (wave-uniform; 0: a level's words beyond the staged window)
+                if (valid) {                                                  // the words the descent's levels drew
+                    const int nw = select_words(len, A);
+                    rng.used += nw; rng.ready -= nw; rng.idx += nw;
+                    if (rng.idx >= kMtN) { rng.idx -= kMtN; rng.wrapped(); }
+                    packed = rng.pack();
+                }
+                int par = 0;
+                if (valid && len > 1) { const int loc = pathw[len - 2], pb = loc >> 8; par = pb == 0 ? 1 + (loc & 3) : 1 + A + (pb - 1) * 2 + (loc & 3); }
+                const int parent = __builtin_amdgcn_readlane(par, 0);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // (planes stored in earlier rounds may be this round's parents)
+                const float *hrow = P.hidden + ((size_t)tree0 * P.N + parent) * P.hs;
+                early_x[0] = hrow[p]; early_x[1] = hrow[kPix + p]; early_x[2] = hrow[2 * kPix + p];
+                stage_issue<VT, false>(P, tree, valid, packed, pre);
+                for (int dd = lane; dd < blen; dd += kWave) select_record(P, stb, pathw, dd, pvals);
+                if (valid) { L = select_leaf(P, stb, pathw, len); h.path_len = len; }
+                bps_done = true;
+            }
+        }
+        if (bps_done) {
+        } else if constexpr (MAXA == 2) {
             const int pk = __builtin_amdgcn_readlane(valid ? rng.pack() : 0, 0), us = __builtin_amdgcn_readlane(valid ? rng.used : 0, 0);
             const float hmn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.mn), 0));
             const float hmx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.mx), 0));
@@ -392,8 +455,8 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
                     hs.mn = hmn; hs.mx = hmx; hs.root_visit = hrv;
                 }
                 int len = 0;
-                const Leaf Lp = select_tree<MAXA, KS, false, true, true>(P, tree0, rng, hs, pbc_lds, len, n_dec, n_chance, n_children,
-                                                                        pvals, lane >> 1);
+                const Leaf Lp = select_tree<MAXA, KS, false, true, true, VBPS>(P, tree0, rng, hs, pbc_lds, len, n_dec, n_chance, n_children,
+                                                                              pvals, lane >> 1);
                 if (lane == 0) {
                     L = Lp;
                     h.path_len = len;
@@ -408,9 +471,10 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
         }
         SMZ_VSTAMP(0)
         // hidden rows written in earlier rounds (by this wave) may be this round's parent rows
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        StagePre<VT> pre;
-        stage_issue<VT, false>(P, tree, valid, packed, pre);
+        if (!bps_done) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            stage_issue<VT, false>(P, tree, valid, packed, pre);
+        }
         // ---- convolutional part of this wave's leaf: flat inputs of its towers into the tiles ------------------------------
         const bool dyn = __builtin_amdgcn_readlane(L.branch, 0) != 0;
         const int leaf = wave;
@@ -420,7 +484,8 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
             const int leaf_id = __builtin_amdgcn_readlane(L.leaf_id, 0);
             const float *hrow = P.hidden + ((size_t)tree0 * P.N + parent) * P.hs;
             const float a_plane = (float)(actn + 1) / (float)d.A;        // muzero_model.py:511-522
-            float x[4] = {hrow[p], hrow[kPix + p], hrow[2 * kPix + p], a_plane};
+            float x[4] = {early_x[0], early_x[1], early_x[2], a_plane};
+            if (!bps_done) { x[0] = hrow[p]; x[1] = hrow[kPix + p]; x[2] = hrow[2 * kPix + p]; }
             SMZ_VDRAIN()
             SMZ_VSTAMP(1)
             const int32_t *o = d.off + SMZ_V_TRANS_BASE + (dyn ? 0 : SMZ_V_TRANS_STRIDE);
@@ -532,7 +597,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
     if (valid) {
         if (P.sims > 0) {
             rng.load(P.mt + (size_t)tree * kMtN, packed, rng_tile + lane * kRngStride, kRngStage);
-            expand_backup_tree<MAXA, KS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
+            expand_backup_tree<MAXA, KS, false, VBPS>(P, tree, rng, h, outs + lane * slot, outs[lane * slot + A + 1], outs[lane * slot + A],
                                          pvals + lane * P.P);
             for (int i = 0; i < h.path_len; i++) P.path[(size_t)i * P.B + tree] = pvals[lane * P.P + i];
             packed = rng.pack();

@@ -699,7 +699,9 @@ def test_env_step_with_record_equals_step_then_pack():
 
 
 @pytest.mark.parametrize("wname,B,sims", [("visionnet_L1_seed0", 1024, 50), ("visionnet_L1_seed0", 37, 12),
-                                          ("visionnet_L2_bn", 200, 16), ("visionnet_L1_seed0", 16, 0)])
+                                          ("visionnet_L2_bn", 200, 16), ("visionnet_L1_seed0", 16, 0),
+                                          # round 5: the block-parallel selection -- two passes of 64 blocks, its largest search, one beyond
+                                          ("visionnet_L1_seed0", 64, 100), ("visionnet_L1_seed0", 48, 126), ("visionnet_L1_seed0", 32, 127)])
 def test_vision_single_launch_search_equals_stepwise_search(wname, B, sims):
     """smz_search_vision (whole vision search in one kernel: towers of 16 leaves on the matrix cores) against the
     step-wise kernels (one wavefront per leaf, towers as k-ordered fma chains on the vector units): an f32-input MFMA is
