@@ -57,6 +57,9 @@ namespace {
 #ifndef SMZ_VISION_BPS
 #define SMZ_VISION_BPS 1
 #endif
+#ifndef SMZ_VISION_BPS_LF
+#define SMZ_VISION_BPS_LF 1
+#endif
 #ifndef SMZ_VISION_BIAS_LDS
 #define SMZ_VISION_BIAS_LDS 1
 #endif
@@ -413,7 +416,8 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
                 const int b = base + lane;
                 if (b <= nexp) {
                     const int depth = b == 0 ? 0 : (int)(selw[b] >> 9);
-                    const uint32_t r = select_block<MAXA, false, RngMt>(P, stb, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged, pbc_lds);
+                    // (LF: a block's auxiliary words requested with its children's fields -- one wavefront per SIMD: every LDS round trip counts)
+                    const uint32_t r = select_block<MAXA, false, RngMt, SMZ_VISION_BPS_LF>(P, stb, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged, pbc_lds);
                     selw[b] = (uint16_t)((depth << 9) | r);
                 }
             }
@@ -436,8 +440,9 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
                 const float *hrow = P.hidden + ((size_t)tree0 * P.N + parent) * P.hs;
                 early_x[0] = hrow[p]; early_x[1] = hrow[kPix + p]; early_x[2] = hrow[2 * kPix + p];
                 stage_issue<VT, false>(P, tree, valid, packed, pre);
+                if (SMZ_VISION_BPS_LF && valid) L = select_leaf(P, stb, pathw, len);      // (its word requested before the records')
                 for (int dd = lane; dd < blen; dd += kWave) select_record(P, stb, pathw, dd, pvals);
-                if (valid) { L = select_leaf(P, stb, pathw, len); h.path_len = len; }
+                if (valid) { if (!SMZ_VISION_BPS_LF) L = select_leaf(P, stb, pathw, len); h.path_len = len; }
                 bps_done = true;
             }
         }
