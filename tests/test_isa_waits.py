@@ -10,6 +10,7 @@ gfx9, and it cannot be counted across branches -- put a memory round trip on eve
   2. the same rounds: the six source-word loads of the NEXT round are issued in the selection, together with the parent-row
      loads (SMZ_EARLY_STAGE), i.e. before the first s_setprio that opens the network phase.
   3. k_search_vision's rounds: no 16-byte global load at all -- the tower biases come from LDS (SMZ_VISION_BIAS_LDS).
+  4. trees in global memory: the blocks of two selection passes are requested before anything waits (SMZ_SELECT_TWO_PASSES).
 """
 import os
 import re
@@ -75,10 +76,35 @@ def _kernel(lines, mangled_prefix):
 
 
 @pytest.fixture(scope="module")
-def search_isa(tmp_path_factory):
-    lines = _isa(tmp_path_factory.mktemp("isa"), "smz_kernels.hip", ["-DSMZ_PART=2"])
+def part2_isa(tmp_path_factory):
+    return _isa(tmp_path_factory.mktemp("isa"), "smz_kernels.hip", ["-DSMZ_PART=2"])
+
+
+@pytest.fixture(scope="module")
+def search_isa(part2_isa):
     # k_search_mlp<2, 2, 1, false, true, false, false, true>: the headline workload's instantiation
-    return _kernel(lines, "_ZN12_GLOBAL__N_112k_search_mlpILi2ELi2ELi1ELb0ELb1ELb0ELb0ELb1EEE")
+    return _kernel(part2_isa, "_ZN12_GLOBAL__N_112k_search_mlpILi2ELi2ELi1ELb0ELb1ELb0ELb0ELb1EEE")
+
+
+def test_two_selection_passes_are_requested_together_on_global_memory_trees(part2_isa):
+    """k_search_mlp<2, 2, 1, false, true, false, false, false> (C5's per-rank shape: trees in global memory): the blocks of two
+    passes of the block-parallel selection -- per block three 16-byte loads, the auxiliary pair, the root's two float64 priors --
+    are all requested before the first wait on the vector-memory counter (SMZ_SELECT_TWO_PASSES, select_block_request)."""
+    body = _kernel(part2_isa, "_ZN12_GLOBAL__N_112k_search_mlpILi2ELi2ELi1ELb0ELb1ELb0ELb0ELb0EEE")
+    best, wide, cur, curw = 0, 0, 0, 0
+    for t, loop in body:
+        if not loop:
+            continue
+        if t.startswith("global_load_dword"):
+            cur += 1
+            curw += t.startswith("global_load_dwordx4")
+        elif t.startswith(("s_waitcnt vmcnt", "global_store")):
+            if curw > wide:
+                best, wide = cur, curw
+            cur = curw = 0
+    # (one pass' block: two 16-byte + an 8-byte load of its twelve words -- the last two are not read --, the auxiliary pair, the
+    #  root's priors: 4-5 loads, 2-3 of them 16-byte)
+    assert wide >= 4 and best >= 8, f"longest run of block requests without a wait: {best} loads, {wide} of them 16-byte (two passes: >= 8 / >= 4)"
 
 
 def test_no_wait_behind_a_twisted_word_store(search_isa):
