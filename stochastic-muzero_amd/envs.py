@@ -219,7 +219,7 @@ class HostVecEnv:
         self.batch_step = bool(batch_step)    # envs whose class offers make_batch are stepped slice-wise (host_envs.CartPoleBatch)
         self.spin = int(spin)        # polls of a shared word before a waiter sleeps in the kernel (futex); 0 on a CPU-quota'd box is fine
         B, row, dtype = self.B, self.adapter.row, self.adapter.dtype
-        lay = _he.block_layout(B, row, dtype)
+        lay = _he.block_layout(B, row, dtype, max(1, self.workers))
         self._procs, self._block, self._registered, self._seq = [], None, False, 0
         if self.workers:
             self._block = _he.SharedBlock(lay["total"])
@@ -232,7 +232,7 @@ class HostVecEnv:
             self._base = torch.zeros(lay["total"], dtype=torch.uint8, pin_memory=self.device.type != "cpu")
             buf = memoryview(self._base.numpy())
         self._arr, self._ctrl, self._lay = _he.map_arrays(buf, B, row, dtype, max(1, self.workers))
-        self._words = _he.control_words(buf)
+        self._words = _he.control_words(buf, max(1, self.workers))
         self._host_ptr = self._base.data_ptr()
         tdt = torch.float32 if dtype is np.float32 else torch.uint8
         self._d_action = torch.zeros(B, dtype=torch.int32, device=self.device)

@@ -204,6 +204,18 @@ class TrajectoryGather:
                 frame_rows.append(torch.cat(list(bufs[k]), 1))
         return torch.cat(rows, 0), (torch.cat(frame_rows, 0) if frame_rows else None)
 
+    def abandon(self):
+        """Drops a half-posted exchange (ChunkExchange.warm_up's fallback): the outstanding work handles are WAITED for first
+        (clearing the list under live sends / receives left them writing into freed buffers), errors of the wait are
+        swallowed -- the exchange has failed already -- and the per-chunk sizes are forgotten."""
+        pend, self._pending, self._sizes = self._pending, [], None
+        for works, _, _ in pend:
+            for w in works or ():
+                try:
+                    w.wait()
+                except Exception:                   # noqa: BLE001
+                    pass
+
     def exposed_gather_ms(self):
         """After a synchronisation: device time between the end of the search and the end of the exchange in the last finish()
         (what of the transfer the search did not hide); None for staged (gloo) exchanges."""
@@ -223,9 +235,12 @@ class ChunkExchange:
         rows(chunks, name, t0, t1) -> tensor   the groups' `name` rows ("data" | "obs") side by side (dim 1), or None
 
     warm_up(n) is the first use of the exchange: an exception raised there (outside any timed region) switches to "plain" and
-    plays again -- what `gather_mode` in bench.py's JSON line reports.  (An RCCL failure that hangs or aborts instead of raising
-    is not caught in-process: bench.py's launcher re-runs the ranks with --gather-mode plain, and the process group carries a
-    timeout so that a hang ends as an error.)"""
+    plays again -- what `gather_mode` in bench.py's JSON line reports.  The switch is AGREED between the ranks (a
+    rank-local decision left one rank in the synchronous plain gather while its peers were in the sliced one): after the first
+    run every rank, failed or not, enters one MAX all-reduce of its failed flag, and all of them switch and replay when any
+    did.  (A peer that is stuck INSIDE the sliced exchange because the failing rank never posted its side cannot reach that
+    all-reduce; like an RCCL failure that hangs or aborts instead of raising, that ends at the process group's timeout as an
+    error, and bench.py's launcher re-runs the ranks with --gather-mode plain.)"""
 
     def __init__(self, tg, play, rows, mode="overlapped", total_envs=None, log=None):
         assert mode in ("overlapped", "plain")
@@ -252,17 +267,32 @@ class ChunkExchange:
             tg.start(self.rows(chunks, "data", cuts[i], cuts[i + 1]), self.rows(chunks, "obs", cuts[i], cuts[i + 1]))
         return chunks, tg.finish()
 
+    def _any_rank_failed(self, failed):
+        """MAX over the ranks of `failed` (every rank calls this exactly once per warm-up in overlapped mode)."""
+        tg = self.tg
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(tg.group) == 1:
+            return bool(failed)
+        dev = "cuda" if dist.get_backend(tg.group) == "nccl" else "cpu"
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=tg.group)
+        return bool(int(flag.item()))
+
     def warm_up(self, n):
+        if self.mode["kind"] == "plain":
+            return self.run(n)
+        out, err = None, None
         try:
-            return self.run(n)
+            out = self.run(n)
         except Exception as e:                      # noqa: BLE001  (whatever the first contact with the collective library raises)
-            if self.mode["kind"] == "plain":
-                raise
-            if self.log is not None:
-                self.log(f"overlapped trajectory gather failed at warm-up ({type(e).__name__}: {e}); using the plain gather")
-            self.mode.update(kind="plain", error=f"{type(e).__name__}: {e}")
-            self.tg._pending, self.tg._sizes = [], None
-            return self.run(n)
+            err = e
+            self.tg.abandon()
+        if not self._any_rank_failed(err is not None):
+            return out
+        why = f"{type(err).__name__}: {err}" if err is not None else "another rank's overlapped exchange failed"
+        if self.log is not None:
+            self.log(f"overlapped trajectory gather failed at warm-up ({why}); using the plain gather")
+        self.mode.update(kind="plain", error=why)
+        return self.run(n)
 
 
 def broadcast_model(model, src=0, group=None, device=None, loopback=False):

@@ -409,15 +409,20 @@ def build_env(e):
     return e() if isinstance(e, type) or (callable(e) and not hasattr(e, "step")) else e
 
 
-CTRL_BYTES = 4096
 CMD_STEP, CMD_RESET, CMD_EXIT = 1, 2, 3
 
 
-def block_layout(B, row, dtype):
+def ctrl_bytes(workers):
+    """Size of the control region in front of the arrays: whole 4 KB pages holding the GO word, the command slot and one 64-byte
+    line per worker's done word (a fixed single page capped the worker count at 60 with a bare assertion)."""
+    return (4 * done_word(max(1, int(workers))) + 4095) // 4096 * 4096
+
+
+def block_layout(B, row, dtype, workers=1):
     """Byte offsets of the arrays of a B-env block, every array on a 4 KB boundary (rows of different workers never share a
-    page with another array)."""
+    page with another array); the control region in front grows with the worker count."""
     item = np.dtype(dtype).itemsize
-    out, off = {}, CTRL_BYTES
+    out, off = {"ctrl": ctrl_bytes(workers)}, ctrl_bytes(workers)
     for name, nbytes in (("action", 4 * B), ("reward", 4 * B), ("flag", B), ("active", B), ("ended", B),
                          ("obs", B * row * item), ("rec", B * row * item)):
         out[name] = off
@@ -427,7 +432,7 @@ def block_layout(B, row, dtype):
 
 
 def map_arrays(buf, B, row, dtype, workers):
-    lay = block_layout(B, row, dtype)
+    lay = block_layout(B, row, dtype, workers)
     arr = dict(action=np.frombuffer(buf, np.int32, B, lay["action"]), reward=np.frombuffer(buf, np.float32, B, lay["reward"]),
                flag=np.frombuffer(buf, np.uint8, B, lay["flag"]), active=np.frombuffer(buf, np.uint8, B, lay["active"]),
                ended=np.frombuffer(buf, np.uint8, B, lay["ended"]),
@@ -436,8 +441,9 @@ def map_arrays(buf, B, row, dtype, workers):
     # control page: int32 word [GO] step sequence (futex, written by the parent); int64 slot [1] command; int32 words
     # [done_word(w)] sequence number worker w has finished (-1: attached, nothing done yet) -- written by worker w ONLY, and the
     # futex word the parent sleeps on while that worker is the one it is waiting for
-    ctrl = np.frombuffer(buf, np.int64, CTRL_BYTES // 8, 0)
-    assert done_word(workers) <= CTRL_BYTES // 4
+    ctrl = np.frombuffer(buf, np.int64, lay["ctrl"] // 8, 0)
+    if 4 * done_word(workers) > lay["ctrl"]:
+        raise ValueError(f"control region of {lay['ctrl']} bytes cannot hold the done words of {workers} workers")
     return arr, ctrl, lay
 
 
@@ -446,8 +452,8 @@ def done_word(w):
     return 64 + 16 * w
 
 
-def control_words(buf):
-    return np.frombuffer(buf, np.int32, CTRL_BYTES // 4, 0)
+def control_words(buf, workers=1):
+    return np.frombuffer(buf, np.int32, ctrl_bytes(workers) // 4, 0)
 
 
 class SharedBlock:
@@ -574,7 +580,7 @@ def worker_main(spec_path):
     envs = [build_env(e) for e in spec["envs"]]
     sl = HostSlice(envs, spec["lo"], spec["adapter"], arr, spec["action_map"], spec["env_seed"], spec["limit"], spec["on_end"],
                    spec["first_env"], batch=spec.get("batch", True))
-    words = control_words(mm)
+    words = control_words(mm, spec["workers"])
     w, parent = spec["worker"], spec["parent_pid"]
     seq = 0
     mine = done_word(w)

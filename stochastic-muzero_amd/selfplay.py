@@ -768,20 +768,29 @@ def self_play_iterations(env, model, mcts, temperature, steps, iterations, repla
         td_steps = getattr(replay_buffer, "td_steps", None)
     kw = _cut_rules(env, steps, ignore_termination, limit_of_game_play)
     cut = {k: kw[k] for k in ("limit_of_game_play", "keep_partial", "observation_shape")}
-    job = None
-    for it in range(int(iterations)):
-        T = temperature(it) if callable(temperature) else temperature
-        got = _play_and_gather(env, heads_of(), mcts, T, steps, gather)
-        new = None
-        if got is not None:
-            data, frames, chunk = got
-            new = RecordsJob(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, td_steps, kw["ignore_termination"],
-                             kw["after_end"], frames)
-        if it > 0:
-            yield (None, None) if job is None else _store(job.finish(priority_scale, **cut), replay_buffer)
-        job = new
-    if int(iterations) > 0:
-        yield (None, None) if job is None else _store(job.finish(priority_scale, **cut), replay_buffer)
+    job = new = None
+    try:
+        for it in range(int(iterations)):
+            T = temperature(it) if callable(temperature) else temperature
+            got = _play_and_gather(env, heads_of(), mcts, T, steps, gather)
+            new = None
+            if got is not None:
+                data, frames, chunk = got
+                new = RecordsJob(data, chunk.rec_obs_dim, env.num_actions, mcts.discount, td_steps, kw["ignore_termination"],
+                                 kw["after_end"], frames)
+            if it > 0:
+                done, job = job, None
+                yield (None, None) if done is None else _store(done.finish(priority_scale, **cut), replay_buffer)
+            job, new = new, None
+        if int(iterations) > 0:
+            done, job = job, None
+            yield (None, None) if done is None else _store(done.finish(priority_scale, **cut), replay_buffer)
+    finally:
+        # closed early (the consumer raised, or stopped iterating): the jobs still pending give their page-locked staging back
+        #  -- RecordsJob.close() waits for the job's own copies first
+        for j in (job, new):
+            if j is not None:
+                j.close()
 
 
 def _window_sums(src, e, t0, n):
@@ -791,7 +800,9 @@ def _window_sums(src, e, t0, n):
     if col is None:
         col = src._reward_col = np.ascontiguousarray(src.rec[:, :, src.o])      # [B][T] contiguous, made once per chunk
     if len(e) == B_ and (n == T).all() and (t0 == 0).all() and (e == np.arange(B_)).all():
-        return np.cumsum(col, axis=1)[:, -1]                       # one game per env over the whole chunk: a row scan each
+        # one game per env over the whole chunk: a row scan each, accumulated in float64 like Python's sum of the floats
+        # (a float32 scan differed from sum(g.rewards) in the 7th digit for non-integer rewards)
+        return np.cumsum(col, axis=1, dtype=np.float64)[:, -1]
     flat = col.reshape(-1)
     order = np.argsort(-n, kind="stable")                          # games ordered by length: step k touches a prefix
     lo_s, n_s = (e * T + t0)[order], n[order]
@@ -870,7 +881,8 @@ def learning_cycle(number_of_iteration=10000, number_of_self_play_before_trainin
     number_of_training_before_self_play == 0 -- the loop is then driven by self_play_iterations: the search of iteration
     k + 1 is enqueued before the host turns iteration k's chunk into games, stores them and saves the model, so the host half
     hides behind the search (the games, rewards and buffer contents are those of the synchronous loop; the weights never
-    change, so the per-iteration broadcast is skipped too).  True forces it for a caller whose train() leaves the searching
+    change, so the per-iteration broadcast is skipped too).  Note that muzero_model.save_model -- file IO -- then runs while
+    the next iteration's search is in flight on the device.  True forces it for a caller whose train() leaves the searching
     weights alone until the loop ends (iteration k + 1 is already running with the weights of the moment it was enqueued when
     iteration k trains); False keeps the synchronous self_play_iteration per iteration.  With training between the
     iterations the loop stays synchronous: iteration k + 1 must search with the weights iteration k's training produced
@@ -900,58 +912,60 @@ def learning_cycle(number_of_iteration=10000, number_of_self_play_before_trainin
         steps = steps_per_iteration or getattr(gameplay, "limit", 0) or 500
         piped = self_play_iterations(gameplay, muzero_model, monte_carlo_tree_search, lambda it: temperature_of(it + 1), steps,
                                      number_of_iteration, replay_buffer=replay_buffer, gather=gather)
-    for ep in range(1, number_of_iteration + 1):
-        temperature = temperature_of(ep)
-        learner = True
-        if pipelined:
-            game, batched_reward = next(piped)                # (iteration ep + 1's search is already enqueued)
-            learner = game is not None
-            game = game or []
-        elif batched:
-            steps = steps_per_iteration or getattr(gameplay, "limit", 0) or 500
-            # (the games are stored by self_play_iteration itself -- replay_buffer.save_game per game, self_play.py:266-268 --
-            #  and their mean reward comes back with them)
-            game, batched_reward = self_play_iteration(gameplay, muzero_model, monte_carlo_tree_search, temperature, steps,
-                                                       replay_buffer=replay_buffer, gather=gather)
-            learner = game is not None        # with `gather`, only the learner rank receives the games (self_play.py:240-256)
-            game = game or []
-        else:
-            game = [play_game(environment=gameplay, model=muzero_model, monte_carlo_tree_search=monte_carlo_tree_search,
-                              temperature=temperature, replay_buffer=replay_buffer)
-                    for _ in range(number_of_self_play_before_training)]
-        cache_reward, cache_loss = [], []
-        if learner:
-            if batched:
-                cache_reward = [batched_reward] if game else []
+    try:
+        for ep in range(1, number_of_iteration + 1):
+            temperature = temperature_of(ep)
+            learner = True
+            if pipelined:
+                game, batched_reward = next(piped)                # (iteration ep + 1's search is already enqueued)
+                learner = game is not None
+                game = game or []
+            elif batched:
+                steps = steps_per_iteration or getattr(gameplay, "limit", 0) or 500
+                # (the games are stored by self_play_iteration itself -- replay_buffer.save_game per game, self_play.py:266-268 --
+                #  and their mean reward comes back with them)
+                game, batched_reward = self_play_iteration(gameplay, muzero_model, monte_carlo_tree_search, temperature, steps,
+                                                           replay_buffer=replay_buffer, gather=gather)
+                learner = game is not None        # with `gather`, only the learner rank receives the games (self_play.py:240-256)
+                game = game or []
             else:
-                for g in game:
-                    replay_buffer.save_game(g)
-                    cache_reward.append(sum(g.rewards))
-            # (the reference divides by zero when an iteration yields no game; a chunk of on_end="reset" envs may hold no
-            # FINISHED game: nan, which never equals max(reward), so nothing is saved for it)
-            reward.append(sum(cache_reward) / len(cache_reward) if cache_reward else float("nan"))
-            did_better = None if (game and reward[-1] == max(r for r in reward if r == r)
-                                  and not all(g.reanalyzed for g in game)) else "do not save"
-            if did_better is None and verbose:
-                print("save model with : ", reward[-1], " reward")
-            muzero_model.save_model(directory=model_directory, tag=model_tag_number, model_update_or_backtrack=did_better)
-            for _ in range(number_of_training_before_self_play):
-                new_priority, batch_game_position = muzero_model.train(replay_buffer.sample_batch())
-                replay_buffer.update_value(new_priority, batch_game_position)
-                cache_loss.append(muzero_model.store_loss[-1][0])
-        else:
-            reward.append(float("nan"))       # an actor rank neither stores games, nor saves, nor trains
-        if broadcast is not None and not (pipelined and number_of_training_before_self_play == 0):
-            broadcast(muzero_model)           # the new weights reach the actors (self_play.py:285-288 -> next :249-256)
-        loss.append(sum(cache_loss) / len(cache_loss) if cache_loss else float("nan"))   # (the reference divides by 0 here)
-        epoch_pr.append(f"EPOCH {ep} || selfplay reward: {reward[-1]} || training loss: {loss[-1]}||")
-        if verbose and learner:
-            print(epoch_pr[-1], end="\r")
+                game = [play_game(environment=gameplay, model=muzero_model, monte_carlo_tree_search=monte_carlo_tree_search,
+                                  temperature=temperature, replay_buffer=replay_buffer)
+                        for _ in range(number_of_self_play_before_training)]
+            cache_reward, cache_loss = [], []
+            if learner:
+                if batched:
+                    cache_reward = [batched_reward] if game else []
+                else:
+                    for g in game:
+                        replay_buffer.save_game(g)
+                        cache_reward.append(sum(g.rewards))
+                # (the reference divides by zero when an iteration yields no game; a chunk of on_end="reset" envs may hold no
+                # FINISHED game: nan, which never equals max(reward), so nothing is saved for it)
+                reward.append(sum(cache_reward) / len(cache_reward) if cache_reward else float("nan"))
+                did_better = None if (game and reward[-1] == max(r for r in reward if r == r)
+                                      and not all(g.reanalyzed for g in game)) else "do not save"
+                if did_better is None and verbose:
+                    print("save model with : ", reward[-1], " reward")
+                muzero_model.save_model(directory=model_directory, tag=model_tag_number, model_update_or_backtrack=did_better)
+                for _ in range(number_of_training_before_self_play):
+                    new_priority, batch_game_position = muzero_model.train(replay_buffer.sample_batch())
+                    replay_buffer.update_value(new_priority, batch_game_position)
+                    cache_loss.append(muzero_model.store_loss[-1][0])
+            else:
+                reward.append(float("nan"))       # an actor rank neither stores games, nor saves, nor trains
+            if broadcast is not None and not (pipelined and number_of_training_before_self_play == 0):
+                broadcast(muzero_model)           # the new weights reach the actors (self_play.py:285-288 -> next :249-256)
+            loss.append(sum(cache_loss) / len(cache_loss) if cache_loss else float("nan"))   # (the reference divides by 0 here)
+            epoch_pr.append(f"EPOCH {ep} || selfplay reward: {reward[-1]} || training loss: {loss[-1]}||")
+            if verbose and learner:
+                print(epoch_pr[-1], end="\r")
+    finally:
+        if piped is not None:                 # also when save_model / train / the generator raised: the job in flight gives its
+            piped.close()                     # staging buffers back
     configuration = {"number_of_iteration": number_of_iteration,
                      "number_of_self_play_before_training": number_of_self_play_before_training,
                      "number_of_training_before_self_play": number_of_training_before_self_play,
                      "model_tag_number": model_tag_number, "number_of_worker_selfplay": number_of_worker_selfplay,
                      "temperature_type": temperature_type, "verbose": verbose}
-    if piped is not None:
-        piped.close()
     return epoch_pr, loss, reward, configuration

@@ -451,7 +451,7 @@ def test_vision_family_heads_on_gpu_match_the_reference_tape(backend):
     """a22: the reference's ResNet-v2 family on the GPU -- the hand-written HIP kernels (HipVisionHeads:
     smz_vision_initial / smz_vision_recurrent) and the torch-ROCm module path (ModuleHeads) -- vs every network call the
     reference (torch CPU) recorded in vision_sims50.npz.  Accumulation orders differ from ATen's CPU kernels; tolerances
-    follow the measured errors (profiles/r02_head_errors.json; round 3: 1.2e-5): 2e-5 on hidden planes, 1e-6 on policies, 3e-5 relative
+    follow the measured errors (profiles/archive/r02_head_errors.json; round 3: 1.2e-5): 2e-5 on hidden planes, 1e-6 on policies, 3e-5 relative
     + 2e-4 absolute on decoded scalars (inverse-transform cancellation)."""
     _, model_mod, _, _ = _mods()
     cfg, data = gu.load("vision_sims50")

@@ -106,6 +106,29 @@ def test_workers_never_import_torch_and_exit_with_their_parent_object():
         assert not os.path.exists(f"/proc/{pid}") or open(f"/proc/{pid}/stat").read().split()[2] == "Z"
 
 
+def test_sixty_four_workers_get_a_control_region_that_holds_their_done_words():
+    """the per-worker done words (one 64-byte line each) outgrew the single 4 KB control page at 61 workers; the
+    region is now sized from the worker count, and 64 workers (the bench / CLI default ceiling) step like the serial adapter."""
+    envs_mod, he = _envs(), _he()
+    assert he.ctrl_bytes(1) == 4096 and he.ctrl_bytes(60) == 4096 and he.ctrl_bytes(61) == 8192 and he.ctrl_bytes(64) == 8192 and he.ctrl_bytes(128) == 12288
+    for w in (1, 60, 61, 64, 128, 500):
+        assert 4 * he.done_word(w - 1) + 4 <= he.ctrl_bytes(w)
+        assert he.block_layout(8, 4, np.float32, w)["action"] == he.ctrl_bytes(w)
+    B = 130
+    res = []
+    for workers in (0, 64):
+        env = envs_mod.HostVecEnv([he.HostCartPole for _ in range(B)], 4, 2, "cpu", env_seed=3, limit=6, workers=workers)
+        try:
+            assert len(env._procs) == workers
+            res.append(_run(env, 8, 9))
+        finally:
+            env.close()
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        for x, y in zip(a, b):
+            assert (x is None and y is None) or torch.equal(x, y)
+
+
 def test_tap_index_is_atens_source_index_rule():
     he = _he()
     for n_in, n_out in ((400, 98), (600, 98), (210, 98), (160, 98), (97, 98), (133, 98), (98, 98), (7, 3)):

@@ -303,6 +303,23 @@ def test_reward_sums_are_pythons_sums_game_by_game_even_with_non_finite_rewards(
     assert sp._reward_sums(got)[0] == sum(got[0].rewards)
 
 
+def test_whole_chunk_reward_sums_accumulate_in_float64_like_pythons_sum():
+    """the fast path for one whole-chunk game per env scanned the float32 reward column in float32; sum(g.rewards)
+    adds Python floats.  Non-integer rewards make the two differ in the 7th digit -- and learning_cycle's save-model decision
+    compares reward means for equality."""
+    sp = _sp()
+    T, B = 40, 6
+    d = make_chunk(T, B, 4, 3, seed=5, p_end=0.0)
+    d[..., 4] = np.random.RandomState(1).rand(T, B).astype(np.float32)    # float32-representable, non-integer
+    want, got = build(d, 4, 3, after_end="drop", keep_partial=True)
+    assert len(got) == B and all(len(g.rewards) == T for g in want)      # the whole-chunk shape: the fast path's condition
+    fast = sp._reward_sums(got)
+    slow = [sum(g.rewards) for g in want]
+    assert fast == slow
+    f32 = np.cumsum(d[..., 4].astype(np.float32).T, axis=1)[:, -1].astype(np.float64).tolist()
+    assert f32 != slow                                                    # (the case does tell the two accumulations apart)
+
+
 def test_make_priority_returns_an_array_the_caller_may_overwrite():
     """ReplayBuffer.update_value writes prio_position[game][h] in place (replay_buffer.py:222); the array a record
     hands out must not be a view of the chunk-wide priorities."""
