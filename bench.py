@@ -120,6 +120,47 @@ def find_traffic(workload, kernel):
                   (kernel, workload, sha, "; stale: " + ", ".join(seen[:3]) if seen else ""))
 
 
+def find_pmc(workload, kernel):
+    """The committed SQ counter file (profiles/*pmc_k_search*.json: tools/pmc_search.sh, separate --pmc passes) of exactly this
+    kernel instantiation, workload and kernel sources -- or (None, why not).  Same rule as find_traffic."""
+    import glob
+    sha = kernel_source_sha16()
+    seen = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_k_search*.json")), reverse=True):
+        try:
+            pj = json.load(open(f))
+        except Exception:
+            continue
+        if pj.get("workload") != workload or pj.get("kernel") != kernel or "per_launch_mean" not in pj:
+            continue
+        if pj.get("source_sha16") != sha:
+            seen.append(os.path.basename(f))
+            continue
+        return pj, os.path.basename(f)
+    return None, ("no SQ counter file for kernel %s on workload %s with the current kernel sources (sha %s)%s" %
+                  (kernel, workload, sha, "; stale: " + ", ".join(seen[:3]) if seen else ""))
+
+
+def valu_issue_bound(pj, fname, sims):
+    """VERDICT r5 next #4a: the hardware-anchored bound that applies to the single-launch MLP search -- vector-instruction issue.
+    From the SQ counters of the committed pass: a wavefront has a VALU instruction executing during ACTIVE_INST_VALU / WAVE_CYCLES
+    of its life; with w wavefronts per SIMD (SQ_WAVES / 1024 SIMDs) the SIMD's vector unit is busy w times that; lanes enabled =
+    THREAD_CYCLES_VALU / (64 x ACTIVE_INST_VALU)."""
+    c = pj["per_launch_mean"]
+    waves_per_simd = c["SQ_WAVES"] / 1024.0
+    per_wave = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
+    busy = per_wave * waves_per_simd
+    return {"bound": "valu_issue", "unit": "fraction of SIMD cycles with a vector instruction executing", "achieved": busy, "peak": 1.0,
+            "frac": busy, "per_wave_frac": per_wave, "waves_per_simd": waves_per_simd,
+            "lanes_enabled": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
+            "valu_insts_per_wave_round": c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / max(1, sims),
+            "wait_any_frac": c.get("SQ_WAIT_ANY", float("nan")) / c["SQ_WAVE_CYCLES"],
+            "source": fname,
+            "note": "SQ counters of a committed rocprofv3 --pmc pass on this kernel instantiation, workload and kernel sources; the "
+                    "launch is a dependent chain per wavefront whose vector unit is this busy -- the headroom a perfect overlap of "
+                    "the two wavefronts per SIMD could still claim is 1 - frac"}
+
+
 def algorithmic_bytes(stats, A, K, S, launches):
     """bytes per simulation per tree for select (K2) and expand+backup (K5), evaluated on the
     measured level histogram.  Returns (k2, k5) in bytes per tree per simulation."""
@@ -354,6 +395,12 @@ def main():
                     help="process-group timeout: a collective that hangs ends as an error instead of stalling the run")
     ap.add_argument("--frame-upload", default="taps", choices=["taps", "frames"],
                     help="--host-env on the vision workload: upload only the pixels the 98x98 resize reads (taps) or whole frames")
+    ap.add_argument("--also-seconds", type=float, default=2.0,
+                    help="headline run only (N = 1, default workload): after the headline's timed region, each of the other single-GPU "
+                         "BASELINE configs -- lunarlander_mlp_4096x50 (configs[2]), its K = 4 stress variant, cartpole_mlp_4096x100 "
+                         "(configs[4]'s per-rank shard) and vision_resnet_1024x50 (configs[3]) -- is timed for this long with the same "
+                         "block rule and appended under the `also` key (value, ms_per_step, kernel, roofline fraction); 0 = off.  The "
+                         "headline fields are not touched")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 64 if args.end_to_end else 16
@@ -813,6 +860,7 @@ def main():
                 torch.cuda.synchronize(dev)
                 chain_us = float(np.mean([a.elapsed_time(b) for a, b in hd[1:]]) / PER_PAIR * 1e3)
                 bound_actual = {"kind": "latency: dependent chain of one wavefront's simulation rounds",
+                                "label": "self-relative (the kernel timed against itself at half occupancy), not a roofline",
                                 "chain_us": chain_us, "launch_us": mean_us, "frac": chain_us / mean_us,
                                 "how": f"{eng_h.last_kernel()} on {Bh} trees in 4-wave workgroups (one wavefront per SIMD, same "
                                        "trees per wavefront): its launch time is the chain; the production launch runs two "
@@ -823,6 +871,7 @@ def main():
         elif single and wl["env"] == "image":
             # k_search_vision runs ONE wavefront per SIMD (4 trees per CU at 1024 trees): the launch is its own dependent chain
             bound_actual = {"kind": "latency: dependent chain of one wavefront's simulation rounds (one wavefront per SIMD)",
+                            "label": "self-relative (the launch is its own chain), not a roofline",
                             "chain_us": mean_us, "launch_us": mean_us, "frac": 1.0,
                             "how": "1024 trees = 4 per CU = one 4-wave workgroup per CU: nothing overlaps a wavefront's own chain"}
         # HBM bytes per launch from the TCC counters, when a PMC pass of this workload/kernel has been committed
@@ -839,7 +888,10 @@ def main():
                                 "; read side may be under-counted up to 2x on gfx950 (upper bound %.0f)" % tj["hbm_bytes_per_launch_read_x2"])
             else:
                 traffic_note = tname
-        compute = None
+        compute, compute_mlp = None, None
+        if single and wl["env"] != "image" and Bg == wl["envs"] and not os.environ.get("SMZ_LIB_PATH"):
+            pj, pname = find_pmc(args.workload + ("" if args.rng == "mt19937" else "+philox"), launched)
+            compute_mlp = valu_issue_bound(pj, pname, wl["sims"]) if pj is not None else {"bound": "valu_issue", "frac": None, "note": pname}
         if single and wl["env"] == "image":
             # f32 multiply-adds of one leaf evaluation (neural_network_vision_model.py:41-515 at 3x7x7): 3x3 convolutions (49 pixels,
             # 3 output channels), 1x1 mixes, the 147 -> H -> [H ->] S / A towers; dynamics leaves also evaluate the reward tower
@@ -857,7 +909,7 @@ def main():
                                "time against the 157.3 TFLOP/s f32 vector peak (MI355X_MICROARCH.md); the launch is latency-bound "
                                "(bound_actual), neither figure is a ceiling it approaches"}
         out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "bound_actual": bound_actual, "compute": compute,
+                           "bound_actual": bound_actual, "compute": compute if compute is not None else compute_mlp,
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                            "kernel_launched": launched or None, "kernel_source_sha16": kernel_source_sha16(),
                            "bytes_per_launch": bytes_launch,
@@ -873,7 +925,7 @@ def main():
                                      "around 4 back-to-back launches of the search kernel alone (elapsed / 4), around each "
                                      "launch for the step-wise tree kernel; bytes = SURVEY 8d formula on this run's level "
                                      "histogram"}
-    if rank == 0 and out.get("roofline", {}).get("compute"):
+    if rank == 0 and wl["env"] == "image" and out.get("roofline", {}).get("compute"):
         # vision family: the leaf networks are arithmetic, not byte movement -- the headline fraction is the f32 one; the
         # bytes-based figures (SURVEY 8d formula) stay beside it
         r = out["roofline"]
@@ -883,6 +935,84 @@ def main():
                  flops_per_launch=c["flops_per_launch"], macs_per_leaf=c["macs_per_leaf"], compute_note=c["note"])
     if cpu_baseline is not None:                                                            # N=1 only (contract)
         out["cpu_baseline"] = cpu_baseline
+
+    def also_line(name, seconds, steps=16):
+        """One of the other single-GPU BASELINE configs, timed like the headline (blocks of `steps` env steps between
+        synchronisations, median block) for ~`seconds`, + the dominant kernel's launch time and algorithmic-bytes fraction."""
+        w = dict(WORKLOADS[name])
+        Bw = w["envs"]
+        wp = os.path.join(ROOT, "tests", "golden", w["weights"])
+        mdl = model_mod.Muzero.from_state_dicts(wp) if w["env"] == "image" else model_mod.Muzero.from_arrays(wp)
+        if w["env"] == "cartpole":
+            e_ = envs_mod.CartPoleVec(Bw, dev, seed=0, first_env=0, total_envs=Bw)
+        elif w["env"] == "image":
+            e_ = envs_mod.ImageVec(Bw, w["A"], dev, seed=0, first_env=0, total_envs=Bw)
+        else:
+            e_ = envs_mod.SyntheticVec(Bw, w["obs"], w["A"], dev, seed=0, first_env=0, total_envs=Bw)
+        m_ = mcts_mod.BatchedMCTS(Bw, num_simulations=w["sims"], maxium_action_sample=w["K"], discount=0.999,
+                                  root_dirichlet_alpha=0.25, root_exploration_fraction=0.1, device=local_rank,
+                                  use_graph=True, fused=True, single_launch=True)
+        m_.seed(np.arange(Bw, dtype=np.uint64))
+        e_.reset()
+        h_ = mdl.heads(dev, instance=7, backend="auto")
+        g_ = [sp.StreamGroup(e_, h_, m_, steps)]
+        sp.play_games_grouped(g_, args.temperature, 3)
+        torch.cuda.synchronize(dev)
+        bl, t_end = [], time.perf_counter() + seconds
+        while not bl or (time.perf_counter() < t_end and len(bl) < args.max_blocks):
+            torch.cuda.synchronize(dev)
+            t0_ = time.perf_counter()
+            sp.play_games_grouped(g_, args.temperature, steps)
+            torch.cuda.synchronize(dev)
+            bl.append(time.perf_counter() - t0_)
+        d_ = float(np.median(bl))
+        line = {"workload": name, "value": Bw * w["sims"] * steps / d_, "unit": "simulations/s", "ms_per_step": 1e3 * d_ / steps,
+                "steps": steps, "blocks": len(bl), "timed_region_s": float(np.sum(bl)), "envs": Bw, "num_simulations": w["sims"],
+                "actions": w["A"], "children_per_expansion": w["K"]}
+        eng_ = m_.engine
+        if getattr(m_, "_single", None) is True:
+            eng_.enable_stats(True)
+            eng_.read_stats(reset=True)
+            m_.run(e_.obs, h_, train=True)
+            torch.cuda.synchronize(dev)
+            st_ = eng_.read_stats(reset=True)
+            eng_.enable_stats(False)
+            k2_, k5_, _ = algorithmic_bytes(st_, eng_.A, eng_.K, eng_.S, w["sims"])
+            if w["env"] == "image":
+                hid_, pol_ = h_.initial(e_.obs)
+                go = lambda: eng_.search_vision(h_.desc, h_.weights, hid_, pol_, train=True, act_temperature=args.temperature)   # noqa: E731
+            else:
+                go = lambda: eng_.search_mlp(h_.desc, h_.weights, e_.obs, train=True, act_temperature=args.temperature)        # noqa: E731
+            ev = []
+            for _ in range(5):
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(2_000_000)
+                a_.record()
+                for _k in range(4):
+                    go()
+                b_.record()
+                ev.append((a_, b_))
+            torch.cuda.synchronize(dev)
+            us_ = float(np.mean([x.elapsed_time(y) for x, y in ev[1:]]) / 4 * 1e3)
+            by_ = (k2_ + k5_) * Bw * w["sims"]
+            line.update(kernel=eng_.last_kernel(), kernel_mean_launch_us=us_, bytes_per_launch=by_,
+                        frac=by_ / (us_ * 1e-6) / 1e9 / HBM_PEAK_GBS, frac_of="HBM peak 8 TB/s, algorithmic bytes (SURVEY 8d) / launch time")
+        else:
+            line.update(kernel="step-wise kernels", frac=None)
+        if hasattr(e_, "close"):
+            e_.close()
+        torch.cuda.synchronize(dev)
+        del g_
+        eng_.close()
+        return line
+
+    if rank == 0 and headline and world == 1 and args.also_seconds > 0 and not args.stepwise and not os.environ.get("SMZ_LIB_PATH_NO_ALSO"):
+        out["also"] = []
+        for name in ("lunarlander_mlp_4096x50", "lunarlander_mlp_4096x50_K4", "cartpole_mlp_4096x100", "vision_resnet_1024x50"):
+            try:
+                out["also"].append(also_line(name, args.also_seconds))
+            except Exception as e:                                     # noqa: BLE001  (the headline line must not die with an extra)
+                out["also"].append({"workload": name, "error": f"{type(e).__name__}: {e}"})
     for g in groups:
         if hasattr(g.env, "close"):
             g.env.close()                                  # host envs: the worker processes exit

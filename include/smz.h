@@ -499,6 +499,12 @@ int smz_debug_dump_tree(smz_handle *h, int tree, smz_node_view *nodes, int cap, 
  * For tests: the results must equal the IEEE quotients bit for bit. */
 int smz_debug_div_by_count(const double *x_dev, const int32_t *n_dev, int count, int table_size, double *out_dev,
                            smz_stream stream);
+/* Element-wise out_log = log(x), out_pow = pow(x, y) as the device computes them inside the Dirichlet root noise: glibc's own
+ * routines restated operation by operation (csrc/smz_glibc_math.hpp; numpy's legacy gamma sampler calls libm's, the reference
+ * draws its noise with it: monte_carlo_tree_search.py:220).  Either output may be NULL (y_dev may then be NULL too for pow).
+ * pow's domain: x >= 0, y > 0 finite; NaN outside.  For tests: the results must equal the host libm's bit for bit. */
+int smz_debug_glibc_log_pow(const double *x_dev, const double *y_dev, int count, double *out_log_dev, double *out_pow_dev,
+                            smz_stream stream);
 /* Per-level counters accumulated by smz_select since the last reset (device-side atomics, off by default):
  * levels_out[0] = decision levels, [1] = chance levels, [2] = descents, [3] = children scored.  [sync] */
 int smz_enable_stats(smz_handle *h, int on);

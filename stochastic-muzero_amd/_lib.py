@@ -120,6 +120,7 @@ SIGNATURES = {
     "smz_traj_targets": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
     "smz_traj_targets_games": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "smz_debug_div_by_count": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "smz_debug_glibc_log_pow": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "smz_debug_dump_tree": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int32), _P]),
     "smz_enable_stats": (C.c_int, [_P, C.c_int]),
     "smz_read_stats": (C.c_int, [_P, _P, C.c_int]),

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "smz_glibc_math.hpp"
+
 namespace smz {
 
 constexpr int kMtN = 624;
@@ -382,21 +384,29 @@ __device__ inline void sort_picks(int32_t (&v)[MAXA], int size) {
     }
 }
 
-// legacy_standard_gamma for shape <= 1 (numpy/random/src/legacy/legacy-distributions.c); log/pow are the device
-// library's (correct to < 1 ulp, not guaranteed bit-identical to glibc's -- see DESIGN.md "Dirichlet noise").
+// legacy_standard_gamma for shape <= 1 (numpy/random/src/legacy/legacy-distributions.c).  log / pow are glibc's own routines,
+// restated operation by operation (smz_glibc_math.hpp): the sample -- and with it the float64 root priors -- is numpy's bit for
+// bit (rounds 1-5 used the device library's, correct to < 1 ulp but not glibc's roundings: priors within 1e-13 only).
+#ifndef SMZ_DEVICE_LIBM
+#define SMZ_DEVICE_LIBM 0        // 1: the device library's log / pow as in rounds 1-5 (A/B builds only: priors to 1e-13)
+#endif
+#if SMZ_DEVICE_LIBM
+#define smz_glibc_log log
+#define smz_glibc_pow pow
+#endif
 template <class RNG>
 __device__ inline double legacy_gamma(RNG &rng, double shape) {
-    if (shape == 1.0) return -log(1.0 - rng.random_sample());
+    if (shape == 1.0) return -smz_glibc_log(1.0 - rng.random_sample());
     if (shape == 0.0) return 0.0;
     for (;;) {
         const double U = rng.random_sample();
-        const double V = -log(1.0 - rng.random_sample());
+        const double V = -smz_glibc_log(1.0 - rng.random_sample());
         if (U <= 1.0 - shape) {
-            const double X = pow(U, 1.0 / shape);
+            const double X = smz_glibc_pow(U, 1.0 / shape);
             if (X <= V) return X;
         } else {
-            const double Y = -log((1.0 - U) / shape);
-            const double X = pow(1.0 - shape + shape * Y, 1.0 / shape);
+            const double Y = -smz_glibc_log((1.0 - U) / shape);
+            const double X = smz_glibc_pow(1.0 - shape + shape * Y, 1.0 / shape);
             if (X <= (V + Y)) return X;
         }
     }
@@ -1148,7 +1158,7 @@ __device__ inline void act_tree(const Params &P, int tree, RNG &rng, double temp
     for (int a = 0; a < A; a++) pol[a] = from_visits ? vis[a] : pri[a];
     if (temperature >= 0.3) {
         for (int a = 0; a < A; a++)
-            pol[a] = (from_visits && P.pow_table) ? P.pow_table[vc[a]] : pow(pol[a], 1.0 / temperature);
+            pol[a] = (from_visits && P.pow_table) ? P.pow_table[vc[a]] : smz_glibc_pow(pol[a], 1.0 / temperature);   // (numpy's ** = libm's pow)
     }
     const double ps = np_sum<double, MAXA>(pol, A);
     for (int a = 0; a < A; a++) pol[a] = pol[a] / ps;

@@ -1501,6 +1501,15 @@ __global__ void __launch_bounds__(256) k_debug_div_by_count(const double *x, con
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
         out[i] = div_by_count(x[i], n[i], smz_dyn_lds);
 }
+
+// glibc's log / pow as the device restates them (smz_glibc_math.hpp), element-wise (inspection: tests compare with the host's libm)
+__global__ void __launch_bounds__(256) k_debug_glibc_log_pow(const double *x, const double *y, int count, double *out_log,
+                                                             double *out_pow) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        if (out_log) out_log[i] = smz_glibc_log(x[i]);
+        if (out_pow) out_pow[i] = smz_glibc_pow(x[i], y[i]);
+    }
+}
 #endif
 
 }  // namespace
@@ -2400,6 +2409,15 @@ int smz_debug_div_by_count(const double *x_dev, const int32_t *n_dev, int count,
         return fail(SMZ_ERR_INVALID, "smz_debug_div_by_count: bad argument%s");
     hipLaunchKernelGGL(k_debug_div_by_count, dim3(256), dim3(256), (size_t)table_size * sizeof(double), (hipStream_t)stream,
                        x_dev, n_dev, count, table_size, out_dev);
+    return launch_check();
+}
+
+int smz_debug_glibc_log_pow(const double *x_dev, const double *y_dev, int count, double *out_log_dev, double *out_pow_dev,
+                            smz_stream stream) {
+    if (!x_dev || count < 1 || (!out_log_dev && !out_pow_dev) || (out_pow_dev && !y_dev))
+        return fail(SMZ_ERR_INVALID, "smz_debug_glibc_log_pow: bad argument%s");
+    hipLaunchKernelGGL(k_debug_glibc_log_pow, dim3(1024), dim3(256), 0, (hipStream_t)stream, x_dev, y_dev, count, out_log_dev,
+                       out_pow_dev);
     return launch_check();
 }
 

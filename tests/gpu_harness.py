@@ -65,10 +65,9 @@ def check_fixture_outputs(eng, cfg, data, prior_exact):
     visits, priors, rv, _ = eng.root_stats()
     torch.cuda.synchronize()
     assert np.array_equal(visits.cpu().numpy(), data["root_visits"])
-    if prior_exact:
-        assert np.array_equal(priors.cpu().numpy(), data["root_priors"])
-    else:
-        np.testing.assert_allclose(priors.cpu().numpy(), data["root_priors"], rtol=1e-13, atol=0)
+    # prior_exact=False: the device DREW the Dirichlet noise itself; =True: the reference's sample was injected.  Both are held
+    # bit for bit since round 6 (glibc's log / pow restated on the device, csrc/smz_glibc_math.hpp; rounds 1-5: 1e-13 relative)
+    assert np.array_equal(priors.cpu().numpy(), data["root_priors"]), ("device-drawn noise" if not prior_exact else "injected noise")
     assert np.array_equal(rv.cpu().numpy(), data["root_value"])
     n = 1 + A + sims * K
     for i in range(B):

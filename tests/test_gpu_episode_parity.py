@@ -137,7 +137,7 @@ def test_every_tree_of_every_step_of_the_timed_loop_equals_the_oracle(on_end, B,
         action, policy, child_visits, root_value = (x.cpu().numpy().copy() for x in (eng.action, eng.policy, eng.child_visits, eng.root_value))
         oa = [tr.act(temperature) for tr in live_trees]       # draws where game.py:213 draws: the stream goes on
         twin.act(temperature)                                 # ... and so does the twin's
-        n_exact += assert_engine_equals_oracle(_Sub(eng, idx), live_trees, sims, prior_rtol=1e-13)
+        n_exact += assert_engine_equals_oracle(_Sub(eng, idx), live_trees, sims, prior_rtol=0)
         assert_engine_equals_oracle(_Sub(twin, idx), live_trees, sims, prior_rtol=0)       # (stream position after the draw)
         assert np.array_equal(action[idx], np.array([a[0] for a in oa], np.int32))
         assert np.array_equal(policy[idx], np.stack([a[1] for a in oa]))

@@ -122,3 +122,35 @@ def test_bench_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=bad, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("launcher", ["bench", "torchrun"])
+def test_the_drivers_eight_rank_command_yields_one_eight_rank_line(launcher):
+    """Scale-run readiness (no 8-GPU node has seen this code): the driver's command SHAPE for the scaling
+    bench -- `python bench.py --gpus 8 --steps K --warmup W`, and the same under `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...` -- on the test box (the eight ranks share
+    its GPU, so the exchange goes through gloo and the line says so).  One JSON line on stdout, eight ranks seen by the collective
+    itself, eight per-rank rates, weak scaling, no cpu_baseline (N = 1 only), no `also` blocks.  The launcher starts the ranks as
+    fresh children before anything has touched the GPU (never an exec from a process that has)."""
+    import socket
+    tail = ["--gpus", "8", "--steps", "2", "--warmup", "1", "--envs", "256", "--min-timed-seconds", "0.05"]
+    if launcher == "bench":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + tail
+    r = subprocess.run(cmd, env=dict(_env(), OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["ranks"] == 8 and out["config"]["ranks_seen_by_collective"] == 8
+    assert len(out["per_rank_simulations_per_s"]) == 8 and all(v > 0 for v in out["per_rank_simulations_per_s"])
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 2 and out["warmup"] == 1
+    assert "cpu_baseline" not in out and "also" not in out
+    assert out["unit"] == "simulations/s" and out["higher_is_better"] is True and out["vs_baseline"] is None
+    assert out["config"]["envs_per_gpu"] == 256 and "x8" in out["config"]["parallelism"]
+    assert out["timing"]["gather_overlap"]["mode"]["kind"] == "plain" and out["timing"]["gather_ms_median"] > 0

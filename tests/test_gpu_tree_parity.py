@@ -98,7 +98,7 @@ def test_whole_game_single_tree(name):
         action, policy, child_visits, root_value = eng.act(T)
         torch.cuda.synchronize()
         assert np.array_equal(visits.cpu().numpy()[0], data["root_visits"][i])
-        np.testing.assert_allclose(priors.cpu().numpy()[0], data["root_priors"][i], rtol=1e-13)
+        assert np.array_equal(priors.cpu().numpy()[0], data["root_priors"][i])      # device-drawn noise, bit for bit
         assert int(action[0]) == data["game_actions"][i]
         assert np.array_equal(policy.cpu().numpy()[0], data["game_policies"][i])
         assert np.array_equal(child_visits.cpu().numpy()[0], data["game_child_visits"][i])
