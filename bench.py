@@ -358,9 +358,11 @@ def main():
                     help="time selfplay.self_play_iteration, the function learning_cycle calls (self_play.py:245-271): K env steps, the "
                          "chunk's transfer to the host, Game records (selfplay.chunk_to_records) and replay_buffer.save_game of every "
                          "game into a sink that does ReplayBuffer.save_game's per-game work -- its own labelled line, never the headline")
-    ap.add_argument("--rng", default="mt19937", choices=["mt19937", "philox"],
+    ap.add_argument("--rng", default="auto", choices=["auto", "mt19937", "philox"],
                     help="mt19937: per-tree numpy-legacy streams (parity mode, the headline); philox: counter-based "
-                         "streams (throughput mode: same distributions, different numbers) -- reported as its own workload")
+                         "streams (throughput mode: same distributions, different numbers) -- reported as its own workload; "
+                         "auto (default): mt19937 up to the single-launch crossover (17 408 envs per GPU: every BASELINE config), "
+                         "philox above it, where the step-wise tree kernel is bandwidth-bound (VERDICT r5 next #1c)")
     ap.add_argument("--host-env", nargs="?", const="python", default=None, choices=["python", "native"],
                     help="cartpole workloads: step the envs on the HOST -- the PCIe-inclusive rate of the boundary's "
                          "host-buffer variant: 'python' = envs.HostVecEnv over Python CartPoles (measures the Python), 'native' = "
@@ -461,6 +463,8 @@ def main():
 
     wl = dict(WORKLOADS[args.workload])
     B = args.envs or wl["envs"]
+    if args.rng == "auto":
+        args.rng = "philox" if mcts_mod.resolve_rng_mode("auto", B) == smz._lib.RNG_PHILOX else "mt19937"
     wpath = os.path.join(ROOT, "tests", "golden", wl["weights"])
     if wl["env"] == "image":
         model = model_mod.Muzero.from_state_dicts(wpath)

@@ -20,6 +20,12 @@
 #ifndef SMZ_EB_WAVES
 #define SMZ_EB_WAVES 4   // waves per SIMD the step-wise tree kernels are register-allocated for
 #endif
+#ifndef SMZ_PAIR_K4
+#define SMZ_PAIR_K4 1              // KS = 4: the paired descent on every decision level (0: one lane scores all four children)
+#endif
+#ifndef SMZ_KS4
+#define SMZ_KS4 1                  // the compile-time K = 4 instantiation for the A = 4 bucket (0: run-time K as in round 5)
+#endif
 #ifndef SMZ_PART
 #define SMZ_PART 0
 #endif
@@ -930,7 +936,9 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
         SMZ_PROBE_B(1)
         // Specialised two-action kernel: the descent runs on lanes 0..3 -- lane t and its helper t + 2 score one child
         // each (pick_decision_pair).  The helper works on a copy of the tree lane's stream position and MinMax bounds.
-        constexpr bool PAIR = AEX && (MAXA == 2 || (SMZ_PAIR_A4 && MAXA == 4)) && KS == 2 && !INSTR;
+        // (round 6: also four children per block on a four-action tree -- KS = 4: the pair splits EVERY decision level two and
+        //  two, pick_decision_pair<Kids<4>>, as it does the root)
+        constexpr bool PAIR = AEX && (MAXA == 2 || (SMZ_PAIR_A4 && MAXA == 4)) && (KS == 2 || (SMZ_PAIR_K4 && KS == 4 && MAXA == 4)) && !INSTR;
         // Trees in LDS: block-parallel selection (smz_device.hpp, select_block / select_chase) -- every block of the wave's two
         // trees gets a lane that computes the block's pick from the words its level will read, then the tree's lane follows the
         // picks.  SMZ_SELECT_BLOCKS=0 (-DSMZ_SELECT_BLOCKS=0 builds) keeps the level-by-level descent.
@@ -2125,6 +2133,33 @@ int SMZ_SEARCH_LAUNCH(smz_handle *h, const smz_mlp_desc *desc, const float *weig
         hipLaunchKernelGGL((k_search_mlp<MA, KS, 1, true, true>), dim3(blocks), dim3(kWaves * kWave), lds, (hipStream_t)stream,
                            P, *desc, weights_dev, obs_dev, train, act, a.env);
         snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<2, 2, 1, true, true, true, false, false>");
+    } else
+#endif
+#if (SMZ_PART == 0 || SMZ_PART == 2) && SMZ_KS4
+    // Four children per expansion on a four-action tree (SURVEY 8d(3)'s stress shape; round 6): the child count is a compile-time
+    // constant (KS = 4: load_kids_static<4>, unrolled scoring, the paired descent on every level) instead of the run-time-K
+    // instantiation (KS = 0) -- 347 -> 409 M simulations/s on the K = 4 stress workload, profiles/r06_c_ab_noks4.txt.
+    // Plain, masked (smz_set_active) and Philox handles.
+    if (fast && !(P.stats || P.dbg) && h->maxa == 4 && h->K == 4) {
+#define SMZ_LAUNCH_KS4(MSK, PHX)                                                                                       \
+        {                                                                                                              \
+            static size_t granted_dev[64] = {};                                                                        \
+            size_t &granted = granted_dev[h->cfg.device & 63];                                                         \
+            if (lds > granted) {                                                                                       \
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_mlp<4, 4, 1, false, true, MSK, PHX>),  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)           \
+                    return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                        \
+                granted = lds;                                                                                         \
+            }                                                                                                          \
+            hipLaunchKernelGGL((k_search_mlp<4, 4, 1, false, true, MSK, PHX>), dim3(blocks), dim3(kWaves * kWave), lds, \
+                               (hipStream_t)stream, P, *desc, weights_dev, obs_dev, train, act, a.env);                \
+            snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_mlp<4, 4, 1, false, true, %s, %s, false>",      \
+                     MSK ? "true" : "false", PHX ? "true" : "false");                                                  \
+        }
+        if (P.philox) SMZ_LAUNCH_KS4(true, true)
+        else if (P.active) SMZ_LAUNCH_KS4(true, false)
+        else SMZ_LAUNCH_KS4(false, false)
+#undef SMZ_LAUNCH_KS4
     } else
 #endif
     if (P.stats || P.dbg) { SMZ_LAUNCH_SEARCH(1, true, false, true, false); }

@@ -78,6 +78,17 @@ class _Hyper:
                     root_exploration_fraction=self.root_exploration_fraction)
 
 
+SINGLE_LAUNCH_MAX_TREES = 17408      # where the step-wise kernels overtake the single launch (tools/crossover.sh)
+
+
+def resolve_rng_mode(rng_mode, num_trees):
+    if isinstance(rng_mode, str):
+        if rng_mode == "auto":
+            return _lib.RNG_PHILOX if int(num_trees) > SINGLE_LAUNCH_MAX_TREES else _lib.RNG_MT19937_NUMPY
+        return {"mt19937": _lib.RNG_MT19937_NUMPY, "philox": _lib.RNG_PHILOX}[rng_mode]
+    return int(rng_mode)
+
+
 class BatchedMCTS(_Hyper):
     def __init__(self, num_trees, pb_c_base=19652, pb_c_init=1.25, discount=0.95, root_dirichlet_alpha=0.25,
                  root_exploration_fraction=0.25, num_simulations=10, maxium_action_sample=2, number_of_player=1,
@@ -87,7 +98,13 @@ class BatchedMCTS(_Hyper):
                         num_simulations, maxium_action_sample, number_of_player, custom_loop)
         self.num_trees = int(num_trees)
         self.device = device
-        self.rng_mode = int(rng_mode)       # RNG_MT19937_NUMPY: the reference's draws (parity); RNG_PHILOX: throughput mode
+        # RNG_MT19937_NUMPY (default): the reference's draws, tree i == np.random.seed(seed_i) (parity mode); RNG_PHILOX: counter
+        # streams (throughput mode: same numpy-legacy distributions, different numbers); "auto" (what bench.py passes): parity
+        # mode up to the single-launch crossover, Philox above it, where the step-wise tree kernel is bandwidth-bound and a
+        # 2.5 KB MT19937 state per tree is 28 % of its traffic (+14 % whole job at 262 144 trees, profiles/r05_l_philox_large.txt).
+        # NOT the constructor's default: the mode then depends on the tree count, so the same envs sharded over more ranks
+        # would draw other numbers (shard invariance, tests/test_gpu_multirank.py, holds within one mode)
+        self.rng_mode = resolve_rng_mode(rng_mode, self.num_trees)
         self.use_graph, self.fused, self.single_launch = bool(use_graph), bool(fused), bool(single_launch)
         self.engine = None
         self._graph = None
@@ -97,7 +114,7 @@ class BatchedMCTS(_Hyper):
         # beyond ~17 k trees the step-wise kernels (64 trees per wavefront, networks as 16-leaf tiles on the matrix cores, rows
         # left in the tree) overtake the single launch: measured on one box (tools/crossover.sh) 440 vs 424 M simulations/s at
         # 16 384 trees, 436 vs 505 at 20 480, 427 vs 586 at 24 576
-        self.single_launch_max_trees = 17408
+        self.single_launch_max_trees = SINGLE_LAUNCH_MAX_TREES
 
     def _ensure_engine(self, num_actions, hidden_size):
         if self.engine is None or (self.engine.A, self.engine.S) != (num_actions, hidden_size):

@@ -250,6 +250,60 @@ def test_single_launch_search_equals_stepwise_search(wname, B, sims, K):
         assert np.array_equal(ra.random_sample(700), rb.random_sample(700))
 
 
+@pytest.mark.parametrize("mode,B,sims", [("plain", 4096, 50), ("plain", 4095, 31), ("mask", 4096, 30), ("philox", 4096, 30), ("plain", 8192, 20)])
+def test_compile_time_four_children_instantiations_equal_the_stepwise_search(mode, B, sims):
+    """Round 6: k_search_mlp<4, 4, ...> -- four children per expansion block as a compile-time constant, the paired descent on
+    every decision level (pick_decision_pair<Kids<4>>) -- for plain, masked (smz_set_active) and Philox handles, against the
+    step-wise kernels (run-time K, one lane per tree) on the same seeds: visits, float64 priors, values, sampled tree dumps, the
+    action outputs and the stream positions over two consecutive searches, bit for bit.  (The every-tree oracle comparison of
+    the plain instantiation at 4096 x 50: tests/test_gpu_fullsize_parity.py.)"""
+    import stochastic_muzero_amd as smz
+    mcts_mod, model_mod, _, _ = _mods()
+    model = model_mod.Muzero.from_arrays(os.path.join(gu.GOLDEN, "weights_lunar_L0.npz"))
+    heads = model.heads("cuda:0", backend="hip")
+    obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(2)).mul(0.6).cuda()
+    active = torch.ones(B, dtype=torch.uint8, device="cuda")
+    active[torch.arange(B, device="cuda") % 5 == 2] = 0
+    active[192:320] = 0
+    res = []
+    for single in (True, False):
+        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=4, discount=0.997, root_exploration_fraction=0.25,
+                                 use_graph=False, single_launch=single,
+                                 rng_mode=smz._lib.RNG_PHILOX if mode == "philox" else smz._lib.RNG_MT19937_NUMPY)
+        m.seed(np.arange(B, dtype=np.uint64) + 11)
+        if mode == "mask":
+            m.set_active(torch.ones(B, dtype=torch.uint8, device="cuda"))
+        for rep in range(2):
+            if mode == "mask" and rep == 1:
+                m.set_active(active)
+            e = m.run(obs, heads, train=True)
+        if single:
+            want = {"plain": "k_search_mlp<4, 4, 1, false, true, false, false, false>", "mask": "k_search_mlp<4, 4, 1, false, true, true, false, false>",
+                    "philox": "k_search_mlp<4, 4, 1, false, true, true, true, false>"}[mode]
+            assert m._single is True and e.last_kernel() == want, e.last_kernel()
+        visits, priors, rv, cr = e.root_stats()
+        action, policy, cv, _ = e.act(1.0)
+        torch.cuda.synchronize()
+        out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr, action, policy, cv)]
+        picks = (0, 1, 2, 3, 63, 64, 191, 192, 200, 319, 320, B // 2, B - 2, B - 1)
+        rng = [e.philox_position(i) for i in picks] if mode == "philox" else [e.get_rng_state(i) for i in picks]
+        res.append((out, [e.dump_tree(i) for i in picks], rng))
+    live = (active.cpu().numpy() != 0) if mode == "mask" else np.ones(B, bool)
+    assert (res[0][0][0][live].sum(1) == sims).all()
+    for i, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+        # (act() skips a switched-off tree: its rows of the action outputs are whatever the buffers held -- compared for live trees;
+        #  its TREE is the first search's, on both sides)
+        assert np.array_equal(a[live], b[live]) if i >= 4 else np.array_equal(a, b), i
+    for da, db in zip(res[0][1], res[1][1]):
+        for k in da:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+    for x, y in zip(res[0][2], res[1][2]):
+        if mode == "philox":
+            assert x == y
+        else:
+            assert np.array_equal(x[0], y[0]) and x[1] == y[1]
+
+
 def test_block_parallel_selection_on_deep_paths_takes_the_sequential_descent_for_them(tmp_path, monkeypatch):
     """Round 4: with the trees in LDS every block's pick is computed by its own lane from the random words its LEVEL will read
     (fixed offsets behind the stream position: select_words) -- as long as those words lie inside the 64 staged ones.  A path

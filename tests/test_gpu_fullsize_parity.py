@@ -151,6 +151,8 @@ def test_production_search_kernel_equals_oracle_on_every_tree(wname, B, sims, K,
     m.seed(seeds)
     e = m.run(torch.from_numpy(obs).cuda(), heads, train=True, act_temperature=T)
     assert m._single is True and e._act_done == T
+    if K == 4 and B == 4096:                        # round 6: the compile-time K = 4 instantiation serves the stress shape
+        assert e.last_kernel() == "k_search_mlp<4, 4, 1, false, true, false, false, false>", e.last_kernel()
     action, policy, child_visits, root_value = (t.clone() for t in e.act(T))
     torch.cuda.synchronize()
     # the oracle's action selection comes after the tree comparison (it draws from the tree's stream); compare the
@@ -342,6 +344,8 @@ def test_vision_search_kernel_equals_oracle_on_every_tree():
     m.seed(seeds)
     e = m.run(frames, heads, train=True, act_temperature=T)
     assert m._single is True and e._act_done == T
+    if K == 4 and B == 4096:                        # round 6: the compile-time K = 4 instantiation serves the stress shape
+        assert e.last_kernel() == "k_search_mlp<4, 4, 1, false, true, false, false, false>", e.last_kernel()
     action, pol_out, child_visits, root_value = (t.clone() for t in e.act(T))
     torch.cuda.synchronize()
     oa = [trees[i].act(T) for i in range(B)]
