@@ -571,28 +571,6 @@ __device__ inline double chance_threshold2(float p0, float p1) {
     return c0 / acc;
 }
 
-// The same for FOUR children (round 6, the compile-time K = 4 instantiation): pick = number of t[i] <= u, t[i] = cdf[i] / cdf[3]
-// of pick_chance<4> + sample_cdf<4> -- three float64 quotients, four float32 ones and two np_sums leave every later visit of the
-// node.  Kept in the padding of the block's second 64-byte granule (words 24..29 of 32).
-#ifndef SMZ_THR4
-#define SMZ_THR4 1
-#endif
-__device__ inline void chance_thresholds4(const float (&p)[4], double (&t)[3]) {
-    float tmp[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { const float om = 1.0f - p[j]; tmp[j] = om + 1e-12f; }
-    const float s = np_sum<float, 4>(tmp, 4);
-    const float r = fabsf((float)((double)s / 4.0));
-#pragma unroll
-    for (int j = 0; j < 4; j++) tmp[j] = p[j] + r;
-    const float qs = np_sum<float, 4>(tmp, 4);
-    double cdf[4], acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) { acc += (double)(tmp[j] / qs); cdf[j] = acc; }
-#pragma unroll
-    for (int j = 0; j < 3; j++) t[j] = cdf[j] / acc;
-}
-
 // Correctly rounded x / n for a visit count n in [1, sims + 1] through a table of correctly rounded reciprocals:
 // q = RN(x r) is a faithful quotient, e = x - q n is exact in an FMA, RN(q + e r) = RN(x / n) (Markstein's theorem; its
 // one exception, a divisor whose significand is all ones, cannot be a small integer).  x = sqrt(N) pb_c prior is a
@@ -771,11 +749,6 @@ __device__ inline Leaf select_tree(const Params &P, int tree, RNG &rng, const Tr
             if constexpr (THR) {
                 const double t = *reinterpret_cast<const double *>(tb + P.thr_off + (size_t)(blk - 1) * P.thr_stride);
                 pick = (t <= rng.random_sample()) ? 1 : 0;
-            } else if constexpr (KS == 4 && SMZ_THR4) {       // (expand_backup_tree<.., KS = 4> wrote them: chance_thresholds4)
-                const double2 t01 = *reinterpret_cast<const double2 *>(bp + 24);
-                const double t2 = *reinterpret_cast<const double *>(bp + 28);
-                const double u = rng.random_sample();
-                pick = ((t01.x <= u) ? 1 : 0) + ((t01.y <= u) ? 1 : 0) + ((t2 <= u) ? 1 : 0);
             } else {
                 pick = pick_chance<NK>(k, cnt, rng);
             }
@@ -1047,7 +1020,8 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, Tr
                 if (depth_flag(len))
                     *reinterpret_cast<double *>(tb + P.thr_off + (size_t)e * P.thr_stride) = chance_threshold2(pj[0], pj[1]);
             }
-        } else if (KS == 4) {   // 24 words at fixed offsets: six 16-byte stores (+ the chance thresholds in the granule's padding)
+        } else if (KS == 4) {   // 24 words at fixed offsets: six 16-byte stores (stored chance thresholds as for K = 2 were measured:
+                                // 413 against 415 M, profiles/r06_f_thr4_ab.txt -- three more stores per block cost what the visits save)
             float pj[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; j++) for (int a = 0; a < A; a++) if (a == picks[j]) pj[j] = p[a];
@@ -1058,14 +1032,6 @@ __device__ inline int expand_backup_tree(const Params &P, int tree, RNG &rng, Tr
             nb4[3] = make_uint4(__float_as_uint(pj[0]), __float_as_uint(pj[1]), __float_as_uint(pj[2]), __float_as_uint(pj[3]));   // prior
             nb4[4] = make_uint4(0u, 0u, 0u, 0u);                                              // child
             nb4[5] = make_uint4((uint32_t)picks[0], (uint32_t)picks[1], (uint32_t)picks[2], (uint32_t)picks[3]);                   // action
-            if constexpr (SMZ_THR4) {
-                if (depth_flag(len)) {
-                    double t[3];
-                    chance_thresholds4(pj, t);
-                    *reinterpret_cast<double2 *>(nb + 24) = make_double2(t[0], t[1]);
-                    *reinterpret_cast<double *>(nb + 28) = t[2];
-                }
-            }
         } else {
             for (int j = 0; j < K; j++) {
                 nb[2 * j] = 0u;                              // visit

@@ -791,6 +791,8 @@ constexpr int kFastTpw = 2, kFastS = 31, kFastH = 64, kFastL = 0;
 // search -- a descent level is an LDS round trip instead of an L2 one, the backup's stores stay on the CU -- and go to their
 // place in global memory once, at the end.  LDS room comes from the compact weight image (smz_mlp::mat_op) and from packing
 // expansion blocks at 6 K words instead of 64-byte granules.
+// (round 6: num_simulations as a ninth, compile-time parameter of the headline instantiation -- LDS map, strides and table offsets
+//  as immediates -- measured +0.2 %, inside the spread: profiles/r06_h_sims50_ab.txt; not kept)
 template <int MAXA, int KS, int U, bool INSTR, bool AEX, bool MSK = true, bool PHX = false, bool TLDS = false>
 __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, smz_mlp_desc d, const float *weights, const float *obs,
                                                     int train, ActOut act, EnvStep env) {

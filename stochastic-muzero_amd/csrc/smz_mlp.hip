@@ -97,7 +97,17 @@ __global__ void __launch_bounds__(512) k_mlp_initial(smz_mlp_desc d, const float
 // 16-neuron tiles t): sums in the association of smz_mlp::wave_sum -- registers, lanes ^ 16, ^ 32, then tiles.
 // Bit-identical to k_mlp_recurrent (tests/test_gpu_mlp_heads.py).
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kTileLeaves = 16, kMfmaWaves = 12;   // (twelve: 100 KB of weights + 4 KB per wavefront + the lists = 158 of 160 KB)
+#ifndef SMZ_MFMA_COMPACT
+#define SMZ_MFMA_COMPACT 1         // 0: round 5's launch -- the 64-wide LDS weight image (100 KB) and twelve wavefronts
+#endif
+// Round 6: the COMPACT LDS weight image of the single-launch search (smz_mlp_device.hpp mat_op<true>: the afterstate-dynamics output
+// layer 32 wide, the two prediction output layers 36, 82 KB instead of 100) leaves room for SIXTEEN wavefronts (four per SIMD:
+// 82 KB + 16 x 4 KB of tiles + 8 KB of lists = 154 of 160 KB), and the output tiles a narrow layer does not have are not
+// computed (afterstate rows: 152 instead of 200 MFMAs per tile, dynamics rows 184).  Each wavefront runs one dependent chain per
+// tile (MFMAs, then tails on their results): the matrix pipe was busy 32 % of the launch with three chains per SIMD
+// (profiles/r06_d_pmc_262k.json); and 32 tiles per CU at 131 072 leaves split 2 + 2 over sixteen wavefronts instead of 3 + 3 + 2.
+constexpr bool kMfmaCompact = SMZ_MFMA_COMPACT != 0;
+constexpr int kTileLeaves = 16, kMfmaWaves = kMfmaCompact ? 16 : 12;
 constexpr int kTileFloats = 32 * 32;                 // one activation tile per wavefront: [32 input pairs][16 leaves][2]
 
 __device__ inline float lane_xor16(float v) {
@@ -126,14 +136,15 @@ __device__ inline float tile_min(float m) { m = fminf(m, lane_xor16(m)); return 
 
 // y[t][r] = bias[16t + 4g + r] + sum_k W[k][16t + 4g + r] * x[k][leaf j]: K8 groups of eight inputs, W = LDS weight image
 // (4-way interleaved, 64 outputs wide), xp = activation tile [input pair][leaf][2]
-template <int K8>
-__device__ inline void tile_layer(const float *W, const float *bias, const float *xp, int lane, v4f (&y)[4]) {
+// NT: output tiles of 16 neurons the layer has (the rest of y stays zero); op: neurons per 4-input group in the LDS image
+template <int K8, int NT = 4>
+__device__ inline void tile_layer(const float *W, int op, const float *bias, const float *xp, int lane, v4f (&y)[4]) {
     const int g = lane >> 4, j = lane & 15;
     v4f e[4], o[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const float4 b = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * g);
-        e[t] = v4f{b.x, b.y, b.z, b.w};
+        e[t] = t < NT ? v4f{b.x, b.y, b.z, b.w} : v4f{0.f, 0.f, 0.f, 0.f};
         o[t] = v4f{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -141,9 +152,10 @@ __device__ inline void tile_layer(const float *W, const float *bias, const float
         // B operands: inputs 8c + 2g (even step) and 8c + 2g + 1 (odd step) of leaf j
         const float2 xb = *reinterpret_cast<const float2 *>(xp + ((4 * c + g) * kTileLeaves + j) * 2);
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            // A operands: the weights of inputs 8c + 2g, 8c + 2g + 1 for neuron 16t + j
-            const float2 wa = *reinterpret_cast<const float2 *>(W + ((2 * c + (g >> 1)) * kWave + 16 * t + j) * 4 + 2 * (g & 1));
+        for (int t = 0; t < NT; t++) {
+            // A operands: the weights of inputs 8c + 2g, 8c + 2g + 1 for neuron 16t + j (a lane beyond a narrow layer's width
+            // reads the next group's weights: a finite value for an output nobody uses -- the tails mask by output index)
+            const float2 wa = *reinterpret_cast<const float2 *>(W + ((2 * c + (g >> 1)) * op + 16 * t + j) * 4 + 2 * (g & 1));
             e[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, xb.x, e[t], 0, 0, 0);
             o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, xb.y, o[t], 0, 0, 0);
         }
@@ -196,8 +208,11 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
                                                                           int B, int chunk, TreeRows tr) {
     float *lds = reinterpret_cast<float *>(smz_mlp_lds4);
     d.S = kFastS; d.H = kFastH; d.L = kFastL; d.OP = kWave; d.A = A;
-    const smz_mlp_desc dl = lds_desc_without_rep(d);           // LDS image: everything but the representation matrices
-    stage_weights_without_rep(lds, weights, d);
+    constexpr bool CP = kMfmaCompact;
+    // LDS image: everything but the representation matrices (CP: narrow output layers stored narrow, mat_op<true>)
+    const smz_mlp_desc dl = CP ? lds_desc_compact(d) : lds_desc_without_rep(d);
+    if (CP) stage_weights_compact(lds, weights, d);
+    else stage_weights_without_rep(lds, weights, d);
     constexpr int S = kFastS, half = S / 2, XW = S + A;
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int g = lane >> 4, j = lane & 15;
@@ -297,13 +312,15 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
             }
             lds_sync();
             v4f y[4];
-            const MatOff m_in = pick(dl, !ady, M_DYN_IN, M_ADY_IN), m_out = pick(dl, !ady, M_DYN_OUT, M_ADY_OUT);
-            const MatOff p_in = pick(dl, !ady, M_PRE_IN, M_APR_IN), p_out = pick(dl, !ady, M_PRE_OUT, M_APR_OUT);
-            tile_layer<5>(lds + m_in.w, lds + m_in.b, tile, lane, y);
+            const MatOff m_in = pick<CP>(dl, !ady, M_DYN_IN, M_ADY_IN), m_out = pick<CP>(dl, !ady, M_DYN_OUT, M_ADY_OUT);
+            const MatOff p_in = pick<CP>(dl, !ady, M_PRE_IN, M_APR_IN), p_out = pick<CP>(dl, !ady, M_PRE_OUT, M_APR_OUT);
+            tile_layer<5>(lds + m_in.w, m_in.op, lds + m_in.b, tile, lane, y);
             lds_sync();
             store_trunk(tile, y, lane);
             lds_sync();
-            tile_layer<8>(lds + m_out.w, lds + m_out.b, tile, lane, y);
+            // (afterstate dynamics: S = 31 outputs, two tiles; dynamics: reward + state, 62 outputs, all four)
+            if (CP && ady) tile_layer<8, 2>(lds + m_out.w, m_out.op, lds + m_out.b, tile, lane, y);
+            else tile_layer<8>(lds + m_out.w, m_out.op, lds + m_out.b, tile, lane, y);
             // dynamics: [reward logits 0..S-1 | next state S..2S-1]; afterstate dynamics: next state 0..S-1
             float reward = 0.f;
             {
@@ -360,11 +377,12 @@ __global__ void __launch_bounds__(kMfmaWaves *kWave) k_mlp_recurrent_mfma(smz_ml
                     if (hrow4[u]) *reinterpret_cast<float4 *>(hrow4[u]) = make_float4(lo.x, lo.y, hi.x, hi.y);
                 }
             }
-            tile_layer<4>(lds + p_in.w, lds + p_in.b, tile, lane, y);
+            tile_layer<4>(lds + p_in.w, p_in.op, lds + p_in.b, tile, lane, y);
             lds_sync();
             store_trunk(tile, y, lane);
             lds_sync();
-            tile_layer<8>(lds + p_out.w, lds + p_out.b, tile, lane, y);
+            // (A + S <= 35 outputs: three tiles)
+            tile_layer<8, (CP && A + kFastS <= 48) ? 3 : 4>(lds + p_out.w, p_out.op, lds + p_out.b, tile, lane, y);
             {   // [policy logits 0..A-1 | value logits A..A+S-1]
                 float mp = -__builtin_inff(), mv = -__builtin_inff();
 #pragma unroll
@@ -695,7 +713,7 @@ int smz_mlp_recurrent(const smz_mlp_desc *d, const float *weights_dev, const flo
         // large batches: 16-leaf tiles on the matrix cores (bit-identical; SMZ_MLP_MFMA_MIN = smallest batch that takes it)
         int min_rows = 8192;      // (measured: 242 vs 217 M simulations/s at 8192 trees, 367 vs 278 at 12 288, 132 vs 144 at 4096)
         if (const char *e = getenv("SMZ_MLP_MFMA_MIN")) min_rows = atoi(e);
-        const size_t lds2 = ((size_t)(d->total_floats - rep_floats(*d)) + (size_t)kMfmaWaves * kTileFloats) * sizeof(float) +
+        const size_t lds2 = ((size_t)(kMfmaCompact ? compact_total_floats(*d) : d->total_floats - rep_floats(*d)) + (size_t)kMfmaWaves * kTileFloats) * sizeof(float) +
                             2 * kMaxChunk * sizeof(unsigned short) + 16;
         if (min_rows == 0 && lds2 > (size_t)kLdsBytes) return SMZ_ERR_TOO_LARGE;     // (forced: say so instead of falling back)
         if (min_rows >= 0 && B >= min_rows && lds2 <= (size_t)kLdsBytes) {
@@ -735,7 +753,7 @@ int smz_mlp_recurrent_rows(const smz_mlp_desc *d, const float *weights_dev, floa
         !value_out_dev || B < 1 || nodes_per_tree < 1 || row_stride < d->S)
         return SMZ_ERR_INVALID;
     const int waves = mfma_launch_waves();
-    const size_t lds2 = ((size_t)(d->total_floats - rep_floats(*d)) + (size_t)waves * kTileFloats) * sizeof(float) +
+    const size_t lds2 = ((size_t)(kMfmaCompact ? compact_total_floats(*d) : d->total_floats - rep_floats(*d)) + (size_t)waves * kTileFloats) * sizeof(float) +
                         2 * kMaxChunk * sizeof(unsigned short) + 16;
     if (!(d->S == kFastS && d->H == kFastH && d->L == kFastL && (d->A == 2 || d->A == 4)) || lds2 > (size_t)kLdsBytes)
         return SMZ_ERR_TOO_LARGE;

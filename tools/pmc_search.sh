@@ -9,7 +9,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_
            "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_BUSY_CU_CYCLES" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-include-regex "k_search_mlp" --output-format csv -d $R/gpurun_out/pmcs_$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --min-timed-seconds 0.05 > $R/gpurun_out/pmcs_$i.log 2>&1
+  rocprofv3 --pmc $grp --kernel-include-regex "k_search_mlp" --output-format csv -d $R/gpurun_out/pmcs_$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --also-seconds 0 --min-timed-seconds 0.05 > $R/gpurun_out/pmcs_$i.log 2>&1
   tail -1 $R/gpurun_out/pmcs_$i.log | cut -c1-160
 done
 python3 - <<'PY'
