@@ -496,6 +496,25 @@ def test_networks_too_large_for_lds_fall_back_to_gemm_heads():
     assert m._single is None and m._graph is not None and (v.sum(1) == 8).all()
 
 
+def _held(name, got, want, atol, rtol=0.0):
+    """A float tolerance that follows a MEASUREMENT: the largest error seen is recorded
+    (gpurun_out/measured_tolerances.jsonl, kept as profiles/r06_i_measured_tolerances.jsonl) and the bound asserted is about
+    twice the largest value measured over the round's boxes -- not a round number picked beforehand."""
+    import json
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    err = np.abs(got - want)
+    rel = float((err / np.maximum(np.abs(want), 1e-30)).max())
+    rec = dict(what=name, max_abs=float(err.max()), max_rel=rel, atol=atol, rtol=rtol)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "measured_tolerances.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    assert (err <= atol + rtol * np.abs(want)).all(), rec
+
+
 def _frame(seed):
     return torch.tensor(np.random.RandomState(int(seed)).rand(1, 3, 98, 98).astype(np.float32))
 
@@ -553,8 +572,8 @@ def test_vision_search_reproduces_the_reference_visit_counts(use_graph, backend)
     visits, priors, root_value, _ = eng.root_stats()
     torch.cuda.synchronize()
     assert np.array_equal(visits.cpu().numpy(), data["root_visits"])
-    np.testing.assert_allclose(priors.cpu().numpy(), data["root_priors"], rtol=0, atol=2e-5)
-    np.testing.assert_allclose(root_value.cpu().numpy(), data["root_value"], rtol=5e-5, atol=2e-4)
+    _held(f"vision search ({backend}, graph={use_graph}): f64 root priors vs the reference's run", priors.cpu().numpy(), data["root_priors"], atol=1e-7)        # measured 3.0e-8: one float32 rounding of the policy
+    _held(f"vision search ({backend}, graph={use_graph}): root value vs the reference's run", root_value.cpu().numpy(), data["root_value"], atol=4e-5)      # measured 1.7e-5 (hip) / 8.0e-6 (torch): 0.12 stairs of the decode
 
 
 def test_hip_vision_heads_agree_with_the_torch_modules_on_a_large_batch():
@@ -620,7 +639,7 @@ def test_drop_in_search_with_the_vision_family_on_its_own_inference_functions():
         assert [c.visit_count for c in root.children.values()] == list(data["root_visits"][i])
         # the network runs on THIS host's CPU (ATen picks kernels per ISA): float32 policy rounding, 1e-6 relative
         np.testing.assert_allclose([c.prior for c in root.children.values()], data["root_priors"][i], rtol=1e-6)
-        np.testing.assert_allclose(root.value(), data["root_value"][i], rtol=5e-5, atol=2e-4)
+        _held("vision drop-in search (this host's torch-CPU heads): root value vs the reference's run", [root.value()], [data["root_value"][i]], atol=8e-5)       # measured 0 .. 3.3e-5 over the four seeds (ATen's CPU kernels differ per host ISA)
         assert np.random.random_sample() == data["probe"][i]          # the global stream is where the reference left it
         m.cycle.global_reset()
 
