@@ -342,7 +342,7 @@ int smz_search_mlp_act(smz_handle *h, const smz_mlp_desc *desc, const float *wei
  * towers for the workgroup's 4 leaves at once on the matrix cores (v_mfma_f32_4x4x1 chains, weights in registers; f32 in /
  * f32 accumulate: bit-identical to smz_vision_recurrent).  Results are read as after
  * the step-wise calls.  SMZ_ERR_TOO_LARGE outside the kernel's limits (maxium_action_sample == 2, A <= 4, S <= 32,
- * H <= 64, MT19937 streams, working set <= 160 KB of LDS): use the step-wise entry points then.
+ * H <= 64, working set <= 160 KB of LDS; MT19937 and -- round 6 -- Philox handles alike): use the step-wise entry points then.
  * monte_carlo_tree_search.py:311-349, neural_network_vision_model.py:41-515, muzero_model.py:802-909. */
 int smz_search_vision(smz_handle *h, const smz_vision_desc *desc, const float *weights_dev, const float *hidden0_dev,
                       const float *policy0_dev, int train, smz_stream stream);

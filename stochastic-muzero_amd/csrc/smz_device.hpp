@@ -163,6 +163,13 @@ struct RngT {
     PhiloxState<PHC> ph;    // (PHC) blocks consumed, key, generator switch
     __device__ __forceinline__ bool philox() const { if constexpr (PHC) return ph.on; else return false; }
     __device__ __forceinline__ uint32_t block() const { if constexpr (PHC) return ph.block; else return 0u; }
+    __device__ __forceinline__ uint32_t key0() const { if constexpr (PHC) return ph.k0; else return 0u; }
+    __device__ __forceinline__ uint32_t key1() const { if constexpr (PHC) return ph.k1; else return 0u; }
+    // a helper lane (paired descent) takes over the tree lane's counter stream: block and key.  bind() gave it none -- it is not a
+    // tree lane -- so a draw of the helper beyond the 64 staged words (a path of 20+ levels) would have come from key 0.  Round 6,
+    // found by reading; no search that hits it was found (tests/test_gpu_end_to_end.py test_philox_paired_descent_on_deep_paths
+    // passes with and without: 2 % of its four-action trees end 20-22 levels deep), so this is a precaution, not a measured fix.
+    __device__ __forceinline__ void follow(uint32_t block, uint32_t k0, uint32_t k1) { if constexpr (PHC) { ph.block = block; ph.k0 = k0; ph.k1 = k1; } }
     __device__ __forceinline__ void wrapped() { if constexpr (PHC) ++ph.block; }
     __device__ __forceinline__ void load(uint32_t *state, int packed, const uint32_t *lds_row, int n_staged) {
         mt = state; idx = packed & 0xffff; ready = packed >> 16; stage = lds_row; staged = n_staged; used = 0;

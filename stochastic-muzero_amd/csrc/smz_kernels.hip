@@ -1073,11 +1073,14 @@ __global__ void __launch_bounds__(SMZ_SEARCH_THREADS) k_search_mlp(Params Pin, s
 
             const float hmn = pick_lane01(h.mn, src), hmx = pick_lane01(h.mx, src);
             const int hrv = pick_lane01(h.root_visit, src);
+            const uint32_t pb = (uint32_t)pick_lane01((int)rng.block(), src), pk0 = (uint32_t)pick_lane01((int)rng.key0(), src),
+                           pk1 = (uint32_t)pick_lane01((int)rng.key1(), src);
             if (lane < 4 && SMZ_SLOT_VALID(src)) {
                 TreeHdr hs = h;
                 if (lane >= 2) {
                     rng.load(P.mt + (size_t)(tree0 + src) * kMtN, pk, rng_tile + src * kRngStride, kRngStage);
                     rng.used = us;
+                    rng.follow(pb, pk0, pk1);      // (Philox: the helper draws beyond the staged window from the TREE's stream)
                     hs.mn = hmn; hs.mx = hmx; hs.root_visit = hrv;
                 }
                 int len = 0;

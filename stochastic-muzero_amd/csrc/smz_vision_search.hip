@@ -226,7 +226,9 @@ extern __shared__ float4 smz_vsearch_lds4[];
 
 // AEQ: the action count equals its bucket MAXA -- a compile-time constant then for everything inlined below (the per-action
 // arrays of the root level stay in registers instead of scratch memory)
-template <int MAXA, bool AEQ>
+// PHX (round 6): the handle draws from Philox4x32-10 counter streams (SMZ_RNG_PHILOX) -- before, such a handle was refused here and
+// ran the step-wise kernels.  The MT19937 instantiations are unchanged (RngT<false> carries no Philox state).
+template <int MAXA, bool AEQ, bool PHX = false>
 // -DSMZ_VISION_WPE=2 (A/B builds only, tools/vision_wpe_ab.sh): register-allocate for TWO wavefronts per SIMD (256 registers a
 // lane instead of 512; the tower weights no longer fit and spill) -- the measurement behind DESIGN 9.3's occupancy argument
 #ifdef SMZ_VISION_WPE
@@ -240,6 +242,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
     constexpr int KS = 2, VT = 1;
     Params P = Pin;
     P.K = KS; P.tpw = VT;
+    P.philox = PHX ? 1 : 0;         // (a constant in everything inlined below)
     if (AEQ) P.A = MAXA;            // (not d.A: a modified copy of the descriptor, indexed at run time, would live in scratch)
     fix_layout(P, AEQ, true);
     // block-parallel selection (two actions, two children, at most 126 simulations: 7-bit block indices): chance thresholds
@@ -346,8 +349,8 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
         if (lane < A) outs[lane] = policy0[(size_t)tree0 * A + lane];
     }
     lds_sync();
-    int packed = wave_stage_rng<false>(P, tree, valid, rng_tile);
-    RngMt rng;
+    int packed = wave_stage_rng<PHX>(P, tree, valid, rng_tile);
+    RngT<PHX> rng;
     rng.bind(P, tree, valid);
     TreeHdr h = {0, 0, 0.f, 0.f, 0, 0.f, 0, 0};
     if (valid) {
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
         packed = rng.pack();
     }
     unsigned n_dec = 0, n_chance = 0, n_children = 0;
-    if (P.sims > 0) packed = wave_stage_rng_from<4, false>(P, tree, valid, rng_tile, packed);
+    if (P.sims > 0) packed = wave_stage_rng_from<4, PHX>(P, tree, valid, rng_tile, packed, rng.block());
 
     // (SMZ_DEBUG_SKIP=16 with statistics on: s_memtime phase accounting per wave in LDS -> stats[8..15] = tree | parent-row
     //  load | transition convolutions | prediction convolutions | barrier wait | layer 1 | hidden + output layers | tails +
@@ -417,7 +420,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
                 if (b <= nexp) {
                     const int depth = b == 0 ? 0 : (int)(selw[b] >> 9);
                     // (LF: a block's auxiliary words requested with its children's fields -- one wavefront per SIMD: every LDS round trip counts)
-                    const uint32_t r = select_block<MAXA, false, RngMt, SMZ_VISION_BPS_LF>(P, stb, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged, pbc_lds);
+                    const uint32_t r = select_block<MAXA, false, RngT<PHX>, SMZ_VISION_BPS_LF>(P, stb, b, depth, rvis, bmn, bmx, rng_tile + bstage, bused, bstaged, pbc_lds);
                     selw[b] = (uint16_t)((depth << 9) | r);
                 }
             }
@@ -439,7 +442,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // (planes stored in earlier rounds may be this round's parents)
                 const float *hrow = P.hidden + ((size_t)tree0 * P.N + parent) * P.hs;
                 early_x[0] = hrow[p]; early_x[1] = hrow[kPix + p]; early_x[2] = hrow[2 * kPix + p];
-                stage_issue<VT, false>(P, tree, valid, packed, pre);
+                stage_issue<VT, PHX>(P, tree, valid, packed, pre);
                 if (SMZ_VISION_BPS_LF && valid) L = select_leaf(P, stb, pathw, len);      // (its word requested before the records')
                 for (int dd = lane; dd < blen; dd += kWave) select_record(P, stb, pathw, dd, pvals);
                 if (valid) { if (!SMZ_VISION_BPS_LF) L = select_leaf(P, stb, pathw, len); h.path_len = len; }
@@ -449,6 +452,8 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
         if (bps_done) {
         } else if constexpr (MAXA == 2) {
             const int pk = __builtin_amdgcn_readlane(valid ? rng.pack() : 0, 0), us = __builtin_amdgcn_readlane(valid ? rng.used : 0, 0);
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)rng.block(), 0), pk0 = (uint32_t)__builtin_amdgcn_readlane((int)rng.key0(), 0),
+                           pk1 = (uint32_t)__builtin_amdgcn_readlane((int)rng.key1(), 0);
             const float hmn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.mn), 0));
             const float hmx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.mx), 0));
             const int hrv = __builtin_amdgcn_readlane(h.root_visit, 0);
@@ -457,6 +462,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
                 if (lane == 2) {
                     rng.load(P.mt + (size_t)tree0 * kMtN, pk, rng_tile, kRngStage);
                     rng.used = us;
+                    rng.follow(pb, pk0, pk1);      // (Philox: the helper draws beyond the staged window from the TREE's stream)
                     hs.mn = hmn; hs.mx = hmx; hs.root_visit = hrv;
                 }
                 int len = 0;
@@ -478,7 +484,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
         // hidden rows written in earlier rounds (by this wave) may be this round's parent rows
         if (!bps_done) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            stage_issue<VT, false>(P, tree, valid, packed, pre);
+            stage_issue<VT, PHX>(P, tree, valid, packed, pre);
         }
         // ---- convolutional part of this wave's leaf: flat inputs of its towers into the tiles ------------------------------
         const bool dyn = __builtin_amdgcn_readlane(L.branch, 0) != 0;
@@ -589,7 +595,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
             if (lane == 0) { outs[A] = value; outs[A + 1] = reward; }
         }
         lds_sync();
-        packed = stage_finish<VT, false>(P, tree, valid, rng_tile, packed, pre);
+        packed = stage_finish<VT, PHX>(P, tree, valid, rng_tile, packed, pre, rng.block());
         SMZ_VSTAMP(7)
     }
 #undef SMZ_VSTAMP
@@ -613,6 +619,7 @@ __global__ void __launch_bounds__(kVW *kWave) SMZ_VISION_OCC k_search_vision(Par
             packed = rng.pack();
         }
         P.rng_pos[tree] = packed;
+        rng.save(P, tree);
     }
     lds_sync();
     if (live0) {                                                         // the finished tree back to its place in global memory
@@ -630,9 +637,9 @@ int search_vision_launch(smz_handle *h, const smz_vision_desc *desc, const float
         return fail(SMZ_ERR_INVALID, "smz_search_vision: descriptor does not describe a vision_model weight buffer%s");
     if (desc->A != h->P.A || h->P.S != kFlat)
         return fail(SMZ_ERR_INVALID, "smz_search_vision: network dimensions differ from the handle's (hidden_size must be 147)%s");
-    if (h->K != 2 || h->P.A > 4 || desc->S > 32 || desc->H > 64 || h->P.philox)
-        return fail(SMZ_ERR_TOO_LARGE, "smz_search_vision: outside the single-launch kernel's limits (K = 2, A <= 4, S <= 32, H <= 64, "
-                                       "MT19937 streams): use the step-wise entry points%s");
+    if (h->K != 2 || h->P.A > 4 || desc->S > 32 || desc->H > 64)
+        return fail(SMZ_ERR_TOO_LARGE, "smz_search_vision: outside the single-launch kernel's limits (K = 2, A <= 4, S <= 32, H <= 64): "
+                                       "use the step-wise entry points%s");
     if (train && h->cfg.num_simulations > 0 && !(h->cfg.root_dirichlet_alpha > 0))
         return fail(SMZ_ERR_INVALID, "root_dirichlet_alpha must be > 0 to draw noise (numpy raises ValueError)%s");
     DeviceGuard guard(h->cfg.device);
@@ -651,25 +658,28 @@ int search_vision_launch(smz_handle *h, const smz_vision_desc *desc, const float
     const size_t lds = (size_t)ml.total * sizeof(float);
     if (lds > 160 * 1024) return fail(SMZ_ERR_TOO_LARGE, "smz_search_vision: working set exceeds the 160 KB LDS of a CU%s");
     const int blocks = (P.B + kVW - 1) / kVW;
-#define SMZ_LAUNCH_VS(MA, EQ)                                                                                          \
+#define SMZ_LAUNCH_VS(MA, EQ) { if (P.philox) SMZ_LAUNCH_VS2(MA, EQ, true) else SMZ_LAUNCH_VS2(MA, EQ, false) }
+#define SMZ_LAUNCH_VS2(MA, EQ, PX)                                                                                     \
     {                                                                                                                  \
         static size_t granted_dev[64] = {};                                                                            \
         size_t &granted = granted_dev[h->cfg.device & 63];                                                             \
         if (lds > granted) {                                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_vision<MA, EQ>),                           \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_vision<MA, EQ, PX>),                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)               \
                 return fail(SMZ_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS) failed%s");                             \
             granted = lds;                                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_search_vision<MA, EQ>), dim3(blocks), dim3(kVW * kWave), lds, (hipStream_t)stream, P,    \
+        hipLaunchKernelGGL((k_search_vision<MA, EQ, PX>), dim3(blocks), dim3(kVW * kWave), lds, (hipStream_t)stream, P, \
                            *desc, weights_dev, hidden0_dev, policy0_dev, train, act);                                  \
-        snprintf(h->last_kernel, sizeof(h->last_kernel), "k_search_vision<%d, %s>", MA, EQ ? "true" : "false");        \
+        snprintf(h->last_kernel, sizeof(h->last_kernel), PX ? "k_search_vision<%d, %s, true>" : "k_search_vision<%d, %s>", MA, \
+                 EQ ? "true" : "false");                                                                               \
     }
     if (h->maxa == 2 && P.A == 2) SMZ_LAUNCH_VS(2, true)
     else if (h->maxa == 2) SMZ_LAUNCH_VS(2, false)
     else if (P.A == 4) SMZ_LAUNCH_VS(4, true)
     else SMZ_LAUNCH_VS(4, false)
 #undef SMZ_LAUNCH_VS
+#undef SMZ_LAUNCH_VS2
     h->root_ready = true;
     h->selected = false;
     return launch_check();

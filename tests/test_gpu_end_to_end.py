@@ -775,10 +775,13 @@ def test_env_step_with_record_equals_step_then_pack():
                                           ("visionnet_L2_bn", 200, 16), ("visionnet_L1_seed0", 16, 0),
                                           # round 5: the block-parallel selection -- two passes of 64 blocks, its largest search, one beyond
                                           ("visionnet_L1_seed0", 64, 100), ("visionnet_L1_seed0", 48, 126), ("visionnet_L1_seed0", 32, 127)])
-def test_vision_single_launch_search_equals_stepwise_search(wname, B, sims):
+@pytest.mark.parametrize("rng", ["mt19937", "philox"])
+def test_vision_single_launch_search_equals_stepwise_search(wname, B, sims, rng):
     """smz_search_vision (whole vision search in one kernel: towers of 16 leaves on the matrix cores) against the
     step-wise kernels (one wavefront per leaf, towers as k-ordered fma chains on the vector units): an f32-input MFMA is
-    that chain, so every tree, value and stream position must be identical -- two consecutive searches per engine."""
+    that chain, so every tree, value and stream position must be identical -- two consecutive searches per engine.
+    rng = philox (round 6): k_search_vision<..., PHX> -- a Philox handle used to be refused by the single launch."""
+    import stochastic_muzero_amd as smz
     mcts_mod, model_mod, _, _ = _mods()
     model = model_mod.Muzero.from_state_dicts(os.path.join(gu.GOLDEN, wname + ".npz"))
     heads = model.heads("cuda:0", backend="hip")
@@ -786,25 +789,78 @@ def test_vision_single_launch_search_equals_stepwise_search(wname, B, sims):
     res = []
     for single in (True, False):
         m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997,
-                                 root_exploration_fraction=0.25, use_graph=False, single_launch=single)
+                                 root_exploration_fraction=0.25, use_graph=False, single_launch=single,
+                                 rng_mode=smz._lib.RNG_PHILOX if rng == "philox" else smz._lib.RNG_MT19937_NUMPY)
         m.seed(np.arange(B, dtype=np.uint64) + 9)
         for rep in range(2):
             e = m.run(obs, heads, train=True, act_temperature=(1.0 if single and rep == 1 else None))
         assert m._single is (True if single else None)
+        if single:
+            assert e.last_kernel().startswith("k_search_vision<") and e.last_kernel().count(",") == (2 if rng == "philox" else 1), e.last_kernel()
         action, policy, cv, rv2 = (t.clone() for t in e.act(1.0))
         visits, priors, rv, cr = e.root_stats()
         torch.cuda.synchronize()
         out = [t.cpu().numpy().copy() for t in (visits, priors, rv, cr, action, policy, cv)]
         dumps = [e.dump_tree(i) for i in (0, B // 2, B - 1)]
-        states = [e.get_rng_state(i) for i in (0, B - 1)]
+        states = [e.philox_position(i) if rng == "philox" else e.get_rng_state(i) for i in (0, B - 1)]
         res.append((out, dumps, states))
     for a, b in zip(res[0][0], res[1][0]):
         assert np.array_equal(a, b)
     for da, db in zip(res[0][1], res[1][1]):
         for k in da:
             assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
-    for (ka, pa), (kb, pb) in zip(res[0][2], res[1][2]):
-        assert np.array_equal(ka, kb) and pa == pb
+    for x, y in zip(res[0][2], res[1][2]):
+        if rng == "philox":
+            assert x == y
+        else:
+            assert np.array_equal(x[0], y[0]) and x[1] == y[1]
+
+
+@pytest.mark.parametrize("wname,A,sims", [("weights_ckpt421", 2, 140), ("weights_lunar_L0", 4, 140)])
+def test_philox_paired_descent_on_deep_paths(wname, A, sims, tmp_path):
+    """The paired descent under Philox streams on DEEP paths.  A helper lane scores one of the level's children from a copy of the
+    tree lane's stream position; round 6 also hands it the tree's counter block and key (bind() gives a non-tree lane none, so a
+    helper draw beyond the 64 staged words -- 20+ levels -- would come from key 0).  One-sided policies make every search one long
+    line (the oracle: last paths up to 27 levels for two actions, 22 for four, at 140 simulations); more than 126 simulations keep
+    the two-action kernel off the block-parallel selection.  Single launch (k_search_mlp<MAXA, 2, ..., PHX, false>) == step-wise
+    kernels (one lane per tree), every tree's root statistics and 43 dumped trees, bit for bit.  (It passes on a build without
+    the hand-over too: no tree of this workload draws there -- the change is a precaution.)"""
+    import stochastic_muzero_amd as smz
+    mcts_mod, model_mod, _, _ = _mods()
+    z = dict(np.load(os.path.join(gu.GOLDEN, wname + ".npz")))
+    for head in ("pre", "apr"):
+        z[head + "_pol_w"] = np.zeros_like(z[head + "_pol_w"])
+        z[head + "_pol_b"] = np.array([8.0] + [-8.0] * (A - 1), np.float32)
+    wpath = os.path.join(tmp_path, "one_sided.npz")
+    np.savez(wpath, **z)
+    model = model_mod.Muzero.from_arrays(wpath)
+    heads = model.heads("cuda:0", backend="hip")
+    B = 4096
+    obs = torch.randn(B, model.observation_dimension, generator=torch.Generator().manual_seed(9)).mul(0.05).cuda()
+    res = []
+    for single in (True, False):
+        m = mcts_mod.BatchedMCTS(B, num_simulations=sims, maxium_action_sample=2, discount=0.997, root_exploration_fraction=0.25,
+                                 use_graph=False, single_launch=single, rng_mode=smz._lib.RNG_PHILOX)
+        m.seed(np.arange(B, dtype=np.uint64) + 17)
+        e = m.run(obs, heads, train=True)
+        assert m._single is (True if single else None)
+        visits, priors, rv, cr = e.root_stats()
+        torch.cuda.synchronize()
+        picks = tuple(range(0, B, 97))
+        if single:
+            assert e.last_kernel() == f"k_search_mlp<{A}, 2, 1, false, true, true, true, false>", e.last_kernel()
+        res.append(([t.cpu().numpy().copy() for t in (visits, priors, rv, cr)], [e.dump_tree(i) for i in picks],
+                    [e.philox_position(i) for i in picks]))
+    deepest = max(len(d["path"]) for d in res[0][1])
+    # beyond the 64 staged words (2 A + 4 per decision level + 2 per chance level): two-action lines get there; four-action trees
+    # spread at their chance levels and stay shallower -- that case still pins the paired four-action descent under Philox
+    assert deepest >= (19 if A == 2 else 10), deepest
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    for da, db in zip(res[0][1], res[1][1]):
+        for k in da:
+            assert np.array_equal(np.asarray(da[k]), np.asarray(db[k])), k
+    assert res[0][2] == res[1][2]
 
 
 @pytest.mark.parametrize("A,L,B,sims", [(4, 1, 130, 14), (3, 0, 64, 9)])
