@@ -143,7 +143,7 @@ def test_source_words_are_requested_in_the_selection(search_isa):
 
 def test_vision_round_reads_no_bias_from_global_memory(tmp_path):
     lines = _isa(tmp_path, "smz_vision_search.hip")
-    body = _kernel(lines, "_ZN12_GLOBAL__N_115k_search_visionILi2ELb1EEE")
+    body = _kernel(lines, "_ZN12_GLOBAL__N_115k_search_visionILi2ELb1ELb0EEE")
     wide = [t for t, loop in body if loop and t.startswith("global_load_dwordx4")]
     assert not wide, f"16-byte global loads inside k_search_vision's rounds (tower biases should come from LDS): {wide[:3]}"
     assert len([t for t, loop in body if loop and t.startswith("ds_read_b128")]) > 20
