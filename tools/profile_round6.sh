@@ -22,7 +22,10 @@ for f in glob.glob(O+"/pmc_traffic/**/*counter_collection.csv", recursive=True):
 m={c: sum(x)/len(x) for c,x in agg.items()}
 kn=kernels.most_common(1)[0][0] if kernels else ""
 mm=re.search(r"(k_search_\w+<[^>]*>)", kn)
-out={"kernel": mm.group(1) if mm else kn, "kernel_name_as_profiled": kn, "workload": workload, "source_sha16": bench.kernel_source_sha16(),
+name=mm.group(1) if mm else kn
+if name.startswith("k_search_vision<") and name.endswith(", false>") and name.count(",") == 2:
+    name=name[:-len(", false>")]+">"        # smz_last_kernel names the MT19937 instantiation without its defaulted PHX parameter
+out={"kernel": name, "kernel_name_as_profiled": kn, "workload": workload, "source_sha16": bench.kernel_source_sha16(),
      "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum> --kernel-include-regex %s -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline %s (three separate passes; tools/profile_round6.sh)" % (rx, extra),
      "FETCH_SIZE_KB_per_launch": m.get("FETCH_SIZE"), "WRITE_SIZE_KB_per_launch": m.get("WRITE_SIZE"),
      "TCC_HIT_sum": m.get("TCC_HIT_sum"), "TCC_MISS_sum": m.get("TCC_MISS_sum"), "launches": {c: len(x) for c,x in agg.items()}}
