@@ -173,9 +173,13 @@ class ArrayGameRecord(GameRecord):
     arrays when they were computed for the same td_steps and the game's lists have not been modified; otherwise by
     GameRecord's own loops over the lists."""
 
+    # (class-level defaults: a record that was never reanalysed / never had an env carries neither in its dict -- 4096 records are
+    #  built per chunk, and every attribute store is ~0.1 us of the loop's exposed host half)
+    reanalyzed, env = False, None
+
     def __init__(self, src, e, t0, t1, done, top=None):
-        self._src, self._e, self._t0, self._t1, self._top = src, e, t0, t1, top      # top: max priority of the window (or None)
-        self.done, self.reanalyzed, self.env = done, False, None
+        d = self.__dict__
+        d["_src"] = src; d["_e"] = e; d["_t0"] = t0; d["_t1"] = t1; d["_top"] = top; d["done"] = done   # top: max priority of the window (or None)
 
     def __getattr__(self, name):                      # only reached for attributes not set yet
         if name in _COLUMNS:
