@@ -8,7 +8,7 @@ Per step t (self_play.py:79-94 for 4096 envs at once):
   2. the 4096 oracle trees (oracle/smz_oracle.c, pinned to the reference's goldens; streams continuing too) replay the tape:
      same leaf / parent / action / branch at every simulation, then S == oracle on visits, all tree arrays, MinMax, root
      value, f64 priors and stream position, bit for bit;
-  3. the production launch runs on the same observations: its trees equal the oracle's (priors 1e-13: device-drawn noise),
+  3. the production launch runs on the same observations: its trees equal the oracle's (float64 priors included, with device-drawn noise),
      its action / policy / child_visits / root value equal orc_act's (which draws from the continuing stream where
      game.py:213 draws), and its stream positions AFTER the action draw equal the oracle's -- so the next step starts from
      the reference's stream state, including the partially twisted MT19937 block (`rng_pos` = ready << 16 | idx) that is

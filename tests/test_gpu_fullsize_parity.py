@@ -11,9 +11,9 @@ The chain closed here, at BASELINE.json's sizes (4096 trees x 50 / 100 simulatio
   3. the single-launch kernel (smz_search_mlp_act) on the same seeds and observations must equal both -- every
      tree -- and so must the action / policy / child_visits it writes in its tail (oracle: orc_act).
 
-Given identical network outputs the tree arithmetic is integer / IEEE-exact, so there is no tolerance anywhere except
-the float64 root priors of the single-launch run, whose Dirichlet sample is drawn with the device's log / pow
-(1e-13 relative).  monte_carlo_tree_search.py:311-349, game.py:179-232.
+Given identical network outputs the tree arithmetic is integer / IEEE-exact, so there is no tolerance anywhere -- since round 6
+not on the float64 root priors of the single-launch run either, whose Dirichlet sample the device draws with glibc's log / pow
+restated operation by operation (rounds 1-5: 1e-13 relative).  monte_carlo_tree_search.py:311-349, game.py:179-232.
 """
 import os
 from importlib import import_module

@@ -29,8 +29,8 @@ def _noise_from_oracle(cfg, data):
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("name", gu.SEARCH_FIXTURES)
 def test_tape_driven_search_matches_reference(name, fused):
-    """Device-drawn Dirichlet noise: everything integer is exact; float64 root priors to 1e-13 relative (the
-    device log/pow are not glibc's); the number of exactly equal priors is reported."""
+    """Device-drawn Dirichlet noise: everything integer is exact, and since round 6 the float64 root priors too (glibc's log / pow
+    restated on the device, csrc/smz_glibc_math.hpp; rounds 1-5: 1e-13 relative)."""
     import gpu_harness as gh
     eng, cfg, data = gh.drive_fixture(name, fused=fused)
     gh.check_fixture_outputs(eng, cfg, data, prior_exact=False)
