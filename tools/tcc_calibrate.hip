@@ -12,6 +12,7 @@ __device__ inline uint64_t line_of(uint64_t i, uint64_t salt) { return ((i + sal
 using v4 = __attribute__((ext_vector_type(4))) uint32_t;
 using v2 = __attribute__((ext_vector_type(2))) uint32_t;
 
+
 __global__ void cal_read16(const uint8_t *buf, uint32_t *out, uint64_t salt) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const v4 x = *(const v4 *)(buf + line_of(i, salt) * 64);
@@ -75,6 +76,28 @@ __global__ void cal_coalesced_write16(uint8_t *buf) {
     *(v4 *)(buf + i * 16) = v4{(uint32_t)i, 1u, 2u, 3u};
 }
 
+// The large-batch tree kernel's shape in miniature: one tree per lane, a DEPENDENT descent over `levels` 48-byte blocks
+// of the lane's own 3.3 KB tree region (the next address is computed from the loaded words), then one 8-byte store into every
+// visited block -- with one block per 64-byte line (today's layout), or with the blocks of consecutive levels PAIRED in one
+// line (what co-locating a node's block with its most-visited child's would give when every transition pairs: the upper bound).
+template <int PAIRED>
+__global__ void cal_descent(uint8_t *buf, int levels, uint64_t trees) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= trees) return;
+    uint8_t *tree = buf + t * 3328;                       // 52 lines per tree, as 50 simulations of two-child blocks
+    uint32_t line = 0, carry = 0;
+    uint32_t at[8];
+    for (int l = 0; l < levels; l++) {
+        const uint32_t off = PAIRED ? (line * 64 + (l & 1) * 32) : line * 64;
+        const uint8_t *p = tree + off;
+        const v4 a = *(const v4 *)p, b = *(const v4 *)(p + 16);
+        carry += a.x + b.y;                               // (zero-filled buffer: the value is 0, the dependency is real)
+        at[l] = off;
+        if (!PAIRED || (l & 1)) line = (line * 7 + 5 + carry) % 52;      // next block's line: scattered inside the tree's region
+    }
+    for (int l = 0; l < levels; l++) *(v2 *)(tree + at[l]) = v2{carry + (uint32_t)l, 1u};
+}
+
 int main() {
     uint8_t *buf; uint32_t *out;
     CHECK(hipMalloc(&buf, LINES * 64));
@@ -99,6 +122,13 @@ int main() {
         RUN(cal_rmw8_after_read48, buf, salt);
         hipLaunchKernelGGL(cal_coalesced_read16, g, b, 0, 0, buf + (size_t)(3ull << 30), out); CHECK(hipDeviceSynchronize());
         hipLaunchKernelGGL(cal_coalesced_write16, g, b, 0, 0, buf + (size_t)(3ull << 30) + (1ull << 28)); CHECK(hipDeviceSynchronize());
+    }
+    {   // 1 M trees x 6 levels: one block per line vs two levels per line
+        const uint64_t trees = 1ull << 20;
+        for (int rep = 0; rep < 3; rep++) {
+            hipLaunchKernelGGL(cal_descent<0>, dim3((unsigned)(trees / 64)), dim3(64), 0, 0, buf, 6, trees); CHECK(hipDeviceSynchronize());
+            hipLaunchKernelGGL(cal_descent<1>, dim3((unsigned)(trees / 64)), dim3(64), 0, 0, buf, 6, trees); CHECK(hipDeviceSynchronize());
+        }
     }
     printf("accesses per kernel: %llu\n", (unsigned long long)N);
     return 0;

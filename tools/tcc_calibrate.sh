@@ -26,6 +26,8 @@ for k,cs in sorted(agg.items()):
 for f in glob.glob(O+"/cal_time/**/*kernel_stats.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k=row["Name"].split("(")[0]
+        if k.startswith("void cal_descent"):
+            out[k.replace("void ","")]={"launch_us": float(row["AverageNs"])/1e3, "trees": 1<<20, "levels": 6, "ns_per_tree": float(row["AverageNs"])/(1<<20)}
         if k in out:
             us=float(row["AverageNs"])/1e3
             out[k]["launch_us"]=us; out[k]["G_accesses_per_s"]=N/us/1e3
