@@ -209,12 +209,13 @@ class TrajectoryGather:
         (clearing the list under live sends / receives left them writing into freed buffers), errors of the wait are
         swallowed -- the exchange has failed already -- and the per-chunk sizes are forgotten."""
         pend, self._pending, self._sizes = self._pending, [], None
-        for works, _, _ in pend:
-            for w in works or ():
-                try:
-                    w.wait()
-                except Exception:                   # noqa: BLE001
-                    pass
+        for works, _, _ in pend:                    # (staged / inactive entries carry no work handles)
+            for w in (works if isinstance(works, list) else ()):
+                if hasattr(w, "wait"):
+                    try:
+                        w.wait()
+                    except Exception:               # noqa: BLE001
+                        pass
 
     def exposed_gather_ms(self):
         """After a synchronisation: device time between the end of the search and the end of the exchange in the last finish()
