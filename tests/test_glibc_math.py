@@ -16,6 +16,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _L = None
 
 
+def _same_libm_as_restated():
+    """The restatement follows the FMA build of glibc 2.35's log / pow (what this image's libm resolves to on a CPU with FMA + AVX2).
+    On another glibc, or a CPU without FMA (libm then resolves to its SSE2 build: other fusions, other last bits), THIS machine's
+    libm is not the thing restated and cannot serve as the checker: the comparisons are skipped, not failed."""
+    import platform
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        flags = ""
+    return platform.libc_ver()[1].startswith("2.35") and " fma " in flags and " avx2 " in flags
+
+
+pytestmark = pytest.mark.skipif(not _same_libm_as_restated(), reason="this machine's libm is not glibc 2.35's FMA build (the code restated)")
+
+
 def glc():
     global _L
     if _L is None:

@@ -9,9 +9,9 @@ import pytest
 import torch
 
 import stochastic_muzero_amd as smz
-from test_glibc_math import glc
+from test_glibc_math import _same_libm_as_restated, glc
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _same_libm_as_restated(), reason="the host's libm is not glibc 2.35's FMA build (the code restated)")]
 
 
 def P(t):
