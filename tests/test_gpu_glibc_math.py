@@ -26,7 +26,7 @@ def device_log_pow(x, y=None):
         assert lib.smz_debug_glibc_log_pow(P(dx), None, dx.numel(), P(ol), None, None) == 0
         torch.cuda.synchronize()
         return ol.cpu().numpy(), None
-    dy = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(y, np.shape(x)), np.float64)).cuda()
+    dy = torch.from_numpy(np.array(np.broadcast_to(y, np.shape(x)), np.float64)).cuda()      # (a writable copy)
     op = torch.empty_like(dx)
     assert lib.smz_debug_glibc_log_pow(P(dx), P(dy), dx.numel(), P(ol), P(op), None) == 0
     torch.cuda.synchronize()
